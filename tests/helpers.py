@@ -1,0 +1,36 @@
+"""Shared test helpers: tiny hand-built scenes and numpy views of scenes."""
+import numpy as np
+import torch
+
+from styl3r_amd.camera import build_view_setup
+
+
+def simple_camera(H=32, W=32, fx=0.86, near=1.0, far=100.0, c2w=None):
+    """One pinhole camera; returns dict of numpy float64 arrays in rasterizer convention."""
+    ext = torch.eye(4)[None] if c2w is None else torch.as_tensor(c2w, dtype=torch.float32)[None]
+    K = torch.tensor([[[fx, 0, 0.5], [0, fx, 0.5], [0, 0, 1.0]]])
+    vs = build_view_setup(ext, K, torch.tensor([near]), torch.tensor([far]))
+    return dict(H=H, W=W, tanfovx=float(vs.tanfovx[0]), tanfovy=float(vs.tanfovy[0]),
+                view=vs.viewmatrix[0].numpy().astype(np.float64), proj=vs.projmatrix[0].numpy().astype(np.float64),
+                proj_raw=vs.projmatrix_raw[0].numpy().astype(np.float64), campos=vs.campos[0].numpy().astype(np.float64))
+
+
+def iso_cov6(s):
+    """isotropic covariance s^2 I as the 6-vector xx,xy,xz,yy,yz,zz"""
+    return np.array([s * s, 0, 0, s * s, 0, s * s], dtype=np.float64)
+
+
+def random_scene(G, seed=0, z_range=(2.0, 6.0), spread=1.2, scale=(0.02, 0.12), sh_degree=0, op_range=(0.2, 0.95)):
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(*z_range, G)
+    xy = rng.uniform(-spread, spread, (G, 2)) * z[:, None] * 0.4
+    means = np.concatenate([xy, z[:, None]], 1)
+    A = rng.normal(size=(G, 3, 3))
+    Q, _ = np.linalg.qr(A)
+    s = rng.uniform(*scale, (G, 3)) * z[:, None] * 0.3
+    cov = Q @ (s[:, :, None] ** 2 * np.eye(3)) @ Q.transpose(0, 2, 1)
+    cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+    opac = rng.uniform(*op_range, G)
+    M = (sh_degree + 1) ** 2
+    shs = rng.normal(size=(G, M, 3)) * (0.5 / np.sqrt(np.arange(M) + 1.0))[None, :, None]
+    return means, cov6, opac, shs
