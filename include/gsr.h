@@ -1,0 +1,132 @@
+/*
+ * gsr.h -- C ABI of libgsr_hip.so: the MI355X (gfx950) Gaussian-splatting
+ * rasterizer that replaces the third-party CUDA extension
+ * `diff_gaussian_rasterization` (requirements.txt:17 of the reference) behind
+ * the reference's own call site src/model/decoder/cuda_splatting.py:101-129.
+ *
+ * Plain C: device pointers, sizes, a hipStream_t passed as void*.  No torch
+ * types, no global state, re-entrant per stream, never throws; every entry
+ * point returns 0 or a negative GSR_E* code.  The caller owns ALL memory
+ * (outputs, the opaque workspace that carries geometry/binning/image state
+ * from forward to backward -- the counterpart of upstream's geomBuffer /
+ * binningBuffer / imgBuffer).
+ *
+ * Reference interface each entry point replaces:
+ *   gsr_forward   <- _C.rasterize_gaussians(...)           as invoked by
+ *                    GaussianRasterizer.forward, cuda_splatting.py:120-129
+ *                    (one call per view there; V views per call here)
+ *   gsr_backward  <- _C.rasterize_gaussians_backward(...)  invoked by autograd
+ *                    for the same call (grads for means3D, means2D, shs /
+ *                    colors_precomp, opacities, cov3D_precomp, theta, rho)
+ *   GsrView       <- GaussianRasterizationSettings fields  cuda_splatting.py:101-115
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_EINVAL (-1)     /* bad dimension / null pointer / unsupported degree */
+#define GSR_ENOSPACE (-2)   /* workspace_bytes too small for (dims, pair_capacity) */
+#define GSR_ELAUNCH (-3)    /* a kernel launch failed (hipGetLastError != success) */
+
+#define GSR_TILE 16
+#define GSR_VIEW_FLOATS 64
+
+/* Per-view camera block, 64 floats = 256 B, array of V in DEVICE memory.
+ * Matrices are the row-vector ("transposed") 4x4 form the reference passes
+ * (cuda_splatting.py:85-88), flat index m[4*r+c]. */
+typedef struct GsrView {
+    float viewmatrix[16];     /* settings.viewmatrix      (:108) */
+    float projmatrix[16];     /* settings.projmatrix      (:109) */
+    float projmatrix_raw[16]; /* settings.projmatrix_raw  (:110) */
+    float campos[3];          /* settings.campos          (:112) */
+    float tanfovx, tanfovy;   /* settings.tanfovx/y       (:104-105) */
+    float bg[3];              /* settings.bg              (:106) */
+    float scale;              /* scene scale folded into the kernel: means*scale, cov*scale^2
+                                 (the make_scale_invariant step, cuda_splatting.py:65-72); 1 = none */
+    float pad[7];
+} GsrView;
+
+/* Problem dimensions.  V = B * Vt views are rendered per call; view v looks at
+ * the Gaussians of scene v / Vt (the (b v) flattening of
+ * decoder_splatting_cuda.py:51-63 WITHOUT replicating the Gaussian arrays). */
+typedef struct GsrDims {
+    int32_t B;          /* scenes (independent Gaussian sets) */
+    int32_t Vt;         /* views per scene */
+    int32_t G;          /* Gaussians per scene */
+    int32_t H, W;       /* image size (all views) */
+    int32_t M;          /* SH coefficients per channel in `shs` (G,M,3); 0 => `shs` is precomputed RGB (G,3) */
+    int32_t sh_degree;  /* active degree 0..4, (sh_degree+1)^2 <= M */
+    int32_t flags;      /* GSR_FLAG_* */
+} GsrDims;
+
+#define GSR_FLAG_NTOUCHED 1  /* forward: also count n_touched (costs LDS + global atomics) */
+
+/* status words written by gsr_forward (device int32[GSR_STATUS_WORDS]) */
+#define GSR_STATUS_WORDS 8
+#define GSR_ST_PAIRS 0       /* R: total (tile, Gaussian) pairs over all views (low 32 bits) */
+#define GSR_ST_OVERFLOW 1    /* 1 if R > pair_capacity: outputs are INVALID, re-run with a larger capacity */
+#define GSR_ST_MAX_TILE 2    /* longest per-tile list */
+#define GSR_ST_PAIRS_HI 3    /* high 32 bits of R */
+
+/* Named offsets into the workspace (bytes), for the parity tests and the bench. */
+typedef struct GsrLayout {
+    size_t records;      /* SplatRec[V*G], 48 B each: x,y,depth,radius | conic A,B,C,opacity | r,g,b,aux */
+    size_t tile_count;   /* uint32[V*T]     per-tile list length */
+    size_t tile_offset;  /* uint32[V*T+1]   exclusive scan; ranges[t] = [off[t], off[t+1]) */
+    size_t tile_cursor;  /* uint32[V*T]     scatter cursors */
+    size_t pairs;        /* uint64[cap]     (depth_bits << 32 | id), bucketed by (view, tile) */
+    size_t point_list;   /* uint32[cap]     per-tile depth-sorted Gaussian ids */
+    size_t final_T;      /* float[V*H*W] */
+    size_t n_contrib;    /* uint32[V*H*W] */
+    size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */
+    size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
+    size_t total;        /* total bytes */
+} GsrLayout;
+
+/* Size/offsets of the workspace for (dims, pair_capacity).  Returns GSR_OK or GSR_EINVAL. */
+int gsr_workspace_layout(const GsrDims *dims, int64_t pair_capacity, GsrLayout *out);
+
+/*
+ * Forward for V = B*Vt views.  All pointers are device pointers.
+ *   views   GsrView[V]
+ *   means   float (B,G,3); cov6 float (B,G,6) xx,xy,xz,yy,yz,zz; opac float (B,G);
+ *   shs     float (B,G,M,3) or, when M == 0, RGB (B,G,3)
+ * Outputs: image (V,3,H,W), depth (V,H,W), opacity (V,H,W), radii int32 (V,G),
+ *          n_touched int32 (V,G) (may be NULL unless GSR_FLAG_NTOUCHED),
+ *          status int32[GSR_STATUS_WORDS].
+ * The call only enqueues work on `stream` (no host sync).  If status[GSR_ST_OVERFLOW]
+ * is set the images are invalid and the call must be repeated with
+ * pair_capacity >= status[GSR_ST_PAIRS].
+ */
+int gsr_forward(const GsrDims *dims, const GsrView *views, const float *means, const float *cov6,
+                const float *opac, const float *shs, int64_t pair_capacity, void *workspace,
+                size_t workspace_bytes, float *image, float *depth, float *opacity, int32_t *radii,
+                int32_t *n_touched, int32_t *status, void *stream);
+
+/*
+ * Backward of the same call (workspace must be the one the forward filled).
+ *   dL_dimage (V,3,H,W); dL_ddepth (V,H,W) or NULL.
+ * Outputs (overwritten): dL_dmeans (B,G,3), dL_dcov6 (B,G,6), dL_dopac (B,G),
+ *   dL_dshs (B,G,M,3) or (B,G,3); optional (NULL to skip): dL_dmeans2D (V,G,3)
+ *   screen-space mean gradient (z = 0), dL_dtau (V,6) = (rho, theta) pose gradient
+ *   of a left se(3) perturbation of each view's world->camera transform.
+ */
+int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means, const float *cov6,
+                 const float *shs, int64_t pair_capacity, void *workspace, size_t workspace_bytes,
+                 const float *dL_dimage, const float *dL_ddepth, float *dL_dmeans, float *dL_dcov6,
+                 float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau, void *stream);
+
+/* Library / build identification ("gsr-hip gfx950 <version>"). */
+const char *gsr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -1,0 +1,100 @@
+"""Loader / builder of the HIP C-ABI library (include/gsr.h).
+
+The library is plain C ABI (no torch types) and is bound here with ctypes --
+the same stub a maintainer of the reference would add.
+There is NO fallback: if the library is missing the import of the product
+path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+_CSRC = _PKG / "csrc"
+_LIBDIR = _PKG / "lib"
+LIB_PATH = _LIBDIR / "libgsr_hip.so"
+
+_SOURCES = ["gsr_forward.hip", "gsr_backward.hip", "gsr_api.hip"]
+_HEADERS = ["gsr_common.h", "../../include/gsr.h"]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fvisibility=hidden",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return "hipcc"
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into styl3r_amd/lib/libgsr_hip.so (cross-compiles without a GPU)."""
+    srcs = [_CSRC / s for s in _SOURCES]
+    deps = srcs + [(_CSRC / h).resolve() for h in _HEADERS]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    _LIBDIR.mkdir(exist_ok=True)
+    cmd = [_hipcc(), *HIPCC_FLAGS, *map(str, srcs), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(_CSRC))
+    return LIB_PATH
+
+
+class GsrDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Vt", C.c_int32), ("G", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("M", C.c_int32), ("sh_degree", C.c_int32), ("flags", C.c_int32)]
+
+
+class GsrLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("records", "tile_count", "tile_offset", "tile_cursor", "pairs", "point_list",
+                                          "final_T", "n_contrib", "grad_rec", "status", "total")]
+
+
+GSR_FLAG_NTOUCHED = 1
+GSR_STATUS_WORDS = 8
+GSR_VIEW_FLOATS = 64
+EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version")
+ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
+          -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and declare the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP rasterizer has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
+    lib.gsr_workspace_layout.argtypes = [C.POINTER(GsrDims), i64, C.POINTER(GsrLayout)]
+    lib.gsr_workspace_layout.restype = C.c_int
+    lib.gsr_forward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_forward.restype = C.c_int
+    lib.gsr_backward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.gsr_backward.restype = C.c_int
+    lib.gsr_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+
+
+def workspace_layout(dims: GsrDims, capacity: int) -> GsrLayout:
+    L = GsrLayout()
+    check(load().gsr_workspace_layout(C.byref(dims), int(capacity), C.byref(L)), "gsr_workspace_layout")
+    return L

@@ -1,0 +1,399 @@
+// gsr_backward.hip -- backward pipeline of the gfx950 rasterizer.
+//
+//   K6 composite_bwd    same tiling as the forward; the per-tile lists are walked
+//                       back-to-front from the tile's deepest contributor; each splat's
+//                       ten partial gradients are summed across the 64 lanes with DPP row
+//                       operations, across the 4 waves in LDS, and leave the CU as ONE
+//                       atomic per (tile, splat, component).                  (upstream R7)
+//   K7 preprocess_bwd   per Gaussian, loops over the scene's views and sums their
+//                       contributions in registers (no atomics, deterministic): conic ->
+//                       cov2D -> cov3D / mean, projection, depth, SH, pose (tau).   (R8)
+#include "gsr_common.h"
+
+namespace gsr {
+
+// grad_rec layout, 12 floats per (view, Gaussian)
+enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_CC = 8, GR_OP = 9, GR_STRIDE = 12 };
+
+// ------------------------------------------------------------------ K6
+__global__ void __launch_bounds__(256) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+                                                      const float *__restrict__ dL_dimage,
+                                                      const float *__restrict__ dL_ddepth)
+{
+    if (ws.status[GSR_ST_OVERFLOW]) return;
+    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
+    __shared__ uint32_t s_id[256];
+    __shared__ float s_acc[256][10];
+    __shared__ uint32_t s_red[4];
+
+    const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
+    const int tile = blockIdx.x, v = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int px = (tile % gx) * TILE + (tid & 15);
+    const int py = (tile / gx) * TILE + (tid >> 4);
+    const bool inside = px < d.W && py < d.H;
+    const float fx = (float)px, fy = (float)py;
+    const size_t P = (size_t)d.H * d.W;
+    const size_t pix = (size_t)py * d.W + px;
+
+    const size_t t = (size_t)v * T + tile;
+    const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
+    if (start == end) return;
+    const SplatRec *recs = ws.records + (size_t)v * d.G;
+    float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
+    const GsrView &vw = views[v];
+
+    const float Tf = inside ? ws.final_T[v * P + pix] : 0.f;
+    const uint32_t last = inside ? ws.n_contrib[v * P + pix] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f;
+    if (inside) {
+        g0 = dL_dimage[(v * 3 + 0) * P + pix];
+        g1 = dL_dimage[(v * 3 + 1) * P + pix];
+        g2 = dL_dimage[(v * 3 + 2) * P + pix];
+        if (dL_ddepth) gd = dL_ddepth[v * P + pix];
+    }
+    const float bg_dot = vw.bg[0] * g0 + vw.bg[1] * g1 + vw.bg[2] * g2;
+    const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
+
+    // deepest contributor of the tile: nothing behind it received any light
+    uint32_t mx = last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (lane == 0) s_red[wid] = mx;
+    __syncthreads();
+    const uint32_t max_last = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+
+    float Tr = Tf;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f, last_alpha = 0.f;
+    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;
+
+    // entries [0, max_last) of the list, processed in batches from the back
+    for (int hi = (int)max_last; hi > 0; hi -= 256) {
+        const int lo = max(0, hi - 256);
+        const int cnt = hi - lo;
+        __syncthreads();  // previous batch fully flushed before LDS is reused
+        if (tid < cnt) {
+            // slot j of the batch holds list entry hi-1-j (so j walks back to front)
+            const uint32_t id = ws.point_list[start + (uint32_t)(hi - 1 - tid)];
+            const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+            s_q0[tid] = r[0]; s_q1[tid] = r[1]; s_q2[tid] = r[2];
+            s_id[tid] = id;
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_acc[tid][k] = 0.f;
+        __syncthreads();
+
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t entry = (uint32_t)(hi - 1 - j);  // 0-based position in the list
+            bool act = inside && entry < last;
+            float4 q0, q1;
+            float dx = 0.f, dy = 0.f, Gv = 0.f, alpha = 0.f;
+            if (act) {
+                q0 = s_q0[j]; q1 = s_q1[j];
+                dx = q0.x - fx; dy = q0.y - fy;
+                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                act = power <= 0.f;
+                if (act) {
+                    Gv = __expf(power);
+                    alpha = fminf(0.99f, q1.w * Gv);
+                    act = alpha >= (1.f / 255.f);
+                }
+            }
+            if (__ballot(act) == 0ull) continue;  // wave-uniform: nobody in this wave sees the splat
+            float a[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] = 0.f;
+            if (act) {
+                const float4 q2 = s_q2[j];
+                Tr = Tr / (1.f - alpha);
+                const float w = alpha * Tr;
+                float dL_dalpha;
+                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = q2.x;
+                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = q2.y;
+                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = q2.z;
+                accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = q0.z;
+                dL_dalpha = (q2.x - acc0) * g0 + (q2.y - acc1) * g1 + (q2.z - acc2) * g2 + (q0.z - accd) * gd;
+                a[GR_RGB + 0] = w * g0; a[GR_RGB + 1] = w * g1; a[GR_RGB + 2] = w * g2;
+                a[GR_DEPTH] = w * gd;
+                dL_dalpha *= Tr;
+                last_alpha = alpha;
+                dL_dalpha += (-Tf / (1.f - alpha)) * bg_dot;
+                const float dL_dG = q1.w * dL_dalpha;
+                const float gdx = Gv * dx, gdy = Gv * dy;
+                const float dG_ddelx = -gdx * q1.x - gdy * q1.y;
+                const float dG_ddely = -gdy * q1.z - gdx * q1.y;
+                a[GR_MX] = dL_dG * dG_ddelx * ddelx_dx;
+                a[GR_MY] = dL_dG * dG_ddely * ddely_dy;
+                a[GR_CA] = -0.5f * gdx * dx * dL_dG;
+                a[GR_CB] = -0.5f * gdx * dy * dL_dG;
+                a[GR_CC] = -0.5f * gdy * dy * dL_dG;
+                a[GR_OP] = Gv * dL_dalpha;
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a[k] = wave_sum_to_lane63(a[k]);
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) atomicAdd(&s_acc[j][k], a[k]);
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            float *gdst = grad + (size_t)s_id[tid] * GR_STRIDE;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) any |= (s_acc[tid][k] != 0.f);
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) atomicAdd(gdst + k, s_acc[tid][k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K7
+__device__ inline float block_sum_256(float v, float *s_tmp, int tid)
+{
+    v = wave_sum_to_lane63(v);
+    __syncthreads();
+    if ((tid & 63) == 63) s_tmp[tid >> 6] = v;
+    __syncthreads();
+    return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView *__restrict__ views,
+                                                        const float *__restrict__ means, const float *__restrict__ cov6,
+                                                        const float *__restrict__ shs, Ptrs ws,
+                                                        float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov6,
+                                                        float *__restrict__ dL_dopac, float *__restrict__ dL_dshs,
+                                                        float *__restrict__ dL_dmeans2D, float *__restrict__ dL_dtau)
+{
+    __shared__ float s_tmp[4];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.x * blockDim.x + tid;
+    const int b = blockIdx.y;
+    const bool valid = g < d.G;
+    const size_t sg = (size_t)b * d.G + (valid ? g : 0);
+    const float m0[3] = {means[3 * sg], means[3 * sg + 1], means[3 * sg + 2]};
+    float S0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S0[k] = cov6[6 * sg + k];
+    const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
+    const int ncol = d.M > 0 ? 3 * d.M : 3;
+    float *dsh = dL_dshs + sg * (size_t)ncol;
+
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f;
+    if (valid)
+        for (int k = 0; k < ncol; ++k) dsh[k] = 0.f;
+
+    for (int j = 0; j < d.Vt; ++j) {
+        const int v = b * d.Vt + j;
+        const GsrView &vw = views[v];
+        const float *V = vw.viewmatrix, *Pm = vw.projmatrix, *Q = vw.projmatrix_raw;
+        const size_t vg = (size_t)v * d.G + (valid ? g : 0);
+        float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float g2x = 0.f, g2y = 0.f;
+        const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
+        const bool vis = valid && __float_as_int(q0.w) > 0;
+        if (vis) {
+            const uint32_t aux = reinterpret_cast<const uint32_t *>(ws.records + vg)[11];
+            const float *gr = ws.grad_rec + vg * GR_STRIDE;
+            const float s = vw.scale, s2 = s * s;
+            const float m[3] = {m0[0] * s, m0[1] * s, m0[2] * s};
+            float S[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) S[k] = S0[k] * s2;
+            Geom ge;
+            geom_eval(V, vw.tanfovx, vw.tanfovy, d.W, d.H, m, S, ge);
+            const float fx = (float)d.W / (2.0f * vw.tanfovx);
+            const float fy = (float)d.H / (2.0f * vw.tanfovy);
+            float dm[3] = {0.f, 0.f, 0.f};
+
+            // ---- colour ----
+            if (d.M > 0) {
+                float ddx = m[0] - vw.campos[0], ddy = m[1] - vw.campos[1], ddz = m[2] - vw.campos[2];
+                float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                float x = ddx / len, y = ddy / len, z = ddz / len;
+                float bs[25], bx[25], by[25], bz[25];
+                sh_basis(d.sh_degree, x, y, z, bs);
+                if (d.sh_degree > 0) sh_basis_grad(d.sh_degree, x, y, z, bx, by, bz);
+                const float *sh = shs + sg * 3 * (size_t)d.M;
+                float dLdx = 0.f, dLdy = 0.f, dLdz = 0.f;
+                for (int c = 0; c < 3; ++c) {
+                    float gcol = ((aux >> c) & 1u) ? 0.f : gr[GR_RGB + c];
+                    for (int k = 0; k < ncoef; ++k) {
+                        dsh[3 * k + c] += bs[k] * gcol;
+                        if (d.sh_degree > 0) {
+                            dLdx += bx[k] * sh[3 * k + c] * gcol;
+                            dLdy += by[k] * sh[3 * k + c] * gcol;
+                            dLdz += bz[k] * sh[3 * k + c] * gcol;
+                        }
+                    }
+                }
+                if (d.sh_degree > 0) {
+                    float dot = x * dLdx + y * dLdy + z * dLdz;
+                    dm[0] += (dLdx - x * dot) / len;
+                    dm[1] += (dLdy - y * dot) / len;
+                    dm[2] += (dLdz - z * dot) / len;
+                }
+            } else {
+                for (int c = 0; c < 3; ++c) dsh[c] += gr[GR_RGB + c];
+            }
+
+            // ---- conic -> cov2D ----
+            const float a = ge.a, bb = ge.b, c = ge.c;
+            const float denom = a * c - bb * bb;
+            const float k2 = 1.0f / (denom * denom + 0.0000001f);
+            const float gA = gr[GR_CA], gB = gr[GR_CB], gC = gr[GR_CC];
+            const float ga = k2 * (-c * c * gA + 2.0f * bb * c * gB + (denom - a * c) * gC);
+            const float gc = k2 * (-a * a * gC + 2.0f * a * bb * gB + (denom - a * c) * gA);
+            const float gb = k2 * 2.0f * (bb * c * gA - (denom + 2.0f * bb * bb) * gB + a * bb * gC);
+
+            // ---- cov2D -> cov3D ----
+            const float *M0 = ge.M0, *M1 = ge.M1;
+            float dc[6];
+            dc[0] = M0[0] * M0[0] * ga + M0[0] * M1[0] * gb + M1[0] * M1[0] * gc;
+            dc[3] = M0[1] * M0[1] * ga + M0[1] * M1[1] * gb + M1[1] * M1[1] * gc;
+            dc[5] = M0[2] * M0[2] * ga + M0[2] * M1[2] * gb + M1[2] * M1[2] * gc;
+            dc[1] = 2.0f * M0[0] * M0[1] * ga + (M0[0] * M1[1] + M0[1] * M1[0]) * gb + 2.0f * M1[0] * M1[1] * gc;
+            dc[2] = 2.0f * M0[0] * M0[2] * ga + (M0[0] * M1[2] + M0[2] * M1[0]) * gb + 2.0f * M1[0] * M1[2] * gc;
+            dc[4] = 2.0f * M0[2] * M0[1] * ga + (M0[1] * M1[2] + M0[2] * M1[1]) * gb + 2.0f * M1[1] * M1[2] * gc;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov[k] += dc[k] * s2;
+
+            // ---- cov2D -> M = J R -> t ----
+            float SM0[3] = {S[0] * M0[0] + S[1] * M0[1] + S[2] * M0[2], S[1] * M0[0] + S[3] * M0[1] + S[4] * M0[2],
+                            S[2] * M0[0] + S[4] * M0[1] + S[5] * M0[2]};
+            float SM1[3] = {S[0] * M1[0] + S[1] * M1[1] + S[2] * M1[2], S[1] * M1[0] + S[3] * M1[1] + S[4] * M1[2],
+                            S[2] * M1[0] + S[4] * M1[1] + S[5] * M1[2]};
+            float dM0[3], dM1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dM0[k] = 2.0f * ga * SM0[k] + gb * SM1[k];
+                dM1[k] = gb * SM0[k] + 2.0f * gc * SM1[k];
+            }
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dJ00 += dM0[k] * V[4 * k + 0];
+                dJ02 += dM0[k] * V[4 * k + 2];
+                dJ11 += dM1[k] * V[4 * k + 1];
+                dJ12 += dM1[k] * V[4 * k + 2];
+            }
+            const float tz = 1.0f / ge.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+            const float xmul = ge.clampx ? 0.f : 1.f, ymul = ge.clampy ? 0.f : 1.f;
+            float dt_cov[3];
+            dt_cov[0] = xmul * -fx * tz2 * dJ02;
+            dt_cov[1] = ymul * -fy * tz2 * dJ12;
+            dt_cov[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.0f * fx * ge.txc) * tz3 * dJ02 +
+                        (2.0f * fy * ge.tyc) * tz3 * dJ12;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dm[k] += V[4 * k + 0] * dt_cov[0] + V[4 * k + 1] * dt_cov[1] + V[4 * k + 2] * dt_cov[2];
+
+            // ---- mean2D -> mean (full projection) ----
+            const float hx = m[0] * Pm[0] + m[1] * Pm[4] + m[2] * Pm[8] + Pm[12];
+            const float hy = m[0] * Pm[1] + m[1] * Pm[5] + m[2] * Pm[9] + Pm[13];
+            const float hw = m[0] * Pm[3] + m[1] * Pm[7] + m[2] * Pm[11] + Pm[15];
+            const float mw = 1.0f / (hw + 0.0000001f);
+            const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+            g2x = gr[GR_MX]; g2y = gr[GR_MY];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dm[k] += (Pm[4 * k + 0] * mw - Pm[4 * k + 3] * mul1) * g2x + (Pm[4 * k + 1] * mw - Pm[4 * k + 3] * mul2) * g2y;
+
+            // ---- depth -> mean ----
+            const float gdep = gr[GR_DEPTH];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dm[k] += V[4 * k + 2] * gdep;
+
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dmean[k] += dm[k] * s;
+            dop += gr[GR_OP];
+
+            // ---- pose ----
+            if (dL_dtau) {
+                const float t0 = ge.t[0], t1 = ge.t[1], t2 = ge.t[2];
+                const float qx = t0 * Q[0] + t1 * Q[4] + t2 * Q[8] + Q[12];
+                const float qy = t0 * Q[1] + t1 * Q[5] + t2 * Q[9] + Q[13];
+                const float qw = t0 * Q[3] + t1 * Q[7] + t2 * Q[11] + Q[15];
+                const float w1 = 1.0f / (qw + 0.0000001f);
+                const float m1 = qx * w1 * w1, m2 = qy * w1 * w1;
+                float dtp[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dtp[k] = (Q[4 * k + 0] * w1 - Q[4 * k + 3] * m1) * g2x + (Q[4 * k + 1] * w1 - Q[4 * k + 3] * m2) * g2y;
+                dtp[2] += gdep;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dtp[k] += dt_cov[k];
+                float dR[3][3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dR[0][k] = ge.J00 * dM0[k];
+                    dR[1][k] = ge.J11 * dM1[k];
+                    dR[2][k] = ge.J02 * dM0[k] + ge.J12 * dM1[k];
+                }
+                float Am[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc += dR[r][k] * V[4 * k + l];
+                        Am[r][l] = acc;
+                    }
+                tau[0] = dtp[0]; tau[1] = dtp[1]; tau[2] = dtp[2];
+                tau[3] = (t1 * dtp[2] - t2 * dtp[1]) + (Am[2][1] - Am[1][2]);
+                tau[4] = (t2 * dtp[0] - t0 * dtp[2]) + (Am[0][2] - Am[2][0]);
+                tau[5] = (t0 * dtp[1] - t1 * dtp[0]) + (Am[1][0] - Am[0][1]);
+            }
+        }
+        if (dL_dmeans2D && valid) {
+            float *o = dL_dmeans2D + vg * 3;
+            o[0] = g2x; o[1] = g2y; o[2] = 0.f;
+        }
+        if (dL_dtau) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                float sum = block_sum_256(tau[k], s_tmp, tid);
+                if (tid == 0 && sum != 0.f) atomicAdd(dL_dtau + (size_t)v * 6 + k, sum);
+            }
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dmeans[3 * sg + k] = dmean[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov6[6 * sg + k] = dcov[k];
+        dL_dopac[sg] = dop;
+    }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------ host
+int layout(const GsrDims &d, long long cap, GsrLayout &L);
+Ptrs carve(void *base, const GsrLayout &L);
+
+int backward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *shs,
+             long long cap, void *workspace, size_t workspace_bytes, const float *dL_dimage, const float *dL_ddepth,
+             float *dL_dmeans, float *dL_dcov6, float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau,
+             hipStream_t stream)
+{
+    GsrLayout L;
+    int rc = layout(d, cap, L);
+    if (rc != GSR_OK) return rc;
+    if (!views || !means || !cov6 || !shs || !workspace || !dL_dimage || !dL_dmeans || !dL_dcov6 || !dL_dopac || !dL_dshs)
+        return GSR_EINVAL;
+    if (workspace_bytes < L.total) return GSR_ENOSPACE;
+    Ptrs ws = carve(workspace, L);
+    const int V = d.B * d.Vt, T = tiles_x(d.W) * tiles_y(d.H);
+    if (hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+    if (dL_dtau && hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+    hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(256), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
+    hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.G + 255) / 256, d.B), dim3(256), 0, stream, d, views, means, cov6, shs,
+                       ws, dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ELAUNCH;
+}
+
+}  // namespace gsr

@@ -1,0 +1,203 @@
+// gsr_common.h -- shared device helpers of the gfx950 rasterizer.
+// Written for CDNA4 only: 64-wide wavefronts, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsr.h"
+
+namespace gsr {
+
+constexpr int TILE = GSR_TILE;
+constexpr int TILE_PIX = TILE * TILE;   // 256 pixels = 4 wavefronts
+constexpr int WAVE = 64;
+
+// 48-byte per-(view,Gaussian) splat record; three aligned float4 so a lane
+// gathers it with three dwordx4 loads.
+struct alignas(16) SplatRec {
+    float x, y, depth;
+    int radius;             // 0 => culled / not rasterized
+    float A, B, C, opacity; // conic + opacity
+    float r, g, b;
+    uint32_t aux;           // bit0..2: SH colour channel clamped at 0
+};
+static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
+
+struct Ptrs {             // carved workspace
+    SplatRec *records;
+    uint32_t *tile_count, *tile_offset, *tile_cursor;
+    unsigned long long *pairs;
+    uint32_t *point_list;
+    float *final_T;
+    uint32_t *n_contrib;
+    float *grad_rec;
+    int32_t *status;
+};
+
+__host__ __device__ inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
+__host__ __device__ inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
+
+// ---- real SH tables (bands 0-3 = published 3DGS constants, band 4 = standard real SH) ----
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2_0 = 1.0925484305920792f, SH_C2_1 = -1.0925484305920792f, SH_C2_2 = 0.31539156525252005f,
+                           SH_C2_3 = -1.0925484305920792f, SH_C2_4 = 0.5462742152960396f;
+__device__ constexpr float SH_C3_0 = -0.5900435899266435f, SH_C3_1 = 2.890611442640554f, SH_C3_2 = -0.4570457994644658f,
+                           SH_C3_3 = 0.3731763325901154f, SH_C3_4 = -0.4570457994644658f, SH_C3_5 = 1.445305721320277f,
+                           SH_C3_6 = -0.5900435899266435f;
+__device__ constexpr float SH_C4_0 = 2.5033429417967046f, SH_C4_1 = -1.7701307697799304f, SH_C4_2 = 0.9461746957575601f,
+                           SH_C4_3 = -0.6690465435572892f, SH_C4_4 = 0.10578554691520431f, SH_C4_5 = -0.6690465435572892f,
+                           SH_C4_6 = 0.47308734787878004f, SH_C4_7 = -1.7701307697799304f, SH_C4_8 = 0.6258357354491761f;
+
+// Everything that must agree bit-for-bit with the fp32 oracle is compiled with
+// fp contraction OFF and written in the oracle's operation order.
+#pragma clang fp contract(off)
+
+__device__ inline void sh_basis(int deg, float x, float y, float z, float *b)
+{
+    b[0] = SH_C0;
+    if (deg < 1) return;
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+    b[7] = SH_C2_3 * xz; b[8] = SH_C2_4 * (xx - yy);
+    if (deg < 3) return;
+    b[9] = SH_C3_0 * y * (3.0f * xx - yy);
+    b[10] = SH_C3_1 * xy * z;
+    b[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+    b[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    b[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+    b[14] = SH_C3_5 * z * (xx - yy);
+    b[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+    if (deg < 4) return;
+    b[16] = SH_C4_0 * xy * (xx - yy);
+    b[17] = SH_C4_1 * yz * (3.0f * xx - yy);
+    b[18] = SH_C4_2 * xy * (7.0f * zz - 1.0f);
+    b[19] = SH_C4_3 * yz * (7.0f * zz - 3.0f);
+    b[20] = SH_C4_4 * (zz * (35.0f * zz - 30.0f) + 3.0f);
+    b[21] = SH_C4_5 * xz * (7.0f * zz - 3.0f);
+    b[22] = SH_C4_6 * (xx - yy) * (7.0f * zz - 1.0f);
+    b[23] = SH_C4_7 * xz * (xx - 3.0f * yy);
+    b[24] = SH_C4_8 * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy));
+}
+
+__device__ inline void sh_basis_grad(int deg, float x, float y, float z, float *dx, float *dy, float *dz)
+{
+    dx[0] = dy[0] = dz[0] = 0.f;
+    if (deg < 1) return;
+    dx[1] = 0.f; dy[1] = -SH_C1; dz[1] = 0.f;
+    dx[2] = 0.f; dy[2] = 0.f; dz[2] = SH_C1;
+    dx[3] = -SH_C1; dy[3] = 0.f; dz[3] = 0.f;
+    if (deg < 2) return;
+    float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    dx[4] = SH_C2_0 * y; dy[4] = SH_C2_0 * x; dz[4] = 0.f;
+    dx[5] = 0.f; dy[5] = SH_C2_1 * z; dz[5] = SH_C2_1 * y;
+    dx[6] = SH_C2_2 * (-2.0f * x); dy[6] = SH_C2_2 * (-2.0f * y); dz[6] = SH_C2_2 * (4.0f * z);
+    dx[7] = SH_C2_3 * z; dy[7] = 0.f; dz[7] = SH_C2_3 * x;
+    dx[8] = SH_C2_4 * (2.0f * x); dy[8] = SH_C2_4 * (-2.0f * y); dz[8] = 0.f;
+    if (deg < 3) return;
+    dx[9] = SH_C3_0 * (6.0f * xy); dy[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy); dz[9] = 0.f;
+    dx[10] = SH_C3_1 * yz; dy[10] = SH_C3_1 * xz; dz[10] = SH_C3_1 * xy;
+    dx[11] = SH_C3_2 * (-2.0f * xy); dy[11] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dz[11] = SH_C3_2 * (8.0f * yz);
+    dx[12] = SH_C3_3 * (-6.0f * xz); dy[12] = SH_C3_3 * (-6.0f * yz); dz[12] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+    dx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dy[13] = SH_C3_4 * (-2.0f * xy); dz[13] = SH_C3_4 * (8.0f * xz);
+    dx[14] = SH_C3_5 * (2.0f * xz); dy[14] = SH_C3_5 * (-2.0f * yz); dz[14] = SH_C3_5 * (xx - yy);
+    dx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dy[15] = SH_C3_6 * (-6.0f * xy); dz[15] = 0.f;
+    if (deg < 4) return;
+    dx[16] = SH_C4_0 * y * (3.0f * xx - yy); dy[16] = SH_C4_0 * x * (xx - 3.0f * yy); dz[16] = 0.f;
+    dx[17] = SH_C4_1 * (6.0f * xy * z); dy[17] = SH_C4_1 * z * (3.0f * xx - 3.0f * yy); dz[17] = SH_C4_1 * y * (3.0f * xx - yy);
+    dx[18] = SH_C4_2 * y * (7.0f * zz - 1.0f); dy[18] = SH_C4_2 * x * (7.0f * zz - 1.0f); dz[18] = SH_C4_2 * (14.0f * xy * z);
+    dx[19] = 0.f; dy[19] = SH_C4_3 * z * (7.0f * zz - 3.0f); dz[19] = SH_C4_3 * y * (21.0f * zz - 3.0f);
+    dx[20] = 0.f; dy[20] = 0.f; dz[20] = SH_C4_4 * (140.0f * zz * z - 60.0f * z);
+    dx[21] = SH_C4_5 * z * (7.0f * zz - 3.0f); dy[21] = 0.f; dz[21] = SH_C4_5 * x * (21.0f * zz - 3.0f);
+    dx[22] = SH_C4_6 * (2.0f * x) * (7.0f * zz - 1.0f); dy[22] = SH_C4_6 * (-2.0f * y) * (7.0f * zz - 1.0f); dz[22] = SH_C4_6 * (xx - yy) * (14.0f * z);
+    dx[23] = SH_C4_7 * z * (3.0f * xx - 3.0f * yy); dy[23] = SH_C4_7 * (-6.0f * xy * z); dz[23] = SH_C4_7 * x * (xx - 3.0f * yy);
+    dx[24] = SH_C4_8 * (4.0f * xx * x - 12.0f * x * yy); dy[24] = SH_C4_8 * (-12.0f * xx * y + 4.0f * yy * y); dz[24] = 0.f;
+}
+
+// Camera-space geometry of one Gaussian (mirrors gso_geom_eval of the oracle
+// operation for operation).
+struct Geom {
+    float t[3];
+    float txc, tyc;
+    bool clampx, clampy;
+    float J00, J02, J11, J12;
+    float M0[3], M1[3];
+    float a, b, c;
+};
+
+__device__ inline bool geom_eval(const float *V, float tanfovx, float tanfovy, int W, int H, const float *mean,
+                                 const float *S, Geom &g)
+{
+    float px = mean[0], py = mean[1], pz = mean[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g.t[c] = px * V[0 + c] + py * V[4 + c] + pz * V[8 + c] + V[12 + c];
+    if (g.t[2] <= 0.2f) return false;
+    float fx = (float)W / (2.0f * tanfovx);
+    float fy = (float)H / (2.0f * tanfovy);
+    float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    float tz = g.t[2];
+    float txtz = g.t[0] / tz, tytz = g.t[1] / tz;
+    float cx = fminf(limx, fmaxf(-limx, txtz));
+    float cy = fminf(limy, fmaxf(-limy, tytz));
+    g.clampx = (txtz < -limx || txtz > limx);
+    g.clampy = (tytz < -limy || tytz > limy);
+    g.txc = cx * tz;
+    g.tyc = cy * tz;
+    g.J00 = fx / tz;
+    g.J02 = -(fx * g.txc) / (tz * tz);
+    g.J11 = fy / tz;
+    g.J12 = -(fy * g.tyc) / (tz * tz);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float R0 = V[4 * j + 0], R1 = V[4 * j + 1], R2 = V[4 * j + 2];
+        g.M0[j] = g.J00 * R0 + g.J02 * R2;
+        g.M1[j] = g.J11 * R1 + g.J12 * R2;
+    }
+    float v0[3], v1[3];
+    v0[0] = S[0] * g.M0[0] + S[1] * g.M0[1] + S[2] * g.M0[2];
+    v0[1] = S[1] * g.M0[0] + S[3] * g.M0[1] + S[4] * g.M0[2];
+    v0[2] = S[2] * g.M0[0] + S[4] * g.M0[1] + S[5] * g.M0[2];
+    v1[0] = S[0] * g.M1[0] + S[1] * g.M1[1] + S[2] * g.M1[2];
+    v1[1] = S[1] * g.M1[0] + S[3] * g.M1[1] + S[4] * g.M1[2];
+    v1[2] = S[2] * g.M1[0] + S[4] * g.M1[1] + S[5] * g.M1[2];
+    g.a = (g.M0[0] * v0[0] + g.M0[1] * v0[1] + g.M0[2] * v0[2]) + 0.3f;
+    g.b = g.M1[0] * v0[0] + g.M1[1] * v0[1] + g.M1[2] * v0[2];
+    g.c = (g.M1[0] * v1[0] + g.M1[1] * v1[1] + g.M1[2] * v1[2]) + 0.3f;
+    return true;
+}
+
+// tile rectangle of a splat (upstream getRect); returns the covered tile count.
+__device__ inline int tile_rect(float px, float py, int rad, int gx, int gy, int &minx, int &miny, int &maxx, int &maxy)
+{
+    minx = min(gx, max(0, (int)((px - (float)rad) / (float)TILE)));
+    miny = min(gy, max(0, (int)((py - (float)rad) / (float)TILE)));
+    maxx = min(gx, max(0, (int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE)));
+    maxy = min(gy, max(0, (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE)));
+    return (maxx - minx) * (maxy - miny);
+}
+
+#pragma clang fp contract(fast)
+
+// ---- wave64 helpers ------------------------------------------------------
+// Sum over the 64 lanes with DPP row operations (no LDS traffic); the total
+// lands in lane 63.  gfx9-family DPP: quad_perm, row_ror, row_bcast15/31.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = false>
+__device__ inline float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+__device__ inline float wave_sum_to_lane63(float v)
+{
+    v += dpp_mov<0xb1, 0xf, 0xf, true>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4e, 0xf, 0xf, true>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124, 0xf, 0xf, true>(v);  // row_ror:4
+    v += dpp_mov<0x128, 0xf, 0xf, true>(v);  // row_ror:8  (every lane of a row now holds the row sum)
+    v += dpp_mov<0x142, 0xa, 0xf, false>(v); // row_bcast:15 -> rows 1,3
+    v += dpp_mov<0x143, 0xc, 0xf, false>(v); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+}  // namespace gsr

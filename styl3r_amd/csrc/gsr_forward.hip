@@ -1,0 +1,414 @@
+// gsr_forward.hip -- forward pipeline of the gfx950 rasterizer.
+//
+//   K1 preprocess      per Gaussian, loops over the scene's views: cull, cov3D->2D, conic,
+//                      radius, tile rect, SH colour; writes one 48-B SplatRec per (view,
+//                      Gaussian) and bumps the per-tile counters.            (upstream R1)
+//   K2 scan_tiles      exclusive scan of the V*T tile counters (one workgroup).   (R2)
+//   K3 scatter         every (view, Gaussian, tile) pair -> its tile bucket as
+//                      (depth_bits<<32 | id).                                     (R3)
+//   K4 tile_sort       per-tile depth sort in LDS (normalised bitonic network on the
+//                      64-bit keys -> order = depth, then id == upstream's stable radix
+//                      order); writes the sorted id list.                      (R4,R5)
+//   K5 composite_fwd   16x16 tile per workgroup, LDS-staged splat queue, front-to-back
+//                      alpha compositing with per-wave early exit.                (R6)
+//
+// The upstream design sorts all pairs of one view globally on 64-bit keys (6-8 radix
+// passes over HBM).  Here the tile id never enters a sort: pairs are bucketed by tile
+// with one counting pass and each bucket is depth-sorted inside the CU's LDS, which cuts
+// the binning traffic from ~140 B/pair to ~20 B/pair and needs no host round trip.
+#include "gsr_common.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------ K1
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__restrict__ views,
+                                                    const float *__restrict__ means, const float *__restrict__ cov6,
+                                                    const float *__restrict__ opac, const float *__restrict__ shs,
+                                                    Ptrs ws, int32_t *__restrict__ radii)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (g >= d.G) return;
+    const size_t sg = (size_t)b * d.G + g;
+    const float m0[3] = {means[3 * sg], means[3 * sg + 1], means[3 * sg + 2]};
+    float S0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S0[k] = cov6[6 * sg + k];
+    const float op = opac[sg];
+    const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
+    const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
+
+    for (int j = 0; j < d.Vt; ++j) {
+        const int v = b * d.Vt + j;
+        const GsrView &vw = views[v];
+        SplatRec rec;
+        rec.x = rec.y = rec.depth = 0.f; rec.radius = 0;
+        rec.A = rec.B = rec.C = rec.opacity = 0.f;
+        rec.r = rec.g = rec.b = 0.f; rec.aux = 0;
+        const size_t vg = (size_t)v * d.G + g;
+
+        const float s = vw.scale, s2 = s * s;
+        const float m[3] = {m0[0] * s, m0[1] * s, m0[2] * s};
+        float S[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = S0[k] * s2;
+
+        Geom ge;
+        bool ok = geom_eval(vw.viewmatrix, vw.tanfovx, vw.tanfovy, d.W, d.H, m, S, ge);
+        int rad = 0, minx = 0, miny = 0, maxx = 0, maxy = 0;
+        float pxx = 0.f, pxy = 0.f, det_inv = 0.f;
+        if (ok) {
+            const float *P = vw.projmatrix;
+            float hx = m[0] * P[0] + m[1] * P[4] + m[2] * P[8] + P[12];
+            float hy = m[0] * P[1] + m[1] * P[5] + m[2] * P[9] + P[13];
+            float hw = m[0] * P[3] + m[1] * P[7] + m[2] * P[11] + P[15];
+            float pw = 1.0f / (hw + 0.0000001f);
+            float ndcx = hx * pw, ndcy = hy * pw;
+            float det = ge.a * ge.c - ge.b * ge.b;
+            ok = (det != 0.0f);
+            if (ok) {
+                det_inv = 1.0f / det;
+                float mid = 0.5f * (ge.a + ge.c);
+                float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                float lam1 = mid + disc, lam2 = mid - disc;
+                rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+                pxx = ((ndcx + 1.0f) * (float)d.W - 1.0f) * 0.5f;
+                pxy = ((ndcy + 1.0f) * (float)d.H - 1.0f) * 0.5f;
+                ok = tile_rect(pxx, pxy, rad, gx, gy, minx, miny, maxx, maxy) != 0;
+            }
+        }
+        if (ok) {
+            if (d.M > 0) {
+                float dx = m[0] - vw.campos[0], dy = m[1] - vw.campos[1], dz = m[2] - vw.campos[2];
+                float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                float x = dx / len, y = dy / len, z = dz / len;
+                float bs[25];
+                sh_basis(d.sh_degree, x, y, z, bs);
+                const float *sh = shs + sg * 3 * (size_t)d.M;
+                float col[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float acc = bs[0] * sh[c];
+                    for (int k = 1; k < ncoef; ++k) acc = acc + bs[k] * sh[3 * k + c];
+                    acc = acc + 0.5f;
+                    if (acc < 0.f) rec.aux |= (1u << c);
+                    col[c] = fmaxf(acc, 0.f);
+                }
+                rec.r = col[0]; rec.g = col[1]; rec.b = col[2];
+            } else {
+                rec.r = shs[3 * sg]; rec.g = shs[3 * sg + 1]; rec.b = shs[3 * sg + 2];
+            }
+            rec.x = pxx; rec.y = pxy; rec.depth = ge.t[2]; rec.radius = rad;
+            rec.A = ge.c * det_inv; rec.B = -ge.b * det_inv; rec.C = ge.a * det_inv; rec.opacity = op;
+            uint32_t *cnt = ws.tile_count + (size_t)v * T;
+            for (int ty = miny; ty < maxy; ++ty)
+                for (int tx = minx; tx < maxx; ++tx) atomicAdd(cnt + ty * gx + tx, 1u);
+        }
+        float4 *dst = reinterpret_cast<float4 *>(ws.records + vg);
+        const float4 *src = reinterpret_cast<const float4 *>(&rec);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+        radii[vg] = rad * (ok ? 1 : 0);
+    }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------ K2
+// One workgroup of 1024 threads scans n = V*T counters (n is at most a few 10^4).
+__global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, Ptrs ws, int32_t *__restrict__ status)
+{
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    __shared__ uint32_t s_max[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    uint32_t mx = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        uint32_t c = (i < n) ? ws.tile_count[i] : 0u;
+        mx = max(mx, c);
+        // inclusive scan inside the wave (64 lanes) with shuffles
+        unsigned long long x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            unsigned long long y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wave[wid] = x;
+        __syncthreads();
+        unsigned long long wave_off = 0;
+        for (int w = 0; w < wid; ++w) wave_off += s_wave[w];
+        unsigned long long carry = s_carry;
+        unsigned long long excl = carry + wave_off + x - c;
+        if (i < n) {
+            ws.tile_offset[i] = (uint32_t)min(excl, (unsigned long long)0xffffffffu);
+            ws.tile_cursor[i] = 0u;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wave_off + x;
+        __syncthreads();
+    }
+    // block max of the tile lengths
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (lane == 0) s_max[wid] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 0;
+        for (int w = 0; w < 16; ++w) m = max(m, s_max[w]);
+        unsigned long long R = s_carry;
+        ws.tile_offset[n] = (uint32_t)min(R, (unsigned long long)0xffffffffu);
+        int ovf = (R > (unsigned long long)capacity || R > 0xffffffffull) ? 1 : 0;
+        int32_t st[GSR_STATUS_WORDS] = {(int32_t)(R & 0xffffffffull), ovf, (int32_t)m, (int32_t)(R >> 32), 0, 0, 0, 0};
+        for (int k = 0; k < GSR_STATUS_WORDS; ++k) { status[k] = st[k]; ws.status[k] = st[k]; }
+    }
+}
+
+// ------------------------------------------------------------------ K3
+#pragma clang fp contract(off)
+__global__ void __launch_bounds__(256) k_scatter(GsrDims d, Ptrs ws)
+{
+    if (ws.status[GSR_ST_OVERFLOW]) return;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= d.G) return;
+    const size_t vg = (size_t)v * d.G + g;
+    const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
+    const int rad = __float_as_int(q0.w);
+    if (rad <= 0) return;
+    const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
+    int minx, miny, maxx, maxy;
+    tile_rect(q0.x, q0.y, rad, gx, gy, minx, miny, maxx, maxy);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(q0.z) << 32) | (unsigned)g;
+    const size_t tb = (size_t)v * T;
+    for (int ty = miny; ty < maxy; ++ty)
+        for (int tx = minx; tx < maxx; ++tx) {
+            const size_t t = tb + ty * gx + tx;
+            uint32_t slot = ws.tile_offset[t] + atomicAdd(ws.tile_cursor + t, 1u);
+            ws.pairs[slot] = key;
+        }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------ K4
+// Normalised bitonic network (every compare-exchange is ascending, so entries at or
+// beyond n behave as +inf without being stored).  Keys are unique (id in the low word).
+template <typename KeyPtr>
+__device__ inline void bitonic_sort_block(KeyPtr key, uint32_t n, int tid, int nthreads)
+{
+    uint32_t N = 1;
+    while (N < n) N <<= 1;
+    for (uint32_t k = 2; k <= N; k <<= 1) {
+        // first sub-step of the merge: mirror partner inside each block of k
+        {
+            const uint32_t half = k >> 1;
+            for (uint32_t p = tid; p < (N >> 1); p += nthreads) {
+                uint32_t blk = p / half, q = p - blk * half;
+                uint32_t i = blk * k + q, l = blk * k + (k - 1 - q);
+                if (l < n) {
+                    unsigned long long a = key[i], c = key[l];
+                    if (a > c) { key[i] = c; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t p = tid; p < (N >> 1); p += nthreads) {
+                uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                uint32_t l = i | j;
+                if (l < n) {
+                    unsigned long long a = key[i], c = key[l];
+                    if (a > c) { key[i] = c; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
+
+__global__ void __launch_bounds__(256) k_tile_sort(int T, Ptrs ws)
+{
+    if (ws.status[GSR_ST_OVERFLOW]) return;
+    __shared__ unsigned long long s_key[SORT_LDS_KEYS];
+    const size_t t = (size_t)blockIdx.y * T + blockIdx.x;
+    const uint32_t start = ws.tile_offset[t];
+    const uint32_t n = ws.tile_offset[t + 1] - start;
+    if (n == 0) return;
+    const int tid = threadIdx.x;
+    unsigned long long *gk = ws.pairs + start;
+    if (n <= SORT_LDS_KEYS) {
+        for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort_block(s_key, n, tid, 256);
+        for (uint32_t i = tid; i < n; i += 256) ws.point_list[start + i] = (uint32_t)(s_key[i] & 0xffffffffull);
+    } else {
+        // oversize bucket: same network, in place in global memory (one workgroup owns the
+        // bucket; __syncthreads orders its own global accesses through the CU's L1/L2 path)
+        __syncthreads();
+        bitonic_sort_block(gk, n, tid, 256);
+        for (uint32_t i = tid; i < n; i += 256) ws.point_list[start + i] = (uint32_t)(gk[i] & 0xffffffffull);
+    }
+}
+
+// ------------------------------------------------------------------ K5
+// One 16x16 tile per workgroup; wave w owns pixel rows 4w..4w+3 of the tile.
+// Splat queue: 256 entries per batch, gathered by id (3 x dwordx4 per lane) into LDS as
+// three float4 planes; every lane then reads the same entry (LDS broadcast).
+template <bool NTOUCH>
+__global__ void __launch_bounds__(256) k_composite_fwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+                                                      float *__restrict__ image, float *__restrict__ out_depth,
+                                                      float *__restrict__ out_opacity, int32_t *__restrict__ n_touched)
+{
+    if (ws.status[GSR_ST_OVERFLOW]) return;
+    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
+    __shared__ uint32_t s_id[NTOUCH ? 256 : 1];
+    __shared__ uint32_t s_touch[NTOUCH ? 256 : 1];
+
+    const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
+    const int tile = blockIdx.x, v = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int px = (tile % gx) * TILE + (tid & 15);
+    const int py = (tile / gx) * TILE + (tid >> 4);
+    const bool inside = px < d.W && py < d.H;
+    const float fx = (float)px, fy = (float)py;
+
+    const size_t t = (size_t)v * T + tile;
+    const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
+    const SplatRec *recs = ws.records + (size_t)v * d.G;
+
+    float Tr = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, O = 0.f;
+    uint32_t contributor = 0, last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = start; base < end; base += 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const uint32_t idx = base + tid;
+        if (idx < end) {
+            const uint32_t id = ws.point_list[idx];
+            const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+            s_q0[tid] = r[0]; s_q1[tid] = r[1]; s_q2[tid] = r[2];
+            if (NTOUCH) { s_id[tid] = id; s_touch[tid] = 0; }
+        }
+        __syncthreads();
+        const int cnt = (int)min(256u, end - base);
+        if (!done) {
+            for (int j = 0; j < cnt; ++j) {
+                contributor++;
+                const float4 q0 = s_q0[j];
+                const float4 q1 = s_q1[j];
+                const float dx = q0.x - fx, dy = q0.y - fy;
+                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+                if (power > 0.f) continue;
+                const float alpha = fminf(0.99f, q1.w * __expf(power));
+                if (alpha < (1.f / 255.f)) continue;
+                const float test_T = Tr * (1.f - alpha);
+                if (test_T < 0.0001f) { done = true; break; }
+                const float4 q2 = s_q2[j];
+                const float w = alpha * Tr;
+                C0 += q2.x * w; C1 += q2.y * w; C2 += q2.z * w;
+                D += q0.z * w;
+                O += w;
+                if (NTOUCH) { if (test_T > 0.5f) atomicAdd(&s_touch[j], 1u); }
+                Tr = test_T;
+                last = contributor;
+            }
+        }
+        if (NTOUCH) {
+            __syncthreads();
+            if (idx < end && s_touch[tid]) atomicAdd(n_touched + (size_t)v * d.G + s_id[tid], (int)s_touch[tid]);
+        }
+    }
+    if (inside) {
+        const size_t P = (size_t)d.H * d.W;
+        const size_t pix = (size_t)py * d.W + px;
+        const GsrView &vw = views[v];
+        ws.final_T[v * P + pix] = Tr;
+        ws.n_contrib[v * P + pix] = last;
+        image[(v * 3 + 0) * P + pix] = C0 + Tr * vw.bg[0];
+        image[(v * 3 + 1) * P + pix] = C1 + Tr * vw.bg[1];
+        image[(v * 3 + 2) * P + pix] = C2 + Tr * vw.bg[2];
+        out_depth[v * P + pix] = D;
+        out_opacity[v * P + pix] = O;
+    }
+}
+
+// ------------------------------------------------------------------ host
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int layout(const GsrDims &d, long long cap, GsrLayout &L)
+{
+    if (d.B <= 0 || d.Vt <= 0 || d.G <= 0 || d.H <= 0 || d.W <= 0 || cap <= 0) return GSR_EINVAL;
+    if (d.M < 0 || d.sh_degree < 0 || d.sh_degree > 4) return GSR_EINVAL;
+    if (d.M > 0 && (d.sh_degree + 1) * (d.sh_degree + 1) > d.M) return GSR_EINVAL;
+    if (d.M == 0 && d.sh_degree != 0) return GSR_EINVAL;
+    if (cap > 0xffffffffll) return GSR_EINVAL;
+    const size_t V = (size_t)d.B * d.Vt, T = (size_t)tiles_x(d.W) * tiles_y(d.H), P = (size_t)d.H * d.W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.records = take(V * d.G * sizeof(SplatRec));
+    L.tile_count = take(V * T * 4);
+    L.tile_offset = take((V * T + 1) * 4);
+    L.tile_cursor = take(V * T * 4);
+    L.pairs = take((size_t)cap * 8);
+    L.point_list = take((size_t)cap * 4);
+    L.final_T = take(V * P * 4);
+    L.n_contrib = take(V * P * 4);
+    L.grad_rec = take(V * d.G * 12 * 4);
+    L.status = take(GSR_STATUS_WORDS * 4);
+    L.total = off;
+    return GSR_OK;
+}
+
+Ptrs carve(void *base, const GsrLayout &L)
+{
+    char *p = static_cast<char *>(base);
+    Ptrs w;
+    w.records = reinterpret_cast<SplatRec *>(p + L.records);
+    w.tile_count = reinterpret_cast<uint32_t *>(p + L.tile_count);
+    w.tile_offset = reinterpret_cast<uint32_t *>(p + L.tile_offset);
+    w.tile_cursor = reinterpret_cast<uint32_t *>(p + L.tile_cursor);
+    w.pairs = reinterpret_cast<unsigned long long *>(p + L.pairs);
+    w.point_list = reinterpret_cast<uint32_t *>(p + L.point_list);
+    w.final_T = reinterpret_cast<float *>(p + L.final_T);
+    w.n_contrib = reinterpret_cast<uint32_t *>(p + L.n_contrib);
+    w.grad_rec = reinterpret_cast<float *>(p + L.grad_rec);
+    w.status = reinterpret_cast<int32_t *>(p + L.status);
+    return w;
+}
+
+int forward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *opac,
+            const float *shs, long long cap, void *workspace, size_t workspace_bytes, float *image, float *depth,
+            float *opacity, int32_t *radii, int32_t *n_touched, int32_t *status, hipStream_t stream)
+{
+    GsrLayout L;
+    int rc = layout(d, cap, L);
+    if (rc != GSR_OK) return rc;
+    if (!views || !means || !cov6 || !opac || !shs || !workspace || !image || !depth || !opacity || !radii || !status)
+        return GSR_EINVAL;
+    const bool ntouch = (d.flags & GSR_FLAG_NTOUCHED) != 0;
+    if (ntouch && !n_touched) return GSR_EINVAL;
+    if (workspace_bytes < L.total) return GSR_ENOSPACE;
+    Ptrs ws = carve(workspace, L);
+    const int V = d.B * d.Vt, gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
+
+    if (hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+    if (ntouch && hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+
+    const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
+    hipLaunchKernelGGL(k_preprocess, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status);
+    hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, T, ws);
+    if (ntouch)
+        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth, opacity,
+                           n_touched);
+    else
+        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth,
+                           opacity, n_touched);
+    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ELAUNCH;
+}
+
+}  // namespace gsr

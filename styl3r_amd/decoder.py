@@ -1,0 +1,119 @@
+"""Decoder boundary: the reference's `Decoder` API on top of the batched HIP
+rasterizer.
+
+Mirrors
+  * `DecoderSplattingCUDA.forward`  src/model/decoder/decoder_splatting_cuda.py:37-68
+  * `render_cuda`                   src/model/decoder/cuda_splatting.py:46-133
+  * `DecoderOutput`                 src/model/decoder/decoder.py:18-24
+with two MI355X-first changes that keep the results identical: the Gaussian
+tensors are NOT replicated per view (the kernels index scene = view // v), and
+all b*v views go through ONE launch sequence instead of a Python loop with two
+host syncs per view; the scale-invariance rescale (cuda_splatting.py:65-72) is
+folded into the kernels through `GsrView.scale`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import isqrt
+from typing import Literal, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .camera import get_fov, get_projection_matrix
+from .rasterizer import pack_views, rasterize_views
+
+DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
+
+
+@dataclass
+class Gaussians:
+    """src/model/types.py:8-12"""
+    means: Tensor        # (b,G,3)
+    covariances: Tensor  # (b,G,3,3)
+    harmonics: Tensor    # (b,G,3,d_sh)
+    opacities: Tensor    # (b,G)
+
+
+@dataclass
+class DecoderOutput:
+    color: Tensor            # (b,v,3,h,w)
+    depth: Optional[Tensor]  # (b,v,h,w)
+
+
+@dataclass
+class DecoderSplattingCUDACfg:
+    name: Literal["splatting_cuda"]
+    background_color: list
+    make_scale_invariant: bool
+
+
+_TRIU = ((0, 0, 0, 1, 1, 2), (0, 1, 2, 1, 2, 2))
+
+
+def prepare_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                  scale_invariant: bool) -> Tensor:
+    """(n,4,4) c2w, (n,3,3), (n,), (n,), (n,3) -> packed (n,64) GsrView rows; pure device-side torch ops in the
+    order of cuda_splatting.py:65-88."""
+    scale = None
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
+        near = near * scale
+        far = far * scale
+    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
+    tan_x = (0.5 * fov_x).tan()
+    tan_y = (0.5 * fov_y).tan()
+    proj_raw = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
+    view = extrinsics.inverse().transpose(1, 2)
+    full = view @ proj_raw
+    return pack_views(view, full, proj_raw, extrinsics[:, :3, 3], tan_x, tan_y, background, scale)
+
+
+def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
+               gaussians: Gaussians, views_per_scene: int, scale_invariant: bool = True, use_sh: bool = True,
+               cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None):
+    """Batched counterpart of `render_cuda`: (b*v) cameras, b un-replicated Gaussian sets.
+    Returns (color (b*v,3,h,w), depth (b*v,h,w))."""
+    n = gaussians.harmonics.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussians.harmonics.permute(0, 1, 3, 2).contiguous()            # (b,g,n,3)  cuda_splatting.py:76
+    cov6 = gaussians.covariances[:, :, _TRIU[0], _TRIU[1]]                 # (b,g,6)    cuda_splatting.py:118,126
+    views = prepare_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    colors = shs if use_sh else shs[:, :, 0, :].contiguous()
+    out = rasterize_views(gaussians.means, cov6, gaussians.opacities, colors, views, image_shape, views_per_scene,
+                          sh_degree=degree, use_sh=use_sh, theta=cam_rot_delta, rho=cam_trans_delta)
+    return out.image, out.depth
+
+
+class DecoderSplattingHIP(nn.Module):
+    """Same constructor cfg / forward signature / DecoderOutput as DecoderSplattingCUDA."""
+
+    def __init__(self, cfg: DecoderSplattingCUDACfg) -> None:
+        super().__init__()
+        self.cfg = cfg
+        self.make_scale_invariant = cfg.make_scale_invariant
+        self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
+                             persistent=False)
+
+    def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape, depth_mode: Optional[DepthRenderingMode] = None,
+                cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None) -> DecoderOutput:
+        b, v = extrinsics.shape[:2]
+        flat = lambda t: t.reshape(b * v, *t.shape[2:])
+        color, depth = render_hip(
+            flat(extrinsics), flat(intrinsics), flat(near), flat(far), image_shape,
+            self.background_color[None].expand(b * v, 3), gaussians, v,
+            scale_invariant=self.make_scale_invariant,
+            cam_rot_delta=flat(cam_rot_delta) if cam_rot_delta is not None else None,
+            cam_trans_delta=flat(cam_trans_delta) if cam_trans_delta is not None else None)
+        h, w = image_shape
+        return DecoderOutput(color.reshape(b, v, 3, h, w), depth.reshape(b, v, h, w))
+
+
+def get_decoder(cfg: DecoderSplattingCUDACfg) -> DecoderSplattingHIP:
+    """src/model/decoder/__init__.py registry: {"splatting_cuda": ...}."""
+    if cfg.name != "splatting_cuda":
+        raise KeyError(cfg.name)
+    return DecoderSplattingHIP(cfg)

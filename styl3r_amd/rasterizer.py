@@ -1,0 +1,214 @@
+"""Host side of the HIP rasterizer: autograd binding over the C ABI and the
+drop-in `diff_gaussian_rasterization` interface.
+
+Mirrors the third-party module the reference imports at
+src/model/decoder/cuda_splatting.py:5-8 and calls at :101-129:
+`GaussianRasterizationSettings` (13 fields) and `GaussianRasterizer(settings)(
+means3D, means2D, opacities, shs, colors_precomp, scales, rotations,
+cov3D_precomp, theta, rho)` -> `(image, radii, depth, opacity, n_touched)`.
+
+PyTorch is plumbing here (device memory, the current HIP stream, autograd);
+all rasterization runs in libgsr_hip.so.  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+# grow-only hint for the (tile, Gaussian) pair capacity, keyed by problem shape
+_CAP_HINT: dict = {}
+# parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
+KEEP_DEBUG = False
+LAST_DEBUG: dict = {}
+
+
+def _ptr(t: Optional[Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pack_views(viewmatrix: Tensor, projmatrix: Tensor, projmatrix_raw: Tensor, campos: Tensor, tanfovx: Tensor,
+               tanfovy: Tensor, bg: Tensor, scale: Optional[Tensor] = None) -> Tensor:
+    """Assemble the (V, 64) float32 GsrView array (include/gsr.h) on the inputs' device.
+    All arguments carry a leading V dimension; nothing touches the host."""
+    V = viewmatrix.shape[0]
+    dev = viewmatrix.device
+    out = torch.zeros((V, _lib.GSR_VIEW_FLOATS), dtype=torch.float32, device=dev)
+    out[:, 0:16] = viewmatrix.reshape(V, 16)
+    out[:, 16:32] = projmatrix.reshape(V, 16)
+    out[:, 32:48] = projmatrix_raw.reshape(V, 16)
+    out[:, 48:51] = campos.reshape(V, 3)
+    out[:, 51] = tanfovx.reshape(V)
+    out[:, 52] = tanfovy.reshape(V)
+    out[:, 53:56] = bg.reshape(V, 3)
+    out[:, 56] = 1.0 if scale is None else scale.reshape(V)
+    return out
+
+
+class RasterOutput(NamedTuple):
+    image: Tensor      # (V,3,H,W)
+    radii: Tensor      # (V,G) int32
+    depth: Tensor      # (V,H,W)
+    opacity: Tensor    # (V,H,W)
+    n_touched: Tensor  # (V,G) int32 (zeros unless requested)
+
+
+class _Rasterize(torch.autograd.Function):
+    """V = B*Vt views of B scenes in one launch sequence (include/gsr.h)."""
+
+    @staticmethod
+    def forward(ctx, means, cov6, opac, colors, views, means2D, theta, rho, H, W, Vt, sh_degree, use_sh, want_ntouched):
+        if not means.is_cuda:
+            raise RuntimeError("styl3r_amd rasterizer needs tensors on an MI355X (HIP) device; there is no CPU path")
+        lib = _lib.load()
+        means = means.contiguous().float(); cov6 = cov6.contiguous().float(); opac = opac.contiguous().float()
+        colors = colors.contiguous().float(); views = views.contiguous().float()
+        B, G = means.shape[0], means.shape[1]
+        V = views.shape[0]
+        assert V == B * Vt, (V, B, Vt)
+        assert cov6.shape == (B, G, 6) and opac.shape[:2] == (B, G)
+        M = colors.shape[2] if use_sh else 0
+        flags = _lib.GSR_FLAG_NTOUCHED if want_ntouched else 0
+        dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags)
+        dev = means.device
+        image = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        opacity = torch.empty((V, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((V, G), dtype=torch.int32, device=dev)
+        n_touched = torch.zeros((V, G) if want_ntouched else (1, 1), dtype=torch.int32, device=dev)
+        status = torch.zeros(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        key = (B, Vt, G, H, W)
+        cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
+        while True:
+            L = _lib.workspace_layout(dims, cap)
+            ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
+            rc = lib.gsr_forward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
+                                 cap, _ptr(ws), L.total, _ptr(image), _ptr(depth), _ptr(opacity), _ptr(radii),
+                                 _ptr(n_touched) if want_ntouched else None, _ptr(status), stream)
+            _lib.check(rc, "gsr_forward")
+            st = status.cpu()
+            R = (int(st[3]) << 32) | (int(st[0]) & 0xFFFFFFFF)
+            if int(st[1]) == 0:
+                break
+            if R > 0xFFFFFFFF:
+                raise RuntimeError(f"gsr_forward: {R} (tile, Gaussian) pairs exceed the 2^32 list limit")
+            cap = int(R * 1.25) + 1024
+        _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
+        ctx.dims, ctx.cap, ctx.ws_bytes = dims, cap, L.total
+        ctx.want_tau = theta is not None or rho is not None
+        ctx.want_m2d = means2D is not None and means2D.requires_grad
+        ctx.has = (theta is not None, rho is not None, means2D is not None)
+        ctx.save_for_backward(means, cov6, colors, views, ws)
+        ctx.mark_non_differentiable(radii, n_touched)
+        ctx.num_pairs = R
+        if KEEP_DEBUG:
+            LAST_DEBUG.update(ws=ws, layout=L, dims=dims, cap=cap, num_pairs=R, status=st)
+        return image, radii, depth, opacity, n_touched
+
+    @staticmethod
+    def backward(ctx, g_image, g_radii, g_depth, g_opacity, g_ntouched):
+        lib = _lib.load()
+        means, cov6, colors, views, ws = ctx.saved_tensors
+        dims = ctx.dims
+        B, G, V = dims.B, dims.G, dims.B * dims.Vt
+        dev = means.device
+        g_image = g_image.contiguous().float()
+        g_depth = g_depth.contiguous().float() if g_depth is not None else None
+        d_means = torch.empty_like(means); d_cov6 = torch.empty_like(cov6)
+        d_opac = torch.empty((B, G), dtype=torch.float32, device=dev)
+        d_colors = torch.empty_like(colors)
+        d_m2d = torch.empty((V, G, 3), dtype=torch.float32, device=dev) if ctx.want_m2d else None
+        d_tau = torch.empty((V, 6), dtype=torch.float32, device=dev) if ctx.want_tau else None
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.gsr_backward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(colors), ctx.cap, _ptr(ws),
+                              ctx.ws_bytes, _ptr(g_image), _ptr(g_depth), _ptr(d_means), _ptr(d_cov6), _ptr(d_opac),
+                              _ptr(d_colors), _ptr(d_m2d), _ptr(d_tau), stream)
+        _lib.check(rc, "gsr_backward")
+        has_theta, has_rho, has_m2d = ctx.has
+        g_theta = d_tau[:, 3:6] if (ctx.want_tau and has_theta) else None
+        g_rho = d_tau[:, 0:3] if (ctx.want_tau and has_rho) else None
+        return (d_means, d_cov6, d_opac, d_colors, None, d_m2d if has_m2d else None, g_theta, g_rho,
+                None, None, None, None, None, None)
+
+
+def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, views: Tensor, image_hw,
+                    views_per_scene: int, sh_degree: int = 0, use_sh: bool = True, means2D: Optional[Tensor] = None,
+                    theta: Optional[Tensor] = None, rho: Optional[Tensor] = None,
+                    want_n_touched: bool = False) -> RasterOutput:
+    """Batched entry point: means (B,G,3), cov6 (B,G,6), opacities (B,G), colors = SH (B,G,M,3) or RGB (B,G,3),
+    views (B*Vt, 64) packed with `pack_views`; theta/rho (B*Vt, 3) receive the pose gradient."""
+    H, W = image_hw
+    out = _Rasterize.apply(means, cov6, opacities, colors, views, means2D, theta, rho, int(H), int(W),
+                           int(views_per_scene), int(sh_degree), bool(use_sh), bool(want_n_touched))
+    return RasterOutput(*out)
+
+
+# ---------------------------------------------------------------------------
+# drop-in interface of `diff_gaussian_rasterization`
+# ---------------------------------------------------------------------------
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    projmatrix_raw: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _cov6_from_scale_rot(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+    """3DGS convention: quaternion (r,x,y,z), Sigma = R S S^T R^T, returned as xx,xy,xz,yy,yz,zz."""
+    q = rotations / rotations.norm(dim=-1, keepdim=True)
+    r, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    Mm = R * (scale_modifier * scales)[:, None, :]
+    S = Mm @ Mm.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+
+
+class GaussianRasterizer(nn.Module):
+    """One view per call, exactly like the module the reference instantiates at cuda_splatting.py:116."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, theta=None, rho=None):
+        s = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        dev = means3D.device
+        if cov3D_precomp is None:
+            cov3D_precomp = _cov6_from_scale_rot(scales, rotations, float(s.scale_modifier))
+        f32 = dict(dtype=torch.float32, device=dev)
+        tanx = torch.as_tensor(s.tanfovx, **f32).reshape(1)
+        tany = torch.as_tensor(s.tanfovy, **f32).reshape(1)
+        views = pack_views(s.viewmatrix.to(**f32)[None], s.projmatrix.to(**f32)[None],
+                           s.projmatrix_raw.to(**f32)[None], s.campos.to(**f32)[None], tanx, tany,
+                           s.bg.to(**f32)[None])
+        use_sh = shs is not None
+        colors = shs if use_sh else colors_precomp
+        th = theta.reshape(1, 3) if theta is not None else None
+        rh = rho.reshape(1, 3) if rho is not None else None
+        m2d = means2D[None] if means2D is not None else None
+        out = rasterize_views(means3D[None], cov3D_precomp[None], opacities.reshape(1, -1), colors[None], views,
+                              (int(s.image_height), int(s.image_width)), 1, int(s.sh_degree), use_sh, m2d, th, rh,
+                              want_n_touched=True)
+        return out.image[0], out.radii[0], out.depth, out.opacity, out.n_touched[0]
