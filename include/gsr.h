@@ -64,6 +64,7 @@ typedef struct GsrDims {
     int32_t M;          /* SH coefficients per channel in `shs` (G,M,3); 0 => `shs` is precomputed RGB (G,3) */
     int32_t sh_degree;  /* active degree 0..4, (sh_degree+1)^2 <= M */
     int32_t flags;      /* GSR_FLAG_* */
+    void *profile;      /* optional GsrProfile* (gsr_profile_create): per-stage hipEvent timing; NULL = off */
 } GsrDims;
 
 #define GSR_FLAG_NTOUCHED 1  /* forward: also count n_touched (costs LDS + global atomics) */
@@ -122,6 +123,26 @@ int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means, 
                  const float *shs, int64_t pair_capacity, void *workspace, size_t workspace_bytes,
                  const float *dL_dimage, const float *dL_ddepth, float *dL_dmeans, float *dL_dcov6,
                  float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau, void *stream);
+
+/*
+ * Optional per-stage timing with hipEvents recorded on the caller's stream
+ * between the kernels of gsr_forward / gsr_backward (bench.py's live roofline
+ * measurement).  A profile holds event pairs for `max_calls` forward and
+ * `max_calls` backward calls; gsr_profile_read waits for them, returns the
+ * summed milliseconds and launch counts per stage and resets the profile.
+ */
+#define GSR_N_STAGES 7
+#define GSR_STAGE_PREPROCESS 0
+#define GSR_STAGE_SCAN 1
+#define GSR_STAGE_SCATTER 2
+#define GSR_STAGE_SORT 3
+#define GSR_STAGE_COMPOSITE_FWD 4
+#define GSR_STAGE_COMPOSITE_BWD 5
+#define GSR_STAGE_PREPROCESS_BWD 6
+typedef struct GsrProfile GsrProfile;
+GsrProfile *gsr_profile_create(int max_calls);
+void gsr_profile_destroy(GsrProfile *prof);
+int gsr_profile_read(GsrProfile *prof, float *ms_sum /* [GSR_N_STAGES] */, int32_t *count /* [GSR_N_STAGES] */);
 
 /* Library / build identification ("gsr-hip gfx950 <version>"). */
 const char *gsr_version(void);

@@ -49,7 +49,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 class GsrDims(C.Structure):
     _fields_ = [("B", C.c_int32), ("Vt", C.c_int32), ("G", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("M", C.c_int32), ("sh_degree", C.c_int32), ("flags", C.c_int32)]
+                ("M", C.c_int32), ("sh_degree", C.c_int32), ("flags", C.c_int32), ("profile", C.c_void_p)]
 
 
 class GsrLayout(C.Structure):
@@ -60,7 +60,10 @@ class GsrLayout(C.Structure):
 GSR_FLAG_NTOUCHED = 1
 GSR_STATUS_WORDS = 8
 GSR_VIEW_FLOATS = 64
-EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version")
+GSR_N_STAGES = 7
+STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
+EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
+           "gsr_profile_destroy", "gsr_profile_read")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
           -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
 
@@ -85,6 +88,12 @@ def load() -> C.CDLL:
     lib.gsr_backward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_version.restype = C.c_char_p
+    lib.gsr_profile_create.argtypes = [C.c_int]
+    lib.gsr_profile_create.restype = C.c_void_p
+    lib.gsr_profile_destroy.argtypes = [C.c_void_p]
+    lib.gsr_profile_destroy.restype = None
+    lib.gsr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.gsr_profile_read.restype = C.c_int
     _lib = lib
     return lib
 
@@ -98,3 +107,23 @@ def workspace_layout(dims: GsrDims, capacity: int) -> GsrLayout:
     L = GsrLayout()
     check(load().gsr_workspace_layout(C.byref(dims), int(capacity), C.byref(L)), "gsr_workspace_layout")
     return L
+
+
+class StageProfile:
+    """hipEvent stage timer of the library (include/gsr.h GsrProfile); pass `.handle` via rasterizer.PROFILE."""
+
+    def __init__(self, max_calls: int):
+        self.handle = load().gsr_profile_create(int(max_calls))
+        if not self.handle:
+            raise RuntimeError("gsr_profile_create failed")
+
+    def read(self) -> dict:
+        ms = (C.c_float * GSR_N_STAGES)()
+        cnt = (C.c_int32 * GSR_N_STAGES)()
+        check(load().gsr_profile_read(self.handle, ms, cnt), "gsr_profile_read")
+        return {STAGE_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(GSR_N_STAGES)}
+
+    def close(self):
+        if self.handle:
+            load().gsr_profile_destroy(self.handle)
+            self.handle = None

@@ -1,4 +1,6 @@
 // gsr_api.hip -- the C ABI declared in include/gsr.h (no torch, no exceptions).
+#include <new>
+
 #include "gsr_common.h"
 
 namespace gsr {
@@ -41,6 +43,47 @@ __attribute__((visibility("default"))) int gsr_backward(const GsrDims *dims, con
     if (!dims) return GSR_EINVAL;
     return gsr::backward(*dims, views, means, cov6, shs, pair_capacity, workspace, workspace_bytes, dL_dimage, dL_ddepth,
                          dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau, static_cast<hipStream_t>(stream));
+}
+
+__attribute__((visibility("default"))) GsrProfile *gsr_profile_create(int max_calls)
+{
+    if (max_calls <= 0) return nullptr;
+    GsrProfile *p = new (std::nothrow) GsrProfile;
+    if (!p) return nullptr;
+    p->max_calls = max_calls; p->next_fwd = p->next_bwd = 0;
+    const size_t n = (size_t)max_calls * GSR_N_STAGES * 2;
+    p->ev = new (std::nothrow) hipEvent_t[n];
+    if (!p->ev) { delete p; return nullptr; }
+    for (size_t i = 0; i < n; ++i)
+        if (hipEventCreate(&p->ev[i]) != hipSuccess) { p->ev[i] = nullptr; }
+    return p;
+}
+
+__attribute__((visibility("default"))) void gsr_profile_destroy(GsrProfile *p)
+{
+    if (!p) return;
+    const size_t n = (size_t)p->max_calls * GSR_N_STAGES * 2;
+    for (size_t i = 0; i < n; ++i)
+        if (p->ev[i]) (void)hipEventDestroy(p->ev[i]);
+    delete[] p->ev;
+    delete p;
+}
+
+__attribute__((visibility("default"))) int gsr_profile_read(GsrProfile *p, float *ms_sum, int32_t *count)
+{
+    if (!p || !ms_sum || !count) return GSR_EINVAL;
+    for (int s = 0; s < GSR_N_STAGES; ++s) { ms_sum[s] = 0.f; count[s] = 0; }
+    for (int s = 0; s < GSR_N_STAGES; ++s) {
+        const int n = (s <= GSR_STAGE_COMPOSITE_FWD) ? p->next_fwd : p->next_bwd;
+        for (int c = 0; c < n; ++c) {
+            float ms = 0.f;
+            if (hipEventSynchronize(p->at(c, s, 1)) != hipSuccess) return GSR_ELAUNCH;
+            if (hipEventElapsedTime(&ms, p->at(c, s, 0), p->at(c, s, 1)) != hipSuccess) return GSR_ELAUNCH;
+            ms_sum[s] += ms; count[s] += 1;
+        }
+    }
+    p->next_fwd = p->next_bwd = 0;
+    return GSR_OK;
 }
 
 __attribute__((visibility("default"))) const char *gsr_version(void) { return "gsr-hip gfx950 0.1.0"; }

@@ -34,6 +34,30 @@ struct Ptrs {             // carved workspace
     int32_t *status;
 };
 
+}  // namespace gsr
+
+// host-side stage timer (include/gsr.h GsrProfile)
+struct GsrProfile {
+    int max_calls;
+    int next_fwd, next_bwd;
+    hipEvent_t *ev;  // [max_calls][GSR_N_STAGES][2]
+    hipEvent_t &at(int call, int stage, int which) { return ev[((size_t)call * GSR_N_STAGES + stage) * 2 + which]; }
+};
+
+namespace gsr {
+
+struct StageTimer {
+    GsrProfile *p; int slot; hipStream_t s;
+    StageTimer(void *prof, bool fwd, hipStream_t stream) : p(static_cast<GsrProfile *>(prof)), slot(-1), s(stream)
+    {
+        if (!p) return;
+        int &n = fwd ? p->next_fwd : p->next_bwd;
+        if (n < p->max_calls) slot = n++;
+    }
+    void begin(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 0), s); }
+    void end(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 1), s); }
+};
+
 __host__ __device__ inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
 __host__ __device__ inline int tiles_y(int H) { return (H + TILE - 1) / TILE; }
 

@@ -393,21 +393,29 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     if (workspace_bytes < L.total) return GSR_ENOSPACE;
     Ptrs ws = carve(workspace, L);
     const int V = d.B * d.Vt, gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
+    (void)hipGetLastError();  // drop stale (non-sticky) errors of earlier runtime calls, e.g. hipErrorNotReady polls
+    StageTimer tm(d.profile, true, stream);
 
     if (hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream) != hipSuccess) return GSR_ELAUNCH;
     if (ntouch && hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream) != hipSuccess) return GSR_ELAUNCH;
 
     const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
+    tm.begin(GSR_STAGE_PREPROCESS);
     hipLaunchKernelGGL(k_preprocess, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii);
+    tm.end(GSR_STAGE_PREPROCESS); tm.begin(GSR_STAGE_SCAN);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status);
+    tm.end(GSR_STAGE_SCAN); tm.begin(GSR_STAGE_SCATTER);
     hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
+    tm.end(GSR_STAGE_SCATTER); tm.begin(GSR_STAGE_SORT);
     hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, T, ws);
+    tm.end(GSR_STAGE_SORT); tm.begin(GSR_STAGE_COMPOSITE_FWD);
     if (ntouch)
         hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth, opacity,
                            n_touched);
     else
         hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth,
                            opacity, n_touched);
+    tm.end(GSR_STAGE_COMPOSITE_FWD);
     return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ELAUNCH;
 }
 

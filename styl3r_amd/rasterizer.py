@@ -25,6 +25,8 @@ _CAP_HINT: dict = {}
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
 KEEP_DEBUG = False
 LAST_DEBUG: dict = {}
+# bench.py sets PROFILE to a _lib.StageProfile to time every stage with hipEvents on the launch stream
+PROFILE = None
 
 
 def _ptr(t: Optional[Tensor]):
@@ -73,7 +75,8 @@ class _Rasterize(torch.autograd.Function):
         assert cov6.shape == (B, G, 6) and opac.shape[:2] == (B, G)
         M = colors.shape[2] if use_sh else 0
         flags = _lib.GSR_FLAG_NTOUCHED if want_ntouched else 0
-        dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags)
+        dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags,
+                            PROFILE.handle if PROFILE is not None else None)
         dev = means.device
         image = torch.empty((V, 3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
