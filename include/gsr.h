@@ -144,6 +144,9 @@ GsrProfile *gsr_profile_create(int max_calls);
 void gsr_profile_destroy(GsrProfile *prof);
 int gsr_profile_read(GsrProfile *prof, float *ms_sum /* [GSR_N_STAGES] */, int32_t *count /* [GSR_N_STAGES] */);
 
+/* Text of the HIP error behind the calling thread's last GSR_ELAUNCH ("" if none). */
+const char *gsr_last_error(void);
+
 /* Library / build identification ("gsr-hip gfx950 <version>"). */
 const char *gsr_version(void);
 

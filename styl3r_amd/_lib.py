@@ -63,7 +63,7 @@ GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7
 STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
-           "gsr_profile_destroy", "gsr_profile_read")
+           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
           -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
 
@@ -79,6 +79,11 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP rasterizer has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    # The library must share ONE HIP runtime with the process that owns the device pointers and
+    # streams it is handed.  torch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's):
+    # load torch's first so the loader resolves our NEEDED entry to it instead of a second copy
+    # (two runtimes => hipErrorNoDevice inside the library).
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
     lib.gsr_workspace_layout.argtypes = [C.POINTER(GsrDims), i64, C.POINTER(GsrLayout)]
@@ -88,6 +93,7 @@ def load() -> C.CDLL:
     lib.gsr_backward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_version.restype = C.c_char_p
+    lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_profile_create.argtypes = [C.c_int]
     lib.gsr_profile_create.restype = C.c_void_p
     lib.gsr_profile_destroy.argtypes = [C.c_void_p]
@@ -100,7 +106,8 @@ def load() -> C.CDLL:
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")
+        detail = load().gsr_last_error().decode() if rc == -3 else ""
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)} {detail}")
 
 
 def workspace_layout(dims: GsrDims, capacity: int) -> GsrLayout:

@@ -14,7 +14,14 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
              hipStream_t stream);
 }  // namespace gsr
 
+namespace gsr { thread_local hipError_t g_last_hip_error = hipSuccess; }
+
 extern "C" {
+
+__attribute__((visibility("default"))) const char *gsr_last_error(void)
+{
+    return gsr::g_last_hip_error == hipSuccess ? "" : hipGetErrorString(gsr::g_last_hip_error);
+}
 
 __attribute__((visibility("default"))) int gsr_workspace_layout(const GsrDims *dims, int64_t pair_capacity, GsrLayout *out)
 {

@@ -390,15 +390,15 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
     const int V = d.B * d.Vt, T = tiles_x(d.W) * tiles_y(d.H);
     (void)hipGetLastError();
     StageTimer tm(d.profile, false, stream);
-    if (hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream) != hipSuccess) return GSR_ELAUNCH;
-    if (dL_dtau && hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+    if (!hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
+    if (dL_dtau && !hip_ok(hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream))) return GSR_ELAUNCH;
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
     hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(256), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
     tm.end(GSR_STAGE_COMPOSITE_BWD); tm.begin(GSR_STAGE_PREPROCESS_BWD);
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.G + 255) / 256, d.B), dim3(256), 0, stream, d, views, means, cov6, shs,
                        ws, dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau);
     tm.end(GSR_STAGE_PREPROCESS_BWD);
-    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ELAUNCH;
+    return launch_status();
 }
 
 }  // namespace gsr

@@ -46,6 +46,22 @@ struct GsrProfile {
 
 namespace gsr {
 
+// remembers the HIP error behind a GSR_ELAUNCH for gsr_last_error()
+extern thread_local hipError_t g_last_hip_error;
+inline int launch_status()
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return GSR_OK;
+    g_last_hip_error = e;
+    return GSR_ELAUNCH;
+}
+inline bool hip_ok(hipError_t e)
+{
+    if (e == hipSuccess) return true;
+    g_last_hip_error = e;
+    return false;
+}
+
 struct StageTimer {
     GsrProfile *p; int slot; hipStream_t s;
     StageTimer(void *prof, bool fwd, hipStream_t stream) : p(static_cast<GsrProfile *>(prof)), slot(-1), s(stream)

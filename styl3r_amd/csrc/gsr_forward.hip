@@ -396,8 +396,8 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     (void)hipGetLastError();  // drop stale (non-sticky) errors of earlier runtime calls, e.g. hipErrorNotReady polls
     StageTimer tm(d.profile, true, stream);
 
-    if (hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream) != hipSuccess) return GSR_ELAUNCH;
-    if (ntouch && hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream) != hipSuccess) return GSR_ELAUNCH;
+    if (!hip_ok(hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream))) return GSR_ELAUNCH;
+    if (ntouch && !hip_ok(hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream))) return GSR_ELAUNCH;
 
     const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
     tm.begin(GSR_STAGE_PREPROCESS);
@@ -416,7 +416,7 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
         hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth,
                            opacity, n_touched);
     tm.end(GSR_STAGE_COMPOSITE_FWD);
-    return hipGetLastError() == hipSuccess ? GSR_OK : GSR_ELAUNCH;
+    return launch_status();
 }
 
 }  // namespace gsr

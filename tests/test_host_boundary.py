@@ -1,0 +1,98 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports every symbol
+include/gsr.h declares, the workspace layout is sane, and the host-side decoder
+boundary reproduces the golden vectors captured from the reference's own
+render_cuda (tests/golden/make_decoder_fixtures.py)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from styl3r_amd import _lib
+from styl3r_amd.decoder import _TRIU, prepare_views
+
+ROOT = Path(__file__).resolve().parents[1]
+GOLD = np.load(ROOT / "tests/golden/decoder_boundary.npz")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build_library()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = (ROOT / "include/gsr.h").read_text()
+    declared = set(re.findall(r"\b(gsr_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gsr_version().decode().startswith("gsr-hip gfx950")
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_lib.GsrDims) == 40          # 8 x int32 + pointer
+    assert C.sizeof(_lib.GsrLayout) == 11 * C.sizeof(C.c_size_t)
+    assert _lib.GSR_VIEW_FLOATS * 4 == 256
+
+
+def test_workspace_layout_and_argument_checks(lib):
+    d = _lib.GsrDims(10, 4, 65536, 256, 256, 1, 0, 0, None)
+    L = _lib.workspace_layout(d, 1 << 22)
+    offs = [getattr(L, n) for n, _ in L._fields_]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert L.tile_count - L.records >= 40 * 65536 * 48
+    assert L.point_list - L.pairs >= (1 << 22) * 8
+    for bad in (_lib.GsrDims(0, 4, 10, 16, 16, 1, 0, 0, None), _lib.GsrDims(1, 1, 10, 16, 16, 1, 1, 0, None),
+                _lib.GsrDims(1, 1, 10, 16, 16, 0, 2, 0, None), _lib.GsrDims(1, 1, 10, 16, 16, 25, 5, 0, None)):
+        out = _lib.GsrLayout()
+        assert lib.gsr_workspace_layout(C.byref(bad), 100, C.byref(out)) == -1
+    out = _lib.GsrLayout()
+    assert lib.gsr_workspace_layout(C.byref(d), 0, C.byref(out)) == -1
+    # null pointers are rejected before anything is launched (no GPU needed)
+    assert lib.gsr_forward(C.byref(d), *([None] * 5), 1 << 20, None, 0, *([None] * 7)) == -1
+    assert lib.gsr_backward(C.byref(d), *([None] * 4), 1 << 20, None, 0, *([None] * 9)) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_path_never_imports_the_oracle():
+    for py in (ROOT / "styl3r_amd").rglob("*.py"):
+        assert "oracle" not in py.read_text().replace("the oracle", "").replace("oracle's", "").replace("fp32 oracle", "") \
+            or py.name == "scenes.py", py
+    for py in (ROOT / "diff_gaussian_rasterization").rglob("*.py"):
+        assert "oracle" not in py.read_text()
+
+
+@pytest.mark.parametrize("tag,scale_inv", [("si", True), ("raw", False)])
+def test_view_setup_matches_reference_render_cuda(tag, scale_inv):
+    """prepare_views == the matrices / tanfov / campos the reference hands to the rasterizer
+    (cuda_splatting.py:65-115), bit for bit on the same CPU torch ops."""
+    g = lambda k: torch.from_numpy(GOLD[f"{tag}_in_{k}"])
+    views = prepare_views(g("extrinsics"), g("intrinsics"), g("near"), g("far"), g("bg"), scale_inv).numpy()
+    for v in range(3):
+        p = f"{tag}_v{v}_"
+        row = views[v]
+        assert np.array_equal(row[0:16].reshape(4, 4), GOLD[p + "viewmatrix"])
+        assert np.array_equal(row[16:32].reshape(4, 4), GOLD[p + "projmatrix"])
+        assert np.array_equal(row[32:48].reshape(4, 4), GOLD[p + "projmatrix_raw"])
+        assert np.array_equal(row[48:51], GOLD[p + "campos"])
+        # the reference passes tanfov through .item() (fp32 -> python float): same fp32 value
+        assert np.array_equal(row[51:53], GOLD[p + "tanfov"].astype(np.float32))
+        assert np.array_equal(row[53:56], GOLD[p + "bg"])
+        s = np.float32(row[56])
+        # Gaussian-side arguments: the kernel folds the scale in; the products it forms are the
+        # reference's pre-scaled tensors bit for bit (one fp32 multiply each)
+        assert np.array_equal(GOLD[f"{tag}_in_means"] * s, GOLD[p + "means3D"])
+        cov6 = GOLD[f"{tag}_in_cov"][:, _TRIU[0], _TRIU[1]]
+        assert np.array_equal(cov6 * np.float32(s * s), GOLD[p + "cov3D_precomp"])
+        assert np.array_equal(GOLD[f"{tag}_in_sh"].transpose(0, 2, 1), GOLD[p + "shs"])
+        assert np.array_equal(GOLD[f"{tag}_in_opac"][:, None], GOLD[p + "opacities"])
+        assert int(GOLD[p + "sh_degree"]) == 1
