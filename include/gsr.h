@@ -67,7 +67,10 @@ typedef struct GsrDims {
     void *profile;      /* optional GsrProfile* (gsr_profile_create): per-stage hipEvent timing; NULL = off */
 } GsrDims;
 
-#define GSR_FLAG_NTOUCHED 1  /* forward: also count n_touched (costs LDS + global atomics) */
+#define GSR_FLAG_NTOUCHED 1  /* forward: also count n_touched (one extra global atomic per tile and splat) */
+#define GSR_FLAG_COV9 2      /* cov6 / dL_dcov6 are full row-major 3x3 matrices (B,G,3,3): the kernels read the
+                                upper triangle and write the gradient there (lower triangle 0), which is what
+                                autograd produces for covariances[:, triu] (cuda_splatting.py:118,126) */
 
 /* status words written by gsr_forward (device int32[GSR_STATUS_WORDS]) */
 #define GSR_STATUS_WORDS 8
@@ -78,12 +81,14 @@ typedef struct GsrDims {
 
 /* Named offsets into the workspace (bytes), for the parity tests and the bench. */
 typedef struct GsrLayout {
-    size_t records;      /* SplatRec[V*G], 48 B each: x,y,depth,radius | conic A,B,C,opacity | r,g,b,aux */
+    size_t records;      /* SplatRec[V*G], 48 B each: x,y,depth,radius+flags | conic A,B,C,opacity | r,g,b,extents */
     size_t tile_count;   /* uint32[V*T]     per-tile list length */
     size_t tile_offset;  /* uint32[V*T+1]   exclusive scan; ranges[t] = [off[t], off[t+1]) */
     size_t tile_cursor;  /* uint32[V*T]     scatter cursors */
     size_t pairs;        /* uint64[cap]     (depth_bits << 32 | id), bucketed by (view, tile) */
     size_t point_list;   /* uint32[cap]     per-tile depth-sorted Gaussian ids */
+    size_t queue;        /* QueueRec[cap]   per-tile depth-sorted splat queue, 48 B each:
+                                            x,y,A,B | C,opacity,depth,id | r,g,b,quadrant mask */
     size_t final_T;      /* float[V*H*W] */
     size_t n_contrib;    /* uint32[V*H*W] */
     size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */

@@ -53,11 +53,12 @@ class GsrDims(C.Structure):
 
 
 class GsrLayout(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("records", "tile_count", "tile_offset", "tile_cursor", "pairs", "point_list",
+    _fields_ = [(n, C.c_size_t) for n in ("records", "tile_count", "tile_offset", "tile_cursor", "pairs", "point_list", "queue",
                                           "final_T", "n_contrib", "grad_rec", "status", "total")]
 
 
 GSR_FLAG_NTOUCHED = 1
+GSR_FLAG_COV9 = 2
 GSR_STATUS_WORDS = 8
 GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7

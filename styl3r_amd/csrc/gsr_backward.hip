@@ -16,135 +16,121 @@ namespace gsr {
 enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_CC = 8, GR_OP = 9, GR_STRIDE = 12 };
 
 // ------------------------------------------------------------------ K6
-__global__ void __launch_bounds__(256) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
-                                                      const float *__restrict__ dL_dimage,
-                                                      const float *__restrict__ dL_ddepth)
+// One wavefront per tile, 4 pixels per lane (same pixel <-> lane map as the forward).
+// A lane first adds the partial gradients of its own pixels in registers, then ONE
+// ten-value wave reduction per splat (wave_reduce10) and ten lanes issue the tile's single
+// atomic per component.  No LDS atomics, no workgroup barriers.
+__global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+                                                     const float *__restrict__ dL_dimage,
+                                                     const float *__restrict__ dL_ddepth)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
-    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
-    __shared__ uint32_t s_id[256];
-    __shared__ float s_acc[256][10];
-    __shared__ uint32_t s_red[4];
+    __shared__ float4 s_q[64 * 3];
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const int tile = blockIdx.x, v = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int px = (tile % gx) * TILE + (tid & 15);
-    const int py = (tile / gx) * TILE + (tid >> 4);
-    const bool inside = px < d.W && py < d.H;
-    const float fx = (float)px, fy = (float)py;
+    const int lane = threadIdx.x;
+    const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
     const size_t P = (size_t)d.H * d.W;
-    const size_t pix = (size_t)py * d.W + px;
 
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
     if (start == end) return;
-    const SplatRec *recs = ws.records + (size_t)v * d.G;
+    const float4 *__restrict__ q = reinterpret_cast<const float4 *>(ws.queue + start);
     float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
     const GsrView &vw = views[v];
 
-    const float Tf = inside ? ws.final_T[v * P + pix] : 0.f;
-    const uint32_t last = inside ? ws.n_contrib[v * P + pix] : 0u;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gd = 0.f;
-    if (inside) {
-        g0 = dL_dimage[(v * 3 + 0) * P + pix];
-        g1 = dL_dimage[(v * 3 + 1) * P + pix];
-        g2 = dL_dimage[(v * 3 + 2) * P + pix];
-        if (dL_ddepth) gd = dL_ddepth[v * P + pix];
+    float fx[4], fy[4], Tf[4], Tr[4], g0[4], g1[4], g2[4], gd[4], bg_dot[4];
+    float acc0[4], acc1[4], acc2[4], accd[4], last_alpha[4], lc0[4], lc1[4], lc2[4], ld[4];
+    uint32_t last[4];
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
+        const bool inside = px < d.W && py < d.H;
+        const size_t pix = (size_t)py * d.W + px;
+        fx[k] = (float)px; fy[k] = (float)py;
+        Tf[k] = inside ? ws.final_T[v * P + pix] : 0.f;
+        last[k] = inside ? ws.n_contrib[v * P + pix] : 0u;
+        g0[k] = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
+        g1[k] = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
+        g2[k] = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
+        gd[k] = (inside && dL_ddepth) ? dL_ddepth[v * P + pix] : 0.f;
+        bg_dot[k] = vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k];
+        Tr[k] = Tf[k];
+        acc0[k] = acc1[k] = acc2[k] = accd[k] = last_alpha[k] = lc0[k] = lc1[k] = lc2[k] = ld[k] = 0.f;
+        mx = max(mx, last[k]);
     }
-    const float bg_dot = vw.bg[0] * g0 + vw.bg[1] * g1 + vw.bg[2] * g2;
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
-
     // deepest contributor of the tile: nothing behind it received any light
-    uint32_t mx = last;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    if (lane == 0) s_red[wid] = mx;
-    __syncthreads();
-    const uint32_t max_last = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    const int max_last = (int)mx;
+    const int slot = reduce10_slot(lane);
 
-    float Tr = Tf;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f, last_alpha = 0.f;
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;
-
-    // entries [0, max_last) of the list, processed in batches from the back
-    for (int hi = (int)max_last; hi > 0; hi -= 256) {
-        const int lo = max(0, hi - 256);
-        const int cnt = hi - lo;
-        __syncthreads();  // previous batch fully flushed before LDS is reused
-        if (tid < cnt) {
-            // slot j of the batch holds list entry hi-1-j (so j walks back to front)
-            const uint32_t id = ws.point_list[start + (uint32_t)(hi - 1 - tid)];
-            const float4 *r = reinterpret_cast<const float4 *>(recs + id);
-            s_q0[tid] = r[0]; s_q1[tid] = r[1]; s_q2[tid] = r[2];
-            s_id[tid] = id;
-        }
-#pragma unroll
-        for (int k = 0; k < 10; ++k) s_acc[tid][k] = 0.f;
+    // entries [0, max_last) of the queue, in batches from the back; slot l of a batch = entry hi-1-l
+    float4 r0, r1, r2;
+    if (max_last - 1 - lane >= 0) { const int e = max_last - 1 - lane; r0 = q[e * 3 + 0]; r1 = q[e * 3 + 1]; r2 = q[e * 3 + 2]; }
+    for (int hi = max_last; hi > 0; hi -= 64) {
+        const int cnt = min(64, hi);
         __syncthreads();
-
+        if (lane < cnt) { s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2; }
+        __syncthreads();
+        {
+            const int e = hi - 64 - 1 - lane;
+            if (e >= 0) { r0 = q[e * 3 + 0]; r1 = q[e * 3 + 1]; r2 = q[e * 3 + 2]; }
+        }
         for (int j = 0; j < cnt; ++j) {
             const uint32_t entry = (uint32_t)(hi - 1 - j);  // 0-based position in the list
-            bool act = inside && entry < last;
-            float4 q0, q1;
-            float dx = 0.f, dy = 0.f, Gv = 0.f, alpha = 0.f;
-            if (act) {
-                q0 = s_q0[j]; q1 = s_q1[j];
-                dx = q0.x - fx; dy = q0.y - fy;
-                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
-                act = power <= 0.f;
-                if (act) {
-                    Gv = __expf(power);
-                    alpha = fminf(0.99f, q1.w * Gv);
-                    act = alpha >= (1.f / 255.f);
-                }
-            }
-            if (__ballot(act) == 0ull) continue;  // wave-uniform: nobody in this wave sees the splat
-            float a[10];
+            const float4 a = s_q[j * 3 + 0];                // x, y, A, B
+            const float4 b = s_q[j * 3 + 1];                // C, opacity, depth, id
+            const float4 c = s_q[j * 3 + 2];                // r, g, b, quad
+            const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+            float s[10];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) a[k] = 0.f;
-            if (act) {
-                const float4 q2 = s_q2[j];
-                Tr = Tr / (1.f - alpha);
-                const float w = alpha * Tr;
-                float dL_dalpha;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = q2.x;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = q2.y;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = q2.z;
-                accd = last_alpha * ld + (1.f - last_alpha) * accd; ld = q0.z;
-                dL_dalpha = (q2.x - acc0) * g0 + (q2.y - acc1) * g1 + (q2.z - acc2) * g2 + (q0.z - accd) * gd;
-                a[GR_RGB + 0] = w * g0; a[GR_RGB + 1] = w * g1; a[GR_RGB + 2] = w * g2;
-                a[GR_DEPTH] = w * gd;
-                dL_dalpha *= Tr;
-                last_alpha = alpha;
-                dL_dalpha += (-Tf / (1.f - alpha)) * bg_dot;
-                const float dL_dG = q1.w * dL_dalpha;
-                const float gdx = Gv * dx, gdy = Gv * dy;
-                const float dG_ddelx = -gdx * q1.x - gdy * q1.y;
-                const float dG_ddely = -gdy * q1.z - gdx * q1.y;
-                a[GR_MX] = dL_dG * dG_ddelx * ddelx_dx;
-                a[GR_MY] = dL_dG * dG_ddely * ddely_dy;
-                a[GR_CA] = -0.5f * gdx * dx * dL_dG;
-                a[GR_CB] = -0.5f * gdx * dy * dL_dG;
-                a[GR_CC] = -0.5f * gdy * dy * dL_dG;
-                a[GR_OP] = Gv * dL_dalpha;
-            }
-#pragma unroll
-            for (int k = 0; k < 10; ++k) a[k] = wave_sum_to_lane63(a[k]);
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < 10; ++k) atomicAdd(&s_acc[j][k], a[k]);
-            }
-        }
-        __syncthreads();
-        if (tid < cnt) {
-            float *gdst = grad + (size_t)s_id[tid] * GR_STRIDE;
+            for (int i = 0; i < 10; ++i) s[i] = 0.f;
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < 10; ++k) any |= (s_acc[tid][k] != 0.f);
-            if (any) {
-#pragma unroll
-                for (int k = 0; k < 10; ++k) atomicAdd(gdst + k, s_acc[tid][k]);
+            for (int k = 0; k < 4; ++k) {
+                if (!(quad & (1u << k))) continue;  // scalar branch
+                if (entry >= last[k]) continue;
+                const float dx = a.x - fx[k], dy = a.y - fy[k];
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                if (power > 0.f) continue;
+                const float Gv = __expf(power);
+                const float alpha = fminf(0.99f, b.y * Gv);
+                if (alpha < (1.f / 255.f)) continue;
+                any = true;
+                Tr[k] = Tr[k] / (1.f - alpha);
+                const float w = alpha * Tr[k];
+                acc0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * acc0[k]; lc0[k] = c.x;
+                acc1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * acc1[k]; lc1[k] = c.y;
+                acc2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * acc2[k]; lc2[k] = c.z;
+                accd[k] = last_alpha[k] * ld[k] + (1.f - last_alpha[k]) * accd[k]; ld[k] = b.z;
+                float dL_dalpha = (c.x - acc0[k]) * g0[k] + (c.y - acc1[k]) * g1[k] + (c.z - acc2[k]) * g2[k] +
+                                  (b.z - accd[k]) * gd[k];
+                s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
+                s[GR_DEPTH] += w * gd[k];
+                dL_dalpha *= Tr[k];
+                last_alpha[k] = alpha;
+                dL_dalpha += (-Tf[k] / (1.f - alpha)) * bg_dot[k];
+                const float dL_dG = b.y * dL_dalpha;
+                const float gdx = Gv * dx, gdy = Gv * dy;
+                const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                const float dG_ddely = -gdy * b.x - gdx * a.w;
+                s[GR_MX] += dL_dG * dG_ddelx * ddelx_dx;
+                s[GR_MY] += dL_dG * dG_ddely * ddely_dy;
+                s[GR_CA] += -0.5f * gdx * dx * dL_dG;
+                s[GR_CB] += -0.5f * gdx * dy * dL_dG;
+                s[GR_CC] += -0.5f * gdy * dy * dL_dG;
+                s[GR_OP] += Gv * dL_dalpha;
+            }
+            if (__ballot(any) == 0ull) continue;  // wave-uniform
+            float tot[3];
+            wave_reduce10(s, tot);
+            if (slot >= 0) {
+                const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
+                if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
             }
         }
     }
@@ -176,8 +162,8 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
     const size_t sg = (size_t)b * d.G + (valid ? g : 0);
     const float m0[3] = {means[3 * sg], means[3 * sg + 1], means[3 * sg + 2]};
     float S0[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S0[k] = cov6[6 * sg + k];
+    const bool cov9 = (d.flags & GSR_FLAG_COV9) != 0;
+    load_cov(cov6, sg, cov9, S0);
     const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
     const int ncol = d.M > 0 ? 3 * d.M : 3;
     float *dsh = dL_dshs + sg * (size_t)ncol;
@@ -194,9 +180,10 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
         float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float g2x = 0.f, g2y = 0.f;
         const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
-        const bool vis = valid && __float_as_int(q0.w) > 0;
+        const uint32_t rad_flags = __float_as_uint(q0.w);
+        const bool vis = valid && (rad_flags & 0xffffffu) != 0;
         if (vis) {
-            const uint32_t aux = reinterpret_cast<const uint32_t *>(ws.records + vg)[11];
+            const uint32_t aux = rad_flags >> 24;
             const float *gr = ws.grad_rec + vg * GR_STRIDE;
             const float s = vw.scale, s2 = s * s;
             const float m[3] = {m0[0] * s, m0[1] * s, m0[2] * s};
@@ -364,8 +351,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) dL_dmeans[3 * sg + k] = dmean[k];
+        if (cov9) {
+            float *o = dL_dcov6 + 9 * sg;
+            o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = 0.f; o[4] = dcov[3]; o[5] = dcov[4];
+            o[6] = 0.f; o[7] = 0.f; o[8] = dcov[5];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov6[6 * sg + k] = dcov[k];
+            for (int k = 0; k < 6; ++k) dL_dcov6[6 * sg + k] = dcov[k];
+        }
         dL_dopac[sg] = dop;
     }
 }
@@ -393,7 +386,7 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
     if (!hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
     if (dL_dtau && !hip_ok(hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream))) return GSR_ELAUNCH;
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(256), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
+    hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
     tm.end(GSR_STAGE_COMPOSITE_BWD); tm.begin(GSR_STAGE_PREPROCESS_BWD);
     hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.G + 255) / 256, d.B), dim3(256), 0, stream, d, views, means, cov6, shs,
                        ws, dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau);

@@ -16,18 +16,28 @@ constexpr int WAVE = 64;
 // gathers it with three dwordx4 loads.
 struct alignas(16) SplatRec {
     float x, y, depth;
-    int radius;             // 0 => culled / not rasterized
+    uint32_t rad_flags;     // bits 0..23 radius (0 => culled / not rasterized), bits 24..26 SH channel clamped at 0
     float A, B, C, opacity; // conic + opacity
     float r, g, b;
-    uint32_t aux;           // bit0..2: SH colour channel clamped at 0
+    uint32_t ext;           // half extents (pixels, rounded up) of the alpha >= 1/255 footprint: hx | hy << 16
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
+
+// 48-byte per-(tile, list position) record written by the tile sort: the queue the
+// composite kernels stream through, already in front-to-back order.
+struct alignas(16) QueueRec {
+    float x, y, A, B;
+    float C, opacity, depth; uint32_t id;
+    float r, g, b; uint32_t quad;  // bit k: the footprint may touch 8x8 quadrant k of the tile
+};
+static_assert(sizeof(QueueRec) == 48, "QueueRec must be 48 bytes");
 
 struct Ptrs {             // carved workspace
     SplatRec *records;
     uint32_t *tile_count, *tile_offset, *tile_cursor;
     unsigned long long *pairs;
     uint32_t *point_list;
+    QueueRec *queue;
     float *final_T;
     uint32_t *n_contrib;
     float *grad_rec;
@@ -208,6 +218,19 @@ __device__ inline bool geom_eval(const float *V, float tanfovx, float tanfovy, i
     return true;
 }
 
+// covariance of Gaussian `sg` as xx,xy,xz,yy,yz,zz from the (.,6) or the row-major (.,3,3) layout
+__device__ inline void load_cov(const float *__restrict__ cov, size_t sg, bool cov9, float *S)
+{
+    if (cov9) {
+        const float *c = cov + 9 * sg;
+        S[0] = c[0]; S[1] = c[1]; S[2] = c[2]; S[3] = c[4]; S[4] = c[5]; S[5] = c[8];
+    } else {
+        const float *c = cov + 6 * sg;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = c[k];
+    }
+}
+
 // tile rectangle of a splat (upstream getRect); returns the covered tile count.
 __device__ inline int tile_rect(float px, float py, int rad, int gx, int gy, int &minx, int &miny, int &maxx, int &maxy)
 {
@@ -238,6 +261,52 @@ __device__ inline float wave_sum_to_lane63(float v)
     v += dpp_mov<0x142, 0xa, 0xf, false>(v); // row_bcast:15 -> rows 1,3
     v += dpp_mov<0x143, 0xc, 0xf, false>(v); // row_bcast:31 -> rows 2,3
     return v;
+}
+
+// ---- ten-value wave reduction for the composite backward ------------------------
+// Sums a[0..9] over the 64 lanes in 8 lane-swaps + 20 adds (a plain per-value DPP
+// reduction costs 60): level 1 pairs (a_i, a_{i+5}) with v_permlane32_swap so each
+// half-wave keeps one value of the pair, level 2 does the same across 16-lane rows with
+// v_permlane16_swap, level 3 finishes inside the rows with DPP.  Afterwards EVERY lane of
+// row r = lane>>4 holds, in out[0..2], the totals of values
+//     out[0]: {0,1,5,6}[r]   out[1]: {2,3,7,8}[r]   out[2]: {4,-,9,-}[r]
+__device__ inline float swap_add32(float x, float y)
+{
+    // x' = [x.lo, y.lo], y' = [x.hi, y.hi]  ->  x'+y' = [sum of x pair, sum of y pair]
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ inline float swap_add16(float x, float y)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ inline float row_allsum(float v)
+{
+    v += dpp_mov<0xb1, 0xf, 0xf, true>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4e, 0xf, 0xf, true>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124, 0xf, 0xf, true>(v);  // row_ror:4
+    v += dpp_mov<0x128, 0xf, 0xf, true>(v);  // row_ror:8
+    return v;
+}
+__device__ inline void wave_reduce10(const float *a, float *out)
+{
+    float b[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b[i] = swap_add32(a[i], a[i + 5]);   // lanes<32: a_i, lanes>=32: a_{i+5}
+    float c0 = swap_add16(b[0], b[1]);   // rows: a0 a1 a5 a6
+    float c1 = swap_add16(b[2], b[3]);   // rows: a2 a3 a7 a8
+    float c2 = swap_add16(b[4], 0.f);    // rows: a4 -  a9 -
+    out[0] = row_allsum(c0); out[1] = row_allsum(c1); out[2] = row_allsum(c2);
+}
+// which of the ten values a lane publishes after wave_reduce10: lanes 16r+s, s<3 -> value index, else -1
+__device__ inline int reduce10_slot(int lane)
+{
+    const int r = lane >> 4, s = lane & 15;
+    if (s == 0) return (r < 2) ? r : r + 3;        // 0,1,5,6
+    if (s == 1) return (r < 2) ? r + 2 : r + 5;    // 2,3,7,8
+    if (s == 2) return (r == 0) ? 4 : (r == 2 ? 9 : -1);
+    return -1;
 }
 
 }  // namespace gsr

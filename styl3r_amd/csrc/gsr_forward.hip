@@ -8,9 +8,14 @@
 //                      (depth_bits<<32 | id).                                     (R3)
 //   K4 tile_sort       per-tile depth sort in LDS (normalised bitonic network on the
 //                      64-bit keys -> order = depth, then id == upstream's stable radix
-//                      order); writes the sorted id list.                      (R4,R5)
-//   K5 composite_fwd   16x16 tile per workgroup, LDS-staged splat queue, front-to-back
-//                      alpha compositing with per-wave early exit.                (R6)
+//                      order); writes the sorted id list AND the tile's splat queue: the
+//                      48-B records gathered once, in order, with a 4-bit mask of the 8x8
+//                      quadrants the splat's alpha>=1/255 footprint can reach.   (R4,R5)
+//   K5 composite_fwd   ONE WAVEFRONT per 16x16 tile, 4 pixels per lane (one per quadrant):
+//                      streams the contiguous queue through a wave-private LDS slot
+//                      (coalesced dwordx4 loads, next batch prefetched in registers, LDS
+//                      broadcast reads), skips quadrants by scalar branch, exits as soon
+//                      as its 256 pixels are saturated.  No workgroup barriers.      (R6)
 //
 // The upstream design sorts all pairs of one view globally on 64-bit keys (6-8 radix
 // passes over HBM).  Here the tile id never enters a sort: pairs are bucketed by tile
@@ -33,8 +38,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
     const size_t sg = (size_t)b * d.G + g;
     const float m0[3] = {means[3 * sg], means[3 * sg + 1], means[3 * sg + 2]};
     float S0[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S0[k] = cov6[6 * sg + k];
+    load_cov(cov6, sg, (d.flags & GSR_FLAG_COV9) != 0, S0);
     const float op = opac[sg];
     const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
     const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
@@ -43,9 +47,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
         const int v = b * d.Vt + j;
         const GsrView &vw = views[v];
         SplatRec rec;
-        rec.x = rec.y = rec.depth = 0.f; rec.radius = 0;
+        rec.x = rec.y = rec.depth = 0.f; rec.rad_flags = 0;
         rec.A = rec.B = rec.C = rec.opacity = 0.f;
-        rec.r = rec.g = rec.b = 0.f; rec.aux = 0;
+        rec.r = rec.g = rec.b = 0.f; rec.ext = 0;
+        uint32_t clampbits = 0;
         const size_t vg = (size_t)v * d.G + g;
 
         const float s = vw.scale, s2 = s * s;
@@ -92,14 +97,21 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
                     float acc = bs[0] * sh[c];
                     for (int k = 1; k < ncoef; ++k) acc = acc + bs[k] * sh[3 * k + c];
                     acc = acc + 0.5f;
-                    if (acc < 0.f) rec.aux |= (1u << c);
+                    if (acc < 0.f) clampbits |= (1u << c);
                     col[c] = fmaxf(acc, 0.f);
                 }
                 rec.r = col[0]; rec.g = col[1]; rec.b = col[2];
             } else {
                 rec.r = shs[3 * sg]; rec.g = shs[3 * sg + 1]; rec.b = shs[3 * sg + 2];
             }
-            rec.x = pxx; rec.y = pxy; rec.depth = ge.t[2]; rec.radius = rad;
+            rec.x = pxx; rec.y = pxy; rec.depth = ge.t[2];
+            rec.rad_flags = (uint32_t)min(rad, 0xffffff) | (clampbits << 24);
+            // conservative half extents of {alpha >= 1/255}: d^T conic d <= 2 ln(255 op), conic^-1 = [[a,b],[b,c]]
+            if (op >= (1.f / 255.f)) {
+                const float tau2 = 2.0f * __logf(255.0f * op) * 1.002f + 1e-3f;
+                const float hx = ceilf(sqrtf(tau2 * ge.a) + 0.05f), hy = ceilf(sqrtf(tau2 * ge.c) + 0.05f);
+                rec.ext = (uint32_t)fminf(hx, 65535.f) | ((uint32_t)fminf(hy, 65535.f) << 16);
+            }
             rec.A = ge.c * det_inv; rec.B = -ge.b * det_inv; rec.C = ge.a * det_inv; rec.opacity = op;
             uint32_t *cnt = ws.tile_count + (size_t)v * T;
             for (int ty = miny; ty < maxy; ++ty)
@@ -175,7 +187,7 @@ __global__ void __launch_bounds__(256) k_scatter(GsrDims d, Ptrs ws)
     if (g >= d.G) return;
     const size_t vg = (size_t)v * d.G + g;
     const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
-    const int rad = __float_as_int(q0.w);
+    const int rad = (int)(__float_as_uint(q0.w) & 0xffffffu);
     if (rad <= 0) return;
     const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
     int minx, miny, maxx, maxy;
@@ -229,109 +241,156 @@ __device__ inline void bitonic_sort_block(KeyPtr key, uint32_t n, int tid, int n
 
 constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
 
-__global__ void __launch_bounds__(256) k_tile_sort(int T, Ptrs ws)
+// gather one record into the tile's queue slot and mark the 8x8 quadrants its footprint can touch
+__device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *__restrict__ out, uint32_t id, int ox,
+                                  int oy)
+{
+    const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    const uint32_t ext = __float_as_uint(q2.w);
+    uint32_t quad = 0;
+    if (ext) {
+        const float hx = (float)(ext & 0xffffu), hy = (float)(ext >> 16);
+        const float x0 = q0.x - hx, x1 = q0.x + hx, y0 = q0.y - hy, y1 = q0.y + hy;
+        const float fox = (float)ox, foy = (float)oy;
+        const bool L = x0 <= fox + 7.f && x1 >= fox, R = x1 >= fox + 8.f && x0 <= fox + 15.f;
+        const bool Tp = y0 <= foy + 7.f && y1 >= foy, Bm = y1 >= foy + 8.f && y0 <= foy + 15.f;
+        quad = (uint32_t)(L && Tp) | ((uint32_t)(R && Tp) << 1) | ((uint32_t)(L && Bm) << 2) | ((uint32_t)(R && Bm) << 3);
+    }
+    float4 *o = reinterpret_cast<float4 *>(out);
+    o[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
+    o[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+    o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
+}
+
+__global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
     __shared__ unsigned long long s_key[SORT_LDS_KEYS];
-    const size_t t = (size_t)blockIdx.y * T + blockIdx.x;
+    const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
+    const int tile = blockIdx.x, v = blockIdx.y;
+    const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
     const uint32_t n = ws.tile_offset[t + 1] - start;
     if (n == 0) return;
     const int tid = threadIdx.x;
+    const int ox = (tile % gx) * TILE, oy = (tile / gx) * TILE;
+    const SplatRec *recs = ws.records + (size_t)v * d.G;
     unsigned long long *gk = ws.pairs + start;
     if (n <= SORT_LDS_KEYS) {
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
         if (n > 1) bitonic_sort_block(s_key, n, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) ws.point_list[start + i] = (uint32_t)(s_key[i] & 0xffffffffull);
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t id = (uint32_t)(s_key[i] & 0xffffffffull);
+            ws.point_list[start + i] = id;
+            emit_queue(recs, ws.queue + start + i, id, ox, oy);
+        }
     } else {
         // oversize bucket: same network, in place in global memory (one workgroup owns the
         // bucket; __syncthreads orders its own global accesses through the CU's L1/L2 path)
         __syncthreads();
         bitonic_sort_block(gk, n, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) ws.point_list[start + i] = (uint32_t)(gk[i] & 0xffffffffull);
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t id = (uint32_t)(gk[i] & 0xffffffffull);
+            ws.point_list[start + i] = id;
+            emit_queue(recs, ws.queue + start + i, id, ox, oy);
+        }
     }
 }
 
 // ------------------------------------------------------------------ K5
-// One 16x16 tile per workgroup; wave w owns pixel rows 4w..4w+3 of the tile.
-// Splat queue: 256 entries per batch, gathered by id (3 x dwordx4 per lane) into LDS as
-// three float4 planes; every lane then reads the same entry (LDS broadcast).
+// One wavefront per tile.  Lane l owns pixel (l&7, l>>3) of each 8x8 quadrant k = 0..3
+// (TL, TR, BL, BR), so a splat whose footprint misses a quadrant costs that quadrant nothing
+// (wave-uniform scalar branch on the queue's quadrant mask).
 template <bool NTOUCH>
-__global__ void __launch_bounds__(256) k_composite_fwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
-                                                      float *__restrict__ image, float *__restrict__ out_depth,
-                                                      float *__restrict__ out_opacity, int32_t *__restrict__ n_touched)
+__global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+                                                     float *__restrict__ image, float *__restrict__ out_depth,
+                                                     float *__restrict__ out_opacity, int32_t *__restrict__ n_touched)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
-    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
-    __shared__ uint32_t s_id[NTOUCH ? 256 : 1];
-    __shared__ uint32_t s_touch[NTOUCH ? 256 : 1];
+    __shared__ float4 s_q[64 * 3];
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const int tile = blockIdx.x, v = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int px = (tile % gx) * TILE + (tid & 15);
-    const int py = (tile / gx) * TILE + (tid >> 4);
-    const bool inside = px < d.W && py < d.H;
-    const float fx = (float)px, fy = (float)py;
+    const int lane = threadIdx.x;
+    const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
 
     const size_t t = (size_t)v * T + tile;
-    const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
-    const SplatRec *recs = ws.records + (size_t)v * d.G;
+    const uint32_t start = ws.tile_offset[t];
+    const int n = (int)(ws.tile_offset[t + 1] - start);
+    const float4 *__restrict__ q = reinterpret_cast<const float4 *>(ws.queue + start);
 
-    float Tr = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, O = 0.f;
-    uint32_t contributor = 0, last = 0;
-    bool done = !inside;
+    float fx[4], fy[4], Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
+    uint32_t last[4];
+    bool done[4], inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
+        inside[k] = px < d.W && py < d.H;
+        fx[k] = (float)px; fy[k] = (float)py;
+        Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = O[k] = 0.f;
+        last[k] = 0; done[k] = !inside[k];
+    }
 
-    for (uint32_t base = start; base < end; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
-        const uint32_t idx = base + tid;
-        if (idx < end) {
-            const uint32_t id = ws.point_list[idx];
-            const float4 *r = reinterpret_cast<const float4 *>(recs + id);
-            s_q0[tid] = r[0]; s_q1[tid] = r[1]; s_q2[tid] = r[2];
-            if (NTOUCH) { s_id[tid] = id; s_touch[tid] = 0; }
-        }
+    float4 r0, r1, r2;
+    if (lane < n) { r0 = q[lane * 3 + 0]; r1 = q[lane * 3 + 1]; r2 = q[lane * 3 + 2]; }
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = min(64, n - base);
+        __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
+        if (lane < cnt) { s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2; }
         __syncthreads();
-        const int cnt = (int)min(256u, end - base);
-        if (!done) {
-            for (int j = 0; j < cnt; ++j) {
-                contributor++;
-                const float4 q0 = s_q0[j];
-                const float4 q1 = s_q1[j];
-                const float dx = q0.x - fx, dy = q0.y - fy;
-                const float power = -0.5f * (q1.x * dx * dx + q1.z * dy * dy) - q1.y * dx * dy;
+        const int nb = base + 64 + lane;
+        if (nb < n) { r0 = q[nb * 3 + 0]; r1 = q[nb * 3 + 1]; r2 = q[nb * 3 + 2]; }  // in flight during the batch
+
+        for (int j = 0; j < cnt; ++j) {
+            const float4 a = s_q[j * 3 + 0];
+            const float4 b = s_q[j * 3 + 1];
+            const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(s_q[j * 3 + 2].w));
+            uint32_t touched = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(quad & (1u << k))) continue;  // scalar branch
+                if (done[k]) continue;
+                const float dx = a.x - fx[k], dy = a.y - fy[k];
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (power > 0.f) continue;
-                const float alpha = fminf(0.99f, q1.w * __expf(power));
+                const float alpha = fminf(0.99f, b.y * __expf(power));
                 if (alpha < (1.f / 255.f)) continue;
-                const float test_T = Tr * (1.f - alpha);
-                if (test_T < 0.0001f) { done = true; break; }
-                const float4 q2 = s_q2[j];
-                const float w = alpha * Tr;
-                C0 += q2.x * w; C1 += q2.y * w; C2 += q2.z * w;
-                D += q0.z * w;
-                O += w;
-                if (NTOUCH) { if (test_T > 0.5f) atomicAdd(&s_touch[j], 1u); }
-                Tr = test_T;
-                last = contributor;
+                const float test_T = Tr[k] * (1.f - alpha);
+                if (test_T < 0.0001f) { done[k] = true; continue; }
+                const float4 c = s_q[j * 3 + 2];
+                const float w = alpha * Tr[k];
+                C0[k] += c.x * w; C1[k] += c.y * w; C2[k] += c.z * w;
+                D[k] += b.z * w;
+                O[k] += w;
+                if (NTOUCH) touched += (test_T > 0.5f) ? 1u : 0u;
+                Tr[k] = test_T;
+                last[k] = (uint32_t)(base + j + 1);
+            }
+            if (NTOUCH) {
+                // wave total of `touched` (0..4 per lane): three ballots, one atomic per (tile, splat)
+                const uint32_t tot = (uint32_t)__popcll(__ballot(touched & 1u)) + 2u * (uint32_t)__popcll(__ballot(touched & 2u)) +
+                                     4u * (uint32_t)__popcll(__ballot(touched & 4u));
+                if (tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)tot);
             }
         }
-        if (NTOUCH) {
-            __syncthreads();
-            if (idx < end && s_touch[tid]) atomicAdd(n_touched + (size_t)v * d.G + s_id[tid], (int)s_touch[tid]);
-        }
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
     }
-    if (inside) {
-        const size_t P = (size_t)d.H * d.W;
-        const size_t pix = (size_t)py * d.W + px;
-        const GsrView &vw = views[v];
-        ws.final_T[v * P + pix] = Tr;
-        ws.n_contrib[v * P + pix] = last;
-        image[(v * 3 + 0) * P + pix] = C0 + Tr * vw.bg[0];
-        image[(v * 3 + 1) * P + pix] = C1 + Tr * vw.bg[1];
-        image[(v * 3 + 2) * P + pix] = C2 + Tr * vw.bg[2];
-        out_depth[v * P + pix] = D;
-        out_opacity[v * P + pix] = O;
+
+    const size_t P = (size_t)d.H * d.W;
+    const GsrView &vw = views[v];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!inside[k]) continue;
+        const size_t pix = (size_t)(oy + (k >> 1) * 8) * d.W + (ox + (k & 1) * 8);
+        ws.final_T[v * P + pix] = Tr[k];
+        ws.n_contrib[v * P + pix] = last[k];
+        image[(v * 3 + 0) * P + pix] = C0[k] + Tr[k] * vw.bg[0];
+        image[(v * 3 + 1) * P + pix] = C1[k] + Tr[k] * vw.bg[1];
+        image[(v * 3 + 2) * P + pix] = C2[k] + Tr[k] * vw.bg[2];
+        out_depth[v * P + pix] = D[k];
+        out_opacity[v * P + pix] = O[k];
     }
 }
 
@@ -354,6 +413,7 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.tile_cursor = take(V * T * 4);
     L.pairs = take((size_t)cap * 8);
     L.point_list = take((size_t)cap * 4);
+    L.queue = take((size_t)cap * sizeof(QueueRec));
     L.final_T = take(V * P * 4);
     L.n_contrib = take(V * P * 4);
     L.grad_rec = take(V * d.G * 12 * 4);
@@ -372,6 +432,7 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.tile_cursor = reinterpret_cast<uint32_t *>(p + L.tile_cursor);
     w.pairs = reinterpret_cast<unsigned long long *>(p + L.pairs);
     w.point_list = reinterpret_cast<uint32_t *>(p + L.point_list);
+    w.queue = reinterpret_cast<QueueRec *>(p + L.queue);
     w.final_T = reinterpret_cast<float *>(p + L.final_T);
     w.n_contrib = reinterpret_cast<uint32_t *>(p + L.n_contrib);
     w.grad_rec = reinterpret_cast<float *>(p + L.grad_rec);
@@ -407,13 +468,13 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     tm.end(GSR_STAGE_SCAN); tm.begin(GSR_STAGE_SCATTER);
     hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
     tm.end(GSR_STAGE_SCATTER); tm.begin(GSR_STAGE_SORT);
-    hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, T, ws);
+    hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, d, ws);
     tm.end(GSR_STAGE_SORT); tm.begin(GSR_STAGE_COMPOSITE_FWD);
     if (ntouch)
-        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth, opacity,
+        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity,
                            n_touched);
     else
-        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(256), 0, stream, d, views, ws, image, depth,
+        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth,
                            opacity, n_touched);
     tm.end(GSR_STAGE_COMPOSITE_FWD);
     return launch_status();

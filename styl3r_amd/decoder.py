@@ -79,7 +79,9 @@ def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor
     n = gaussians.harmonics.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussians.harmonics.permute(0, 1, 3, 2).contiguous()            # (b,g,n,3)  cuda_splatting.py:76
-    cov6 = gaussians.covariances[:, :, _TRIU[0], _TRIU[1]]                 # (b,g,6)    cuda_splatting.py:118,126
+    # cuda_splatting.py:118,126 passes covariances[:, triu]; the kernels read that upper triangle straight from
+    # the (b,g,3,3) tensor (GSR_FLAG_COV9) and write its gradient there, so no gather / index_put kernels run.
+    cov6 = gaussians.covariances
     views = prepare_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
     colors = shs if use_sh else shs[:, :, 0, :].contiguous()
     out = rasterize_views(gaussians.means, cov6, gaussians.opacities, colors, views, image_shape, views_per_scene,

@@ -72,9 +72,10 @@ class _Rasterize(torch.autograd.Function):
         B, G = means.shape[0], means.shape[1]
         V = views.shape[0]
         assert V == B * Vt, (V, B, Vt)
-        assert cov6.shape == (B, G, 6) and opac.shape[:2] == (B, G)
+        cov9 = cov6.dim() == 4   # full (B,G,3,3) matrices: GSR_FLAG_COV9, no triu gather / scatter kernels
+        assert (cov6.shape == (B, G, 3, 3) if cov9 else cov6.shape == (B, G, 6)) and opac.shape[:2] == (B, G)
         M = colors.shape[2] if use_sh else 0
-        flags = _lib.GSR_FLAG_NTOUCHED if want_ntouched else 0
+        flags = (_lib.GSR_FLAG_NTOUCHED if want_ntouched else 0) | (_lib.GSR_FLAG_COV9 if cov9 else 0)
         dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags,
                             PROFILE.handle if PROFILE is not None else None)
         dev = means.device
@@ -143,7 +144,7 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
                     views_per_scene: int, sh_degree: int = 0, use_sh: bool = True, means2D: Optional[Tensor] = None,
                     theta: Optional[Tensor] = None, rho: Optional[Tensor] = None,
                     want_n_touched: bool = False) -> RasterOutput:
-    """Batched entry point: means (B,G,3), cov6 (B,G,6), opacities (B,G), colors = SH (B,G,M,3) or RGB (B,G,3),
+    """Batched entry point: means (B,G,3), cov6 (B,G,6) or full covariances (B,G,3,3), opacities (B,G), colors = SH (B,G,M,3) or RGB (B,G,3),
     views (B*Vt, 64) packed with `pack_views`; theta/rho (B*Vt, 3) receive the pose gradient."""
     H, W = image_hw
     out = _Rasterize.apply(means, cov6, opacities, colors, views, means2D, theta, rho, int(H), int(W),
