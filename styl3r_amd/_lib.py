@@ -15,7 +15,8 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 _LIBDIR = _PKG / "lib"
-LIB_PATH = _LIBDIR / "libgsr_hip.so"
+# GSR_LIB_NAME / GSR_HIPCC_EXTRA: kernel-experiment builds (tools/ only); the product is libgsr_hip.so
+LIB_PATH = _LIBDIR / os.environ.get("GSR_LIB_NAME", "libgsr_hip.so")
 
 _SOURCES = ["gsr_forward.hip", "gsr_backward.hip", "gsr_api.hip"]
 _HEADERS = ["gsr_common.h", "../../include/gsr.h"]
@@ -40,7 +41,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     _LIBDIR.mkdir(exist_ok=True)
-    cmd = [_hipcc(), *HIPCC_FLAGS, *map(str, srcs), "-o", str(LIB_PATH)]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *os.environ.get("GSR_HIPCC_EXTRA", "").split(), *map(str, srcs), "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=str(_CSRC))

@@ -270,16 +270,20 @@ __device__ inline float wave_sum_to_lane63(float v)
 // v_permlane16_swap, level 3 finishes inside the rows with DPP.  Afterwards EVERY lane of
 // row r = lane>>4 holds, in out[0..2], the totals of values
 //     out[0]: {0,1,5,6}[r]   out[1]: {2,3,7,8}[r]   out[2]: {4,-,9,-}[r]
+// (inline asm, not __builtin_amdgcn_permlane{32,16}_swap: hipcc 7.2 folds r[0]+r[1] of the builtin's
+// result pair into r[0]+r[0] -- tools/probes/permlane_probe.hip.  The two v_nop are the wait states
+// the gfx950 rule "VALU write -> v_permlane*_swap read" asks for; hipcc pads nothing inside asm.)
 __device__ inline float swap_add32(float x, float y)
 {
     // x' = [x.lo, y.lo], y' = [x.hi, y.hi]  ->  x'+y' = [sum of x pair, sum of y pair]
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
 }
 __device__ inline float swap_add16(float x, float y)
 {
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    // rows: x' = [x.r0, y.r0, x.r2, y.r2], y' = [x.r1, y.r1, x.r3, y.r3]
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
 }
 __device__ inline float row_allsum(float v)
 {

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.GsrDims) == 40          # 8 x int32 + pointer
-    assert C.sizeof(_lib.GsrLayout) == 11 * C.sizeof(C.c_size_t)
+    assert C.sizeof(_lib.GsrLayout) == 12 * C.sizeof(C.c_size_t)
     assert _lib.GSR_VIEW_FLOATS * 4 == 256
 
 
