@@ -40,8 +40,11 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
     const GsrView &vw = views[v];
 
-    float fx[4], fy[4], Tf[4], Tr[4], g0[4], g1[4], g2[4], gd[4], bg_dot[4];
-    float acc0[4], acc1[4], acc2[4], accd[4], last_alpha[4], lc0[4], lc1[4], lc2[4], ld[4];
+    // Per pixel the colour/depth recurrences of upstream (accum_rec[ch], last_color[ch]) only ever enter
+    // through their dot product with the pixel's incoming gradient, and both are linear, so ONE scalar
+    // recurrence on u = rgb.g + depth*gd replaces four (identical up to rounding).
+    float fx[4], fy[4], Tr[4], g0[4], g1[4], g2[4], gd[4], bgT[4];
+    float accu[4], last_alpha[4], last_u[4];
     uint32_t last[4];
     uint32_t mx = 0;
 #pragma unroll
@@ -50,15 +53,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         const bool inside = px < d.W && py < d.H;
         const size_t pix = (size_t)py * d.W + px;
         fx[k] = (float)px; fy[k] = (float)py;
-        Tf[k] = inside ? ws.final_T[v * P + pix] : 0.f;
+        const float Tf = inside ? ws.final_T[v * P + pix] : 0.f;
         last[k] = inside ? ws.n_contrib[v * P + pix] : 0u;
         g0[k] = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
         g1[k] = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
         g2[k] = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
         gd[k] = (inside && dL_ddepth) ? dL_ddepth[v * P + pix] : 0.f;
-        bg_dot[k] = vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k];
-        Tr[k] = Tf[k];
-        acc0[k] = acc1[k] = acc2[k] = accd[k] = last_alpha[k] = lc0[k] = lc1[k] = lc2[k] = ld[k] = 0.f;
+        bgT[k] = -Tf * (vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k]);
+        Tr[k] = Tf;
+        accu[k] = last_alpha[k] = last_u[k] = 0.f;
         mx = max(mx, last[k]);
     }
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
@@ -101,30 +104,29 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 const float alpha = fminf(0.99f, b.y * Gv);
                 if (alpha < (1.f / 255.f)) continue;
                 any = true;
-                Tr[k] = Tr[k] / (1.f - alpha);
+                const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp) for both 1/(1-alpha) uses
+                Tr[k] *= inv;
                 const float w = alpha * Tr[k];
-                acc0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * acc0[k]; lc0[k] = c.x;
-                acc1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * acc1[k]; lc1[k] = c.y;
-                acc2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * acc2[k]; lc2[k] = c.z;
-                accd[k] = last_alpha[k] * ld[k] + (1.f - last_alpha[k]) * accd[k]; ld[k] = b.z;
-                float dL_dalpha = (c.x - acc0[k]) * g0[k] + (c.y - acc1[k]) * g1[k] + (c.z - acc2[k]) * g2[k] +
-                                  (b.z - accd[k]) * gd[k];
+                const float u = c.x * g0[k] + c.y * g1[k] + c.z * g2[k] + b.z * gd[k];
+                accu[k] = last_alpha[k] * last_u[k] + (1.f - last_alpha[k]) * accu[k];
+                last_u[k] = u;
+                last_alpha[k] = alpha;
+                const float dL_dalpha = (u - accu[k]) * Tr[k] + bgT[k] * inv;
                 s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
                 s[GR_DEPTH] += w * gd[k];
-                dL_dalpha *= Tr[k];
-                last_alpha[k] = alpha;
-                dL_dalpha += (-Tf[k] / (1.f - alpha)) * bg_dot[k];
                 const float dL_dG = b.y * dL_dalpha;
                 const float gdx = Gv * dx, gdy = Gv * dy;
                 const float dG_ddelx = -gdx * a.z - gdy * a.w;
                 const float dG_ddely = -gdy * b.x - gdx * a.w;
-                s[GR_MX] += dL_dG * dG_ddelx * ddelx_dx;
-                s[GR_MY] += dL_dG * dG_ddely * ddely_dy;
-                s[GR_CA] += -0.5f * gdx * dx * dL_dG;
-                s[GR_CB] += -0.5f * gdx * dy * dL_dG;
-                s[GR_CC] += -0.5f * gdy * dy * dL_dG;
+                s[GR_MX] += dL_dG * dG_ddelx;      // x 0.5 W after the loop
+                s[GR_MY] += dL_dG * dG_ddely;      // x 0.5 H
+                const float hg = -0.5f * dL_dG;
+                s[GR_CA] += hg * gdx * dx;
+                s[GR_CB] += hg * gdx * dy;
+                s[GR_CC] += hg * gdy * dy;
                 s[GR_OP] += Gv * dL_dalpha;
             }
+            s[GR_MX] *= ddelx_dx; s[GR_MY] *= ddely_dy;
             if (__ballot(any) == 0ull) continue;  // wave-uniform
 #if defined(GSR_EXP) && GSR_EXP == 2
             { float z = 0.f; for (int i = 0; i < 10; ++i) z += s[i]; asm volatile("" ::"v"(z)); continue; }

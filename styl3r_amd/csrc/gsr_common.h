@@ -263,6 +263,35 @@ __device__ inline float wave_sum_to_lane63(float v)
     return v;
 }
 
+// ---- wave-aggregated counter bump ---------------------------------------------------
+// Every valid lane wants counters[t] += 1 (and, if SLOT, its unique old value).  Lanes of a
+// wavefront handle neighbouring Gaussians, which mostly fall into the same few tiles: group the
+// lanes by target with ballots and issue ONE atomic per distinct tile instead of one per lane.
+template <bool SLOT>
+__device__ inline uint32_t wave_agg_inc(uint32_t *__restrict__ counters, uint32_t t, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    uint32_t slot = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
+        const bool mine = valid && t == tl;
+        const unsigned long long m = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == leader) {
+            if (SLOT) base = atomicAdd(counters + tl, (uint32_t)__popcll(m));
+            else atomicAdd(counters + tl, (uint32_t)__popcll(m));
+        }
+        if (SLOT) {
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (mine) slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        todo &= ~m;
+    }
+    return slot;
+}
+
 // ---- ten-value wave reduction for the composite backward ------------------------
 // Sums a[0..9] over the 64 lanes in 8 lane-swaps + 20 adds (a plain per-value DPP
 // reduction costs 60): level 1 pairs (a_i, a_{i+5}) with v_permlane32_swap so each

@@ -34,8 +34,8 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
-    if (g >= d.G) return;
-    const size_t sg = (size_t)b * d.G + g;
+    const bool live = g < d.G;   // no early return: the tile counting below is a wave-level operation
+    const size_t sg = (size_t)b * d.G + (live ? g : 0);
     const float m0[3] = {means[3 * sg], means[3 * sg + 1], means[3 * sg + 2]};
     float S0[6];
     load_cov(cov6, sg, (d.flags & GSR_FLAG_COV9) != 0, S0);
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
         rec.A = rec.B = rec.C = rec.opacity = 0.f;
         rec.r = rec.g = rec.b = 0.f; rec.ext = 0;
         uint32_t clampbits = 0;
-        const size_t vg = (size_t)v * d.G + g;
+        const size_t vg = (size_t)v * d.G + (live ? g : 0);
 
         const float s = vw.scale, s2 = s * s;
         const float m[3] = {m0[0] * s, m0[1] * s, m0[2] * s};
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
         for (int k = 0; k < 6; ++k) S[k] = S0[k] * s2;
 
         Geom ge;
-        bool ok = geom_eval(vw.viewmatrix, vw.tanfovx, vw.tanfovy, d.W, d.H, m, S, ge);
+        bool ok = live && geom_eval(vw.viewmatrix, vw.tanfovx, vw.tanfovy, d.W, d.H, m, S, ge);
         int rad = 0, minx = 0, miny = 0, maxx = 0, maxy = 0;
         float pxx = 0.f, pxy = 0.f, det_inv = 0.f;
         if (ok) {
@@ -113,14 +113,26 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
                 rec.ext = (uint32_t)fminf(hx, 65535.f) | ((uint32_t)fminf(hy, 65535.f) << 16);
             }
             rec.A = ge.c * det_inv; rec.B = -ge.b * det_inv; rec.C = ge.a * det_inv; rec.opacity = op;
-            uint32_t *cnt = ws.tile_count + (size_t)v * T;
-            for (int ty = miny; ty < maxy; ++ty)
-                for (int tx = minx; tx < maxx; ++tx) atomicAdd(cnt + ty * gx + tx, 1u);
         }
-        float4 *dst = reinterpret_cast<float4 *>(ws.records + vg);
-        const float4 *src = reinterpret_cast<const float4 *>(&rec);
-        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-        radii[vg] = rad * (ok ? 1 : 0);
+        // per-tile list lengths: k-th tile of every lane's rect, one aggregated atomic per distinct tile
+        {
+            const int rw = maxx - minx, area = ok ? rw * (maxy - miny) : 0;
+            int amax = area;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+            uint32_t *cnt = ws.tile_count + (size_t)v * T;
+            for (int k = 0; k < amax; ++k) {
+                const bool has = k < area;
+                const int ty = has ? miny + k / rw : 0, tx = has ? minx + k % rw : 0;
+                wave_agg_inc<false>(cnt, (uint32_t)(ty * gx + tx), has);
+            }
+        }
+        if (live) {
+            float4 *dst = reinterpret_cast<float4 *>(ws.records + vg);
+            const float4 *src = reinterpret_cast<const float4 *>(&rec);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+            radii[vg] = rad * (ok ? 1 : 0);
+        }
     }
 }
 #pragma clang fp contract(fast)
@@ -184,22 +196,26 @@ __global__ void __launch_bounds__(256) k_scatter(GsrDims d, Ptrs ws)
     if (ws.status[GSR_ST_OVERFLOW]) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int v = blockIdx.y;
-    if (g >= d.G) return;
-    const size_t vg = (size_t)v * d.G + g;
+    const bool live = g < d.G;
+    const size_t vg = (size_t)v * d.G + (live ? g : 0);
     const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
-    const int rad = (int)(__float_as_uint(q0.w) & 0xffffffu);
-    if (rad <= 0) return;
+    const int rad = live ? (int)(__float_as_uint(q0.w) & 0xffffffu) : 0;
     const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
-    int minx, miny, maxx, maxy;
-    tile_rect(q0.x, q0.y, rad, gx, gy, minx, miny, maxx, maxy);
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (rad > 0) tile_rect(q0.x, q0.y, rad, gx, gy, minx, miny, maxx, maxy);
     const unsigned long long key = ((unsigned long long)__float_as_uint(q0.z) << 32) | (unsigned)g;
     const size_t tb = (size_t)v * T;
-    for (int ty = miny; ty < maxy; ++ty)
-        for (int tx = minx; tx < maxx; ++tx) {
-            const size_t t = tb + ty * gx + tx;
-            uint32_t slot = ws.tile_offset[t] + atomicAdd(ws.tile_cursor + t, 1u);
-            ws.pairs[slot] = key;
-        }
+    const int rw = maxx - minx, area = rw * (maxy - miny);
+    int amax = area;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = max(amax, __shfl_xor(amax, o, 64));
+    for (int k = 0; k < amax; ++k) {
+        const bool has = k < area;
+        const int ty = has ? miny + k / rw : 0, tx = has ? minx + k % rw : 0;
+        const uint32_t tl = (uint32_t)(ty * gx + tx);
+        const uint32_t slot = wave_agg_inc<true>(ws.tile_cursor + tb, tl, has);
+        if (has) ws.pairs[ws.tile_offset[tb + tl] + slot] = key;
+    }
 }
 #pragma clang fp contract(fast)
 
