@@ -51,8 +51,9 @@ def parse():
 def build_batch(args, rank, dev):
     from styl3r_amd.decoder import Gaussians
     from styl3r_amd.scenes import make_scene
+    from styl3r_amd.dist_utils import scene_seeds
     scenes = [make_scene(n_ctx=args.ctx, grid_hw=(256, 256), n_views=args.views, image_hw=(args.res, args.res),
-                         sh_degree=args.sh_degree, seed=1234 + 1000 * rank + i) for i in range(args.scenes)]
+                         sh_degree=args.sh_degree, seed=sd) for sd in scene_seeds(rank, args.scenes)]
     st = lambda name: torch.stack([getattr(s, name) for s in scenes]).to(dev)
     g = Gaussians(st("means"), st("covariances"), st("harmonics"), st("opacities"))
     cams = dict(extrinsics=st("extrinsics"), intrinsics=st("intrinsics"), near=st("near"), far=st("far"))
@@ -102,17 +103,12 @@ def cpu_baseline(args, scenes):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from styl3r_amd import dist_utils
+    rank, local_rank, world = dist_utils.env_world()
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = dist_utils.init_distributed("nccl", dev)   # "nccl" is RCCL on ROCm
 
     from styl3r_amd import _lib, rasterizer as rz
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
@@ -135,29 +131,14 @@ def main():
         loss.backward()
         return loss
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(args.warmup):
         step()
     prof = _lib.StageProfile(args.steps + 1)
     rz.PROFILE = prof
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = dist_utils.timed_steps(step, args.steps, lambda: torch.cuda.synchronize(dev), dist, dev)
     rz.PROFILE = None
     stage_ms = prof.read()
     prof.close()
-
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
     # ---- per-launch algorithmic bytes of every stage (one extra un-timed forward to read R / n_contrib) ----
     rz.KEEP_DEBUG = True
@@ -181,23 +162,26 @@ def main():
                         "GBps": round(by / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
     dominant = max(stages, key=lambda k: stages[k]["avg_ms"])
     dk = stages[dominant]
-    traffic = None
+    # HBM traffic / VALU occupancy of the same kernel from the committed rocprofv3 --pmc passes of this workload
+    # (profiles/pmc_latest.json, produced by tools/pmc_run.sh + tools/pmc_summary.py; FETCH_SIZE doubled as the
+    # MI355X guide prescribes for gfx950).  null when the file does not cover the kernel.
+    traffic, valu_busy = None, None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists():
+    if pmc.exists() and (B, Vt, args.ctx, args.res, args.sh_degree) == (10, 4, 1, 256, 0):
         try:
-            traffic = json.loads(pmc.read_text()).get(dominant, {}).get("hbm_bytes_per_launch")
+            rec = json.loads(pmc.read_text()).get(dominant, {})
+            traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac")
         except Exception:
-            traffic = None
+            pass
     roofline = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "valu_busy_frac_pmc": valu_busy,
                 "alg_bytes_per_launch": dk["alg_bytes"], "avg_launch_ms": dk["avg_ms"],
                 "pairs_R": R, "R_eff": R_eff, "stages": stages}
 
     if rank == 0:
-        views_total = V * world * args.steps
         res = {
             "metric": "256x256 stylized views/sec (fwd+bwd) @ ~65k Gaussians",
-            "value": round(views_total / dt, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "value": round(dist_utils.aggregate_throughput(V, args.steps, world, dt), 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
