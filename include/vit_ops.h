@@ -1,0 +1,80 @@
+/*
+ * vit_ops.h -- C ABI of libvit_hip.so: gfx950 kernels for the ViT side of the
+ * Styl3R hot path.  Plain C, device pointers,
+ * hipStream_t as void*, 0 / negative return codes, no torch types.
+ *
+ * Reference interface each entry point replaces:
+ *   vit_rope2d        <- curope.rope_2d(tokens, positions, base, F0)
+ *                        src/model/encoder/backbone/croco/curope/curope.cpp:49-65,
+ *                        kernels.cu:17-108 (in place, forward F0 / backward -F0),
+ *                        called from cuRoPE2D_func curope2d.py:12-29
+ *   vit_attention_fwd <- xformers.ops.memory_efficient_attention(q, k, v, scale, p=0)
+ *                        call sites blocks.py:129,195 (fp32, (B,N,H,64), no mask)
+ *   vit_attention_bwd <- its autograd backward
+ */
+#ifndef VIT_OPS_H
+#define VIT_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_OK 0
+#define VIT_EINVAL (-1)
+#define VIT_ELAUNCH (-3)
+
+/*
+ * In-place 2-D RoPE on tokens viewed as (B, N, H, D) with element strides
+ * (stride_b, stride_n, stride_h), innermost dimension contiguous, D % 4 == 0.
+ * The D features of a token are four quarters [u_Y, v_Y, u_X, v_X] (Q = D/4); pair d < Q is rotated by
+ * theta = pos * sign / base^(d/Q), the Y quarters by pos[b,n,0], the X quarters by pos[b,n,1]:
+ *     u' = u cos(theta) - v sin(theta),   v' = v cos(theta) + u sin(theta).
+ * cos_tab / sin_tab are (P, Q) tables for positions 0..P-1 at sign = +1 (built once by the host with
+ * the reference's own formula, pos_embed.py:121-128); `sign` = +1 forward, -1 backward (curope's F0 / -F0).
+ * positions: int64 (B, N, 2), every value in [0, P).
+ */
+int vit_rope2d(float *tokens, const int64_t *positions, const float *cos_tab, const float *sin_tab, int B, int N,
+               int H, int D, int P, int64_t stride_b, int64_t stride_n, int64_t stride_h, float sign, void *stream);
+
+/*
+ * softmax(q k^T * scale) v for head_dim 64, fp32, no mask, no dropout.
+ * q (B, Nq, H, 64), k/v (B, Nk, H, 64), out (B, Nq, H, 64), given by element strides of the (b, n, h)
+ * dimensions (innermost contiguous), so q/k/v may be views into a fused qkv buffer.
+ * lse (B, H, Nq) receives log-sum-exp (natural log) of the scaled scores, needed by the backward.
+ * If cos_tab != NULL the 2-D RoPE of vit_rope2d is applied to q (positions qpos) and k (positions kpos)
+ * on the fly while the tiles are loaded (the buffers are NOT modified).
+ */
+typedef struct VitAttnArgs {
+    int32_t B, H, Nq, Nk;
+    float scale;
+    int64_t q_sb, q_sn, q_sh;
+    int64_t k_sb, k_sn, k_sh;
+    int64_t v_sb, v_sn, v_sh;
+    int64_t o_sb, o_sn, o_sh;
+    const int64_t *qpos, *kpos;       /* (B,Nq,2) / (B,Nk,2) or NULL */
+    const float *cos_tab, *sin_tab;   /* (P,16) or NULL */
+    int32_t P;
+} VitAttnArgs;
+
+int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,
+                      void *stream);
+
+/*
+ * Backward of vit_attention_fwd.  q/k/v as in the forward (same strides / RoPE arguments); out, dout,
+ * dq (B,Nq,H,64) and dk, dv (B,Nk,H,64) contiguous; lse from the forward; delta_ws: float workspace of
+ * B*H*Nq elements.  With fused RoPE the returned dq / dk are gradients w.r.t. the UNROTATED q / k.
+ */
+int vit_attention_bwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, const float *out,
+                      const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta_ws,
+                      void *stream);
+
+const char *vit_version(void);
+const char *vit_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

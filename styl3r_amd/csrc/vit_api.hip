@@ -1,0 +1,45 @@
+// vit_api.hip -- the C ABI declared in include/vit_ops.h.
+#include <hip/hip_runtime.h>
+
+#include "../../include/vit_ops.h"
+
+namespace vit {
+thread_local hipError_t g_last_hip_error = hipSuccess;
+int rope2d(float *tokens, const int64_t *positions, const float *cos_tab, const float *sin_tab, int B, int N, int H,
+           int D, int P, int64_t sb, int64_t sn, int64_t sh, float sign, hipStream_t stream);
+int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse,
+                  hipStream_t stream);
+int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *out, const float *lse,
+                  const float *dout, float *dq, float *dk, float *dv, float *delta_ws, hipStream_t stream);
+}  // namespace vit
+
+#define VIT_EXPORT extern "C" __attribute__((visibility("default")))
+
+VIT_EXPORT int vit_rope2d(float *tokens, const int64_t *positions, const float *cos_tab, const float *sin_tab, int B,
+                          int N, int H, int D, int P, int64_t stride_b, int64_t stride_n, int64_t stride_h, float sign,
+                          void *stream)
+{
+    return vit::rope2d(tokens, positions, cos_tab, sin_tab, B, N, H, D, P, stride_b, stride_n, stride_h, sign,
+                       static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out,
+                                 float *lse, void *stream)
+{
+    if (!a) return VIT_EINVAL;
+    return vit::attention_fwd(*a, q, k, v, out, lse, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_attention_bwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, const float *out,
+                                 const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta_ws,
+                                 void *stream)
+{
+    if (!a) return VIT_EINVAL;
+    return vit::attention_bwd(*a, q, k, v, out, lse, dout, dq, dk, dv, delta_ws, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }
+VIT_EXPORT const char *vit_last_error(void)
+{
+    return vit::g_last_hip_error == hipSuccess ? "" : hipGetErrorString(vit::g_last_hip_error);
+}

@@ -1,0 +1,209 @@
+// vit_attention.hip -- fp32 flash attention forward for gfx950 (head_dim 64, no mask).
+//
+// The reference runs attention in fp32 (xformers memory_efficient_attention on fp32 tensors,
+// blocks.py:129,195); gfx950 has no TF32/xf32 MFMA, but it has the exact-f32 matrix instruction
+// v_mfma_f32_32x32x2_f32 at the fp32 vector peak (157 TF).  Both contractions run on it, in the
+// TRANSPOSED orientation so that the query index is always the MFMA column = the lane:
+//
+//     S^T (32 keys x 32 queries) = K (32 x 64) . Q^T (64 x 32)       A = K from LDS, B = Q in registers
+//     O^T (32 d    x 32 queries) = V^T (32 x keys) . P^T (keys x 32)  A = V from LDS, B = P in registers
+//
+// With C/D layout col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5), the probabilities a lane holds
+// after the softmax are exactly the B-operand fragments of the second product (no cross-lane
+// movement), and the online-softmax rescale of O^T is lane-local (one query per lane; the two
+// half-waves of a query exchange their partial max / sum once per tile).
+// A workgroup = 4 wavefronts = 128 queries of one (batch, head); K/V tiles of 64 keys are staged in
+// LDS once per workgroup (K with a 65-float row stride: the A-fragment read K[key=lane][d] is then
+// bank-conflict free).  Optional fused 2-D RoPE: Q is rotated in registers, K while it is written to
+// LDS, so the qkv buffer is never rewritten (the reference's curope pass costs 2 R/W sweeps of q and k).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vit_ops.h"
+
+namespace vit {
+extern thread_local hipError_t g_last_hip_error;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 64;          // head dim
+constexpr int QW = 32;          // queries per wavefront
+constexpr int QB = 128;         // queries per workgroup
+constexpr int KT = 64;          // keys per tile
+constexpr int KSTR = 65;        // LDS row stride of the K tile (floats)
+
+__device__ inline float wave_xor32(float x)
+{
+    // value of lane ^ 32 (the other half-wave of the same query)
+    float y = x;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    // after the swap: x = [x.lo, y.lo] , y = [x.hi, y.hi] with y == old x  ->  lanes<32 read y (= x.hi), lanes>=32 read x (= x.lo)
+    return (threadIdx.x & 32) ? x : y;
+}
+
+template <bool ROPE>
+__global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
+                                                  const float *__restrict__ v, float *__restrict__ out,
+                                                  float *__restrict__ lse)
+{
+    __shared__ float s_k[KT * KSTR];
+    __shared__ __attribute__((aligned(16))) float s_v[KT * HD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * QB + wave * QW;
+    const int qi = min(q0 + col, a.Nq - 1);   // clamped: rows beyond Nq compute garbage that is never stored
+    const float qscale = a.scale * 1.4426950408889634f;   // scores in the base-2 domain
+
+    // ---- Q fragment: qf[s] = Q[qi][2s + half], optionally rotated, pre-scaled ----
+    float qf[32];
+    {
+        const float *qr = q + (int64_t)b * a.q_sb + (int64_t)qi * a.q_sn + (int64_t)h * a.q_sh;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qf[s] = qr[2 * s + half];
+        if (ROPE) {
+            const int64_t py = a.qpos[((int64_t)b * a.Nq + qi) * 2 + 0], px = a.qpos[((int64_t)b * a.Nq + qi) * 2 + 1];
+            // feature d = 2s+half; quarters of 16: pairs (d, d+16) within [0,32) use py, within [32,64) use px
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int d = 2 * s + half;   // 0..15
+                const float cy = a.cos_tab[py * 16 + d], sy = a.sin_tab[py * 16 + d];
+                const float cx = a.cos_tab[px * 16 + d], sx = a.sin_tab[px * 16 + d];
+                const float uy = qf[s], vy = qf[s + 8], ux = qf[s + 16], vx = qf[s + 24];
+                qf[s] = uy * cy - vy * sy;      qf[s + 8] = vy * cy + uy * sy;
+                qf[s + 16] = ux * cx - vx * sx; qf[s + 24] = vx * cx + ux * sx;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) qf[s] *= qscale;
+    }
+
+    f32x16 o0 = {0}, o1 = {0};          // O^T rows d = rowmap(r) and 32 + rowmap(r), column = this lane's query
+    float m = -INFINITY, l = 0.f;
+
+    const float *kb = k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const float *vb = v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+
+    for (int k0 = 0; k0 < a.Nk; k0 += KT) {
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage K (rotated if ROPE) and V ----
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + 256 * it;
+            const int key = item >> 4, dq = item & 15;
+            const int kg = k0 + key;
+            float uy = 0.f, vy = 0.f, ux = 0.f, vx = 0.f;
+            if (kg < a.Nk) {
+                const float *kr = kb + (int64_t)kg * a.k_sn;
+                uy = kr[dq]; vy = kr[16 + dq]; ux = kr[32 + dq]; vx = kr[48 + dq];
+                if (ROPE) {
+                    const int64_t py = a.kpos[((int64_t)b * a.Nk + kg) * 2 + 0], px = a.kpos[((int64_t)b * a.Nk + kg) * 2 + 1];
+                    const float cy = a.cos_tab[py * 16 + dq], sy = a.sin_tab[py * 16 + dq];
+                    const float cx = a.cos_tab[px * 16 + dq], sx = a.sin_tab[px * 16 + dq];
+                    const float t0 = uy * cy - vy * sy, t1 = vy * cy + uy * sy;
+                    const float t2 = ux * cx - vx * sx, t3 = vx * cx + ux * sx;
+                    uy = t0; vy = t1; ux = t2; vx = t3;
+                }
+            }
+            float *dst = s_k + key * KSTR;
+            dst[dq] = uy; dst[16 + dq] = vy; dst[32 + dq] = ux; dst[48 + dq] = vx;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + 256 * it;
+            const int key = item >> 4, c4 = item & 15;
+            const int kg = k0 + key;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kg < a.Nk) val = *reinterpret_cast<const float4 *>(vb + (int64_t)kg * a.v_sn + 4 * c4);
+            *reinterpret_cast<float4 *>(s_v + key * HD + 4 * c4) = val;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for the two 32-key blocks ----
+        f32x16 st0 = {0}, st1 = {0};
+        {
+            const float *ka = s_k + col * KSTR + half;          // K[key = col][d = 2s + half]
+            const float *kc = s_k + (32 + col) * KSTR + half;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                st0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], st0, 0, 0, 0);
+                st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[2 * s], qf[s], st1, 0, 0, 0);
+            }
+        }
+        // mask keys beyond Nk: element r of block kb is key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 half
+        if (k0 + KT > a.Nk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (key >= a.Nk) st0[r] = -INFINITY;
+                if (key + 32 >= a.Nk) st1[r] = -INFINITY;
+            }
+        }
+        // ---- online softmax (base 2) ----
+        float tmax = st0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, st0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st1[r]);
+        tmax = fmaxf(tmax, wave_xor32(tmax));
+        const float m_new = fmaxf(m, tmax);
+        const float alpha = exp2f(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st0[r] = exp2f(st0[r] - m_new); psum += st0[r]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st1[r] = exp2f(st1[r] - m_new); psum += st1[r]; }
+        psum += wave_xor32(psum);
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T P^T : step (kb, r) contracts keys 32 kb + (r&3) + 8 (r>>2) + {0, 4} ----
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float *va = s_v + key * HD + col;           // V[key][d = col (+32)]
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], st0[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], st0[r], o1, 0, 0, 0);
+                const float *vc = va + 32 * HD;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0], st1[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[32], st1[r], o1, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O = O^T / l, out[q][d], d = 8g + 4 half + {0..3} (+32) ----
+    if (q0 + col < a.Nq) {
+        const float inv = 1.f / l;
+        float *orow = out + (int64_t)b * a.o_sb + (int64_t)(q0 + col) * a.o_sn + (int64_t)h * a.o_sh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * half;
+            *reinterpret_cast<float4 *>(orow + d) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4 *>(orow + 32 + d) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+        if (lse && half == 0) lse[((int64_t)b * a.H + h) * a.Nq + q0 + col] = (m + log2f(l)) * 0.6931471805599453f;
+    }
+}
+
+int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse,
+                  hipStream_t stream)
+{
+    if (!q || !k || !v || !out) return VIT_EINVAL;
+    if (a.B <= 0 || a.H <= 0 || a.Nq <= 0 || a.Nk <= 0) return VIT_EINVAL;
+    const bool rope = a.cos_tab != nullptr;
+    if (rope && (!a.sin_tab || !a.qpos || !a.kpos || a.P <= 0)) return VIT_EINVAL;
+    // float4 epilogue / V loads need 16-byte aligned rows
+    if ((a.o_sn | a.o_sh | a.o_sb | a.v_sn | a.v_sh | a.v_sb) & 3) return VIT_EINVAL;
+    const dim3 grid((a.Nq + QB - 1) / QB, a.H, a.B);
+    (void)hipGetLastError();
+    if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+    else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+}  // namespace vit

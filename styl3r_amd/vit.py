@@ -1,0 +1,130 @@
+"""CroCo / MASt3R ViT building blocks on the gfx950 kernels, with the reference's parameter names.
+
+Mirrors src/model/encoder/backbone/croco/blocks.py: `Mlp` (:61-82), `Attention` (:84-134),
+`Block` (:136-152), `CrossAttention` (:154-200), `DecoderBlock` (:202-222).  state_dict keys are
+identical (qkv / proj / projq / projk / projv / fc1 / fc2 / norm1..3 / norm_y), so reference
+checkpoints load unchanged.  Differences that do not change results: q, k, v are strided views of
+the fused qkv buffer (no rearrange copies), the 2-D RoPE is applied inside the attention kernel
+(the reference rotates the qkv buffer in place with two extra read/write sweeps), dropout layers with
+p = 0 are omitted (every Styl3R config uses drop = attn_drop = drop_path = 0).
+Linear / LayerNorm / GELU run through torch (hipBLASLt / rocm kernels) in fp32.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .vit_ops import memory_efficient_attention
+
+
+class RopeCfg:
+    """what the reference passes around as a `rope` module: RoPE2D(freq=100) (backbone_croco_multiview.py:29)."""
+
+    def __init__(self, freq: float = 100.0, max_pos: int = 64):
+        self.freq, self.max_pos = freq, max_pos
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, bias=True, drop=0.0):
+        super().__init__()
+        assert drop == 0.0
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, rope: Optional[RopeCfg] = None, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        assert attn_drop == 0.0 and proj_drop == 0.0 and dim // num_heads == 64
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.rope = rope
+
+    def forward(self, x: Tensor, xpos: Tensor) -> Tensor:
+        B, N, C = x.shape
+        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B,N,H,64) views, no copies
+        if self.rope is not None:
+            o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=xpos, kpos=xpos, rope_base=self.rope.freq,
+                                           max_pos=self.rope.max_pos)
+        else:
+            o = memory_efficient_attention(q, k, v, scale=self.scale)
+        return self.proj(o.reshape(B, N, C))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, rope=None):
+        super().__init__()
+        assert drop_path == 0.0
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, rope=rope, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x: Tensor, xpos: Tensor) -> Tensor:
+        x = x + self.attn(self.norm1(x), xpos)
+        x = x + self.mlp(self.norm2(x))
+        return x
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, dim, rope: Optional[RopeCfg] = None, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        assert attn_drop == 0.0 and proj_drop == 0.0 and dim // num_heads == 64
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.projq = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projk = nn.Linear(dim, dim, bias=qkv_bias)
+        self.projv = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.rope = rope
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, qpos: Tensor, kpos: Tensor) -> Tensor:
+        B, Nq, C = query.shape
+        H = self.num_heads
+        q = self.projq(query).view(B, Nq, H, C // H)
+        k = self.projk(key).view(B, key.shape[1], H, C // H)
+        v = self.projv(value).view(B, value.shape[1], H, C // H)
+        if self.rope is not None:
+            o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=qpos, kpos=kpos, rope_base=self.rope.freq,
+                                           max_pos=self.rope.max_pos)
+        else:
+            o = memory_efficient_attention(q, k, v, scale=self.scale)
+        return self.proj(o.reshape(B, Nq, C))
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, norm_mem=True, rope=None):
+        super().__init__()
+        assert drop_path == 0.0
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, rope=rope, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.cross_attn = CrossAttention(dim, rope=rope, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop,
+                                         proj_drop=drop)
+        self.norm2 = norm_layer(dim)
+        self.norm3 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.norm_y = norm_layer(dim) if norm_mem else nn.Identity()
+
+    def forward(self, x: Tensor, y: Tensor, xpos: Tensor, ypos: Tensor):
+        x = x + self.attn(self.norm1(x), xpos)
+        y_ = self.norm_y(y)
+        x = x + self.cross_attn(self.norm2(x), y_, y_, xpos, ypos)
+        x = x + self.mlp(self.norm3(x))
+        return x, y
+
+
+LayerNorm6 = partial(nn.LayerNorm, eps=1e-6)   # croco.py:34 norm_layer=partial(nn.LayerNorm, eps=1e-6)

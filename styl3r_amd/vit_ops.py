@@ -1,0 +1,228 @@
+"""Host side of libvit_hip.so (include/vit_ops.h): fused 2-D RoPE and fp32 MFMA
+flash attention for the CroCo/MASt3R ViT blocks.
+
+Mirrors the reference operator interfaces:
+  * `cuRoPE2D` / `cuRoPE2D_func`   src/model/encoder/backbone/croco/curope/curope2d.py:12-39
+    (in-place on the (B,H,N,D) view, backward = same kernel with -F0)
+  * `memory_efficient_attention(q, k, v, scale=, p=0)` on (B,N,H,64) fp32 tensors, blocks.py:129,195
+No CPU / eager fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+_PKG = Path(__file__).resolve().parent
+_CSRC = _PKG / "csrc"
+LIB_PATH = _PKG / "lib" / "libvit_hip.so"
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_api.hip"]
+EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_version", "vit_last_error")
+ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
+_lib = None
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    srcs = [_CSRC / s for s in _SOURCES if (_CSRC / s).exists()]
+    deps = srcs + [(_PKG.parent / "include" / "vit_ops.h")]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    LIB_PATH.parent.mkdir(exist_ok=True)
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           *map(str, srcs), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(_CSRC))
+    return LIB_PATH
+
+
+class VitAttnArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float),
+                ("q_sb", C.c_int64), ("q_sn", C.c_int64), ("q_sh", C.c_int64),
+                ("k_sb", C.c_int64), ("k_sn", C.c_int64), ("k_sh", C.c_int64),
+                ("v_sb", C.c_int64), ("v_sn", C.c_int64), ("v_sh", C.c_int64),
+                ("o_sb", C.c_int64), ("o_sn", C.c_int64), ("o_sh", C.c_int64),
+                ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+                ("P", C.c_int32)]
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+    import torch  # noqa: F401  one shared HIP runtime (see _lib.py)
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i64 = C.c_void_p, C.c_int64
+    lib.vit_rope2d.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp]
+    lib.vit_rope2d.restype = C.c_int
+    lib.vit_attention_fwd.argtypes = [C.POINTER(VitAttnArgs), vp, vp, vp, vp, vp, vp]
+    lib.vit_attention_fwd.restype = C.c_int
+    if hasattr(lib, "vit_attention_bwd"):
+        lib.vit_attention_bwd.argtypes = [C.POINTER(VitAttnArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.vit_attention_bwd.restype = C.c_int
+    lib.vit_version.restype = C.c_char_p
+    lib.vit_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)} {load().vit_last_error().decode()}")
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t: Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: styl3r_amd ViT kernels need tensors on an MI355X (HIP) device; there is no CPU path")
+
+
+# ---------------------------------------------------------------------------
+# RoPE
+# ---------------------------------------------------------------------------
+_ROPE_TABLES: dict = {}
+
+
+def rope_tables(D: int, P: int, base: float, device) -> tuple:
+    """(cos, sin) of shape (P, D/4), built with the reference fallback's own ops (pos_embed.py:121-128)
+    so that the kernel reproduces it bit for bit on the same device."""
+    key = (D, P, float(base), str(device))
+    if key not in _ROPE_TABLES:
+        Dh = D // 2
+        inv_freq = 1.0 / (base ** (torch.arange(0, Dh, 2).float().to(device) / Dh))
+        t = torch.arange(P, device=device, dtype=inv_freq.dtype)
+        freqs = torch.einsum("i,j->ij", t, inv_freq)
+        _ROPE_TABLES[key] = (freqs.cos().contiguous(), freqs.sin().contiguous())
+    return _ROPE_TABLES[key]
+
+
+def _rope_inplace(tokens_bnhd: Tensor, positions: Tensor, base: float, F0: float, max_pos: int):
+    """tokens_bnhd: (B,N,H,D) view with contiguous last dim (may be a view into a qkv buffer)."""
+    _need_gpu(tokens_bnhd, "rope_2d")
+    B, N, H, D = tokens_bnhd.shape
+    assert tokens_bnhd.dtype == torch.float32 and tokens_bnhd.stride(3) == 1 and D % 4 == 0
+    assert positions.dtype == torch.int64 and positions.shape == (B, N, 2) and positions.is_contiguous()
+    cos, sin = rope_tables(D, max_pos + 1, base, tokens_bnhd.device)
+    sign = 1.0 if F0 >= 0 else -1.0
+    assert abs(F0) == 1.0, "only F0 = +-1 (the reference uses F0 = 1)"
+    rc = load().vit_rope2d(tokens_bnhd.data_ptr(), positions.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, N, H, D,
+                           max_pos + 1, tokens_bnhd.stride(0), tokens_bnhd.stride(1), tokens_bnhd.stride(2), sign,
+                           _stream(tokens_bnhd.device))
+    _check(rc, "vit_rope2d")
+
+
+class _RoPE2DFunc(torch.autograd.Function):
+    """cuRoPE2D_func (curope2d.py:12-29): in place forward, backward = inverse rotation of the incoming grad."""
+
+    @staticmethod
+    def forward(ctx, tokens, positions, base, F0, max_pos):
+        ctx.save_for_backward(positions)
+        ctx.cfg = (base, F0, max_pos)
+        _rope_inplace(tokens, positions, base, F0, max_pos)
+        ctx.mark_dirty(tokens)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, grad):
+        (positions,) = ctx.saved_tensors
+        base, F0, max_pos = ctx.cfg
+        grad = grad.contiguous() if grad.stride(3) != 1 else grad
+        _rope_inplace(grad, positions, base, -F0, max_pos)
+        return grad, None, None, None, None
+
+
+class RoPE2D(nn.Module):
+    """Drop-in for `cuRoPE2D(freq, F0)`; `max_pos` bounds the positions (16 at 256x256 incl. the
+    intrinsics token at (16,0)), which replaces the fallback's `int(positions.max())` host sync."""
+
+    def __init__(self, freq: float = 100.0, F0: float = 1.0, max_pos: int = 64):
+        super().__init__()
+        self.base, self.F0, self.max_pos = freq, F0, max_pos
+
+    def forward(self, tokens: Tensor, positions: Tensor) -> Tensor:
+        _RoPE2DFunc.apply(tokens.transpose(1, 2), positions, self.base, self.F0, self.max_pos)
+        return tokens
+
+
+# ---------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------
+def _attn_args(q, k, v, out, scale, rope):
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    assert D == 64 and k.shape == (B, Nk, H, D) and v.shape == (B, Nk, H, D)
+    for t in (q, k, v, out):
+        assert t.dtype == torch.float32 and t.stride(3) == 1
+    a = VitAttnArgs()
+    a.B, a.H, a.Nq, a.Nk, a.scale = B, H, Nq, Nk, float(scale)
+    a.q_sb, a.q_sn, a.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    a.k_sb, a.k_sn, a.k_sh = k.stride(0), k.stride(1), k.stride(2)
+    a.v_sb, a.v_sn, a.v_sh = v.stride(0), v.stride(1), v.stride(2)
+    a.o_sb, a.o_sn, a.o_sh = out.stride(0), out.stride(1), out.stride(2)
+    keep = None
+    if rope is not None:
+        qpos, kpos, base, max_pos = rope
+        cos, sin = rope_tables(D, max_pos + 1, base, q.device)
+        assert qpos.shape == (B, Nq, 2) and kpos.shape == (B, Nk, 2) and qpos.dtype == torch.int64
+        qpos, kpos = qpos.contiguous(), kpos.contiguous()
+        a.qpos, a.kpos, a.cos_tab, a.sin_tab, a.P = qpos.data_ptr(), kpos.data_ptr(), cos.data_ptr(), sin.data_ptr(), max_pos + 1
+        keep = (qpos, kpos, cos, sin)
+    return a, keep
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale, qpos, kpos, base, max_pos):
+        _need_gpu(q, "attention")
+        B, Nq, H, D = q.shape
+        out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        rope = (qpos, kpos, base, max_pos) if qpos is not None else None
+        a, keep = _attn_args(q, k, v, out, scale, rope)
+        _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                        lse.data_ptr(), _stream(q.device)), "vit_attention_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, qpos, kpos)
+        ctx.cfg = (scale, base, max_pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse, qpos, kpos = ctx.saved_tensors
+        scale, base, max_pos = ctx.cfg
+        lib = load()
+        if not hasattr(lib, "vit_attention_bwd"):
+            raise RuntimeError("vit_attention_bwd is not built into libvit_hip.so")
+        g = g.contiguous()
+        dq = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+        dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
+        dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
+        rope = (qpos, kpos, base, max_pos) if qpos is not None else None
+        a, keep = _attn_args(q, k, v, out, scale, rope)
+        delta = torch.empty_like(lse)
+        _check(lib.vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                     lse.data_ptr(), g.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                     delta.data_ptr(), _stream(q.device)), "vit_attention_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[float] = None, p: float = 0.0,
+                               qpos: Optional[Tensor] = None, kpos: Optional[Tensor] = None, rope_base: float = 100.0,
+                               max_pos: int = 64) -> Tensor:
+    """xformers-compatible call on (B,N,H,64) fp32 tensors (views into a qkv buffer are fine).  With
+    qpos/kpos the 2-D RoPE is applied to q and k inside the kernel (the buffers stay untouched)."""
+    if p != 0.0:
+        raise NotImplementedError("attention dropout is 0 in every Styl3R config (blocks.py: attn_drop=0.)")
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    return _Attention.apply(q, k, v, float(scale), qpos, kpos, rope_base, max_pos)

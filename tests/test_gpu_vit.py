@@ -1,0 +1,144 @@
+"""-m gpu: the ViT kernels (through libvit_hip.so) against the numpy oracle and the golden vectors
+captured from the reference's own RoPE2D / Attention / Block / CrossAttention / DecoderBlock."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+from tests.gpu_utils import assert_close_rel
+
+pytestmark = pytest.mark.gpu
+G = np.load(Path(__file__).resolve().parent / "golden" / "vit_blocks.npz")
+DEV = "cuda:0"
+
+
+def T(a, **kw):
+    return torch.tensor(np.asarray(a), device=DEV, **kw)
+
+
+def test_rope_kernel_matches_reference_golden_and_is_inplace_on_views():
+    from styl3r_amd.vit_ops import RoPE2D
+    tok = T(G["rope_tokens"]).requires_grad_(True)       # (B,H,N,D) contiguous
+    pos = T(G["rope_pos"])
+    rope = RoPE2D(100.0, max_pos=16)
+    work = tok.clone()
+    out = rope(work, pos)
+    assert out.data_ptr() == work.data_ptr()             # in place like cuRoPE2D
+    assert_close_rel(out.detach().cpu().numpy(), G["rope_out"], 2e-6, "rope fwd vs reference")
+    (out * T(G["rope_gout"])).sum().backward()
+    assert_close_rel(tok.grad.cpu().numpy(), G["rope_gin"], 2e-6, "rope bwd vs reference")
+    # bit-identical to the reference fallback's formula evaluated with torch on the SAME device
+    from styl3r_amd.vit_ops import rope_tables
+    cos, sin = rope_tables(64, 17, 100.0, torch.device(DEV))
+    t = T(G["rope_tokens"])
+    def half(x, p):
+        c = torch.cat((cos, cos), -1)[p][:, None]; s = torch.cat((sin, sin), -1)[p][:, None]
+        x1, x2 = x[..., :16], x[..., 16:]
+        return x * c + torch.cat((-x2, x1), -1) * s
+    ref = torch.cat((half(t[..., :32], pos[:, :, 0]), half(t[..., 32:], pos[:, :, 1])), -1)
+    assert torch.equal(rope(t.clone(), pos), ref)
+    # strided view of a qkv buffer: (B,N,3,H,D) -> q view (B,H,N,D)
+    qkv = torch.randn(2, 21, 3, 4, 64, device=DEV)
+    before = qkv.clone()
+    qv = qkv[:, :, 0].transpose(1, 2)
+    rope(qv, pos)
+    want = vo.rope2d(before[:, :, 0].cpu().numpy(), pos.cpu().numpy())
+    assert_close_rel(qkv[:, :, 0].cpu().numpy(), want, 2e-6, "rope on qkv view")
+    assert torch.equal(qkv[:, :, 1:], before[:, :, 1:])   # k, v untouched
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1)])
+def test_attention_forward_vs_oracle(B, H, Nq, Nk):
+    from styl3r_amd.vit_ops import memory_efficient_attention
+    g = torch.Generator(DEV).manual_seed(Nq * 7 + Nk)
+    q = torch.randn(B, Nq, H, 64, device=DEV, generator=g)
+    k = torch.randn(B, Nk, H, 64, device=DEV, generator=g)
+    v = torch.randn(B, Nk, H, 64, device=DEV, generator=g)
+    out = memory_efficient_attention(q, k, v, scale=0.125)
+    ref, _ = vo.attention(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), 0.125)
+    assert_close_rel(out.cpu().numpy(), ref, 1e-5, "attention fwd")
+
+
+def test_attention_forward_fused_rope_on_qkv_views():
+    from styl3r_amd.vit_ops import memory_efficient_attention
+    B, N, H = 2, 257, 4
+    g = torch.Generator(DEV).manual_seed(3)
+    qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g)
+    keep = qkv.clone()
+    pos = torch.cartesian_prod(torch.arange(17), torch.arange(17))[:N].to(DEV)[None].expand(B, -1, -1).contiguous()
+    out = memory_efficient_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], scale=0.125, qpos=pos, kpos=pos, max_pos=16)
+    assert torch.equal(qkv, keep)                          # the qkv buffer is not rewritten
+    qn, kn, vn = (keep[:, :, i].cpu().numpy() for i in range(3))
+    p = pos.cpu().numpy()
+    ref, _ = vo.attention(vo.rope2d(qn, p), vo.rope2d(kn, p), vn, 0.125)
+    assert_close_rel(out.cpu().numpy(), ref, 1e-5, "attention fwd + fused rope")
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, False), (1, 2, 130, 771, True), (1, 1, 5, 1, False), (2, 2, 33, 160, True)])
+def test_attention_backward_vs_oracle(B, H, Nq, Nk, rope):
+    from styl3r_amd.vit_ops import memory_efficient_attention
+    g = torch.Generator(DEV).manual_seed(Nq * 3 + Nk)
+    q = torch.randn(B, Nq, H, 64, device=DEV, generator=g, requires_grad=True)
+    k = torch.randn(B, Nk, H, 64, device=DEV, generator=g, requires_grad=True)
+    v = torch.randn(B, Nk, H, 64, device=DEV, generator=g, requires_grad=True)
+    w = torch.randn(B, Nq, H, 64, device=DEV, generator=g)
+    kw = {}
+    qn, kn = q.detach().cpu().numpy(), k.detach().cpu().numpy()
+    if rope:
+        side = 28
+        grid = torch.cartesian_prod(torch.arange(side), torch.arange(side)).to(DEV)
+        qpos = grid[:Nq][None].expand(B, -1, -1).contiguous(); kpos = grid[5:5 + Nk][None].expand(B, -1, -1).contiguous()
+        kw = dict(qpos=qpos, kpos=kpos, max_pos=side)
+    out = memory_efficient_attention(q, k, v, scale=0.125, **kw)
+    (out * w).sum().backward()
+    if rope:
+        qr, kr = vo.rope2d(qn, qpos.cpu().numpy()), vo.rope2d(kn, kpos.cpu().numpy())
+    else:
+        qr, kr = qn, kn
+    dq, dk, dv = vo.attention_backward(qr, kr, v.detach().cpu().numpy(), 0.125, w.cpu().numpy())
+    if rope:   # gradient w.r.t. the unrotated inputs = inverse rotation of the gradient of the rotated ones
+        dq, dk = vo.rope2d(dq, qpos.cpu().numpy(), fwd=-1.0), vo.rope2d(dk, kpos.cpu().numpy(), fwd=-1.0)
+    assert_close_rel(q.grad.cpu().numpy(), dq, 2e-5, "dq")
+    assert_close_rel(k.grad.cpu().numpy(), dk, 2e-5, "dk")
+    assert_close_rel(v.grad.cpu().numpy(), dv, 2e-5, "dv")
+
+
+def _load(mod, prefix):
+    sd = {k[len(prefix) + 4:]: T(G[k]) for k in G.files if k.startswith(prefix + "_sd_")}
+    missing = mod.load_state_dict(sd, strict=True)
+    return mod.to(DEV).eval()
+
+
+def _check_module(prefix, mod, call, in_names, tol=2e-5):
+    mod = _load(mod, prefix)
+    ins = {}
+    for n in in_names:
+        a = T(G[f"{prefix}_in_{n}"])
+        ins[n] = a.requires_grad_(True) if a.is_floating_point() else a
+    y = call(mod, ins)
+    y = y[0] if isinstance(y, tuple) else y
+    assert_close_rel(y.detach().cpu().numpy(), G[f"{prefix}_out"], tol, f"{prefix} output vs reference")
+    (y * T(G[f"{prefix}_gout"])).sum().backward()
+    for n in in_names:
+        if ins[n].is_floating_point():
+            assert_close_rel(ins[n].grad.cpu().numpy(), G[f"{prefix}_gin_{n}"], 5e-5, f"{prefix} d{n} vs reference")
+    for k in G.files:
+        if k.startswith(prefix + "_gp_"):
+            name = k[len(prefix) + 4:]
+            got = dict(mod.named_parameters())[name].grad
+            assert_close_rel(got.cpu().numpy(), G[k], 5e-5, f"{prefix} d{name} vs reference")
+
+
+def test_blocks_match_reference_modules():
+    from styl3r_amd import vit
+    rope = vit.RopeCfg(100.0, max_pos=16)
+    _check_module("mlp", vit.Mlp(128, 256), lambda m, i: m(i["x"]), ["x"])
+    _check_module("attn", vit.Attention(128, rope=rope, num_heads=2, qkv_bias=True), lambda m, i: m(i["x"], i["xpos"]), ["x", "xpos"])
+    _check_module("block", vit.Block(128, 2, 1.0, qkv_bias=True, norm_layer=vit.LayerNorm6, rope=rope),
+                  lambda m, i: m(i["x"], i["xpos"]), ["x", "xpos"])
+    _check_module("xattn", vit.CrossAttention(128, rope=rope, num_heads=2, qkv_bias=True),
+                  lambda m, i: m(i["q"], i["kv"], i["kv"], i["qpos"], i["kpos"]), ["q", "kv", "qpos", "kpos"])
+    _check_module("dec", vit.DecoderBlock(128, 2, 1.0, qkv_bias=True, norm_layer=vit.LayerNorm6, rope=rope),
+                  lambda m, i: m(i["x"], i["y"], i["xpos"], i["ypos"]), ["x", "y", "xpos", "ypos"])
