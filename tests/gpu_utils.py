@@ -51,9 +51,9 @@ def oracle_single_view(precision, means, cov6, opac, cam, shs=None, colors=None,
     return orc, st, ctx
 
 
-def assert_close_rel(actual, expected, rel=1e-4, what=""):
+def assert_close_rel(actual, expected, rel=1e-4, what="", atol=0.0):
     """max |a-e| <= rel * max|e| (+ tiny absolute floor): the 1e-4-rel bar of BASELINE.json's north_star."""
     a = np.asarray(actual, dtype=np.float64); e = np.asarray(expected, dtype=np.float64)
     scale = max(np.abs(e).max(), 1e-12)
     err = np.abs(a - e).max()
-    assert err <= rel * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"
+    assert err <= rel * scale + atol, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"

@@ -100,9 +100,10 @@ def test_attention_backward_vs_oracle(B, H, Nq, Nk, rope):
     dq, dk, dv = vo.attention_backward(qr, kr, v.detach().cpu().numpy(), 0.125, w.cpu().numpy())
     if rope:   # gradient w.r.t. the unrotated inputs = inverse rotation of the gradient of the rotated ones
         dq, dk = vo.rope2d(dq, qpos.cpu().numpy(), fwd=-1.0), vo.rope2d(dk, kpos.cpu().numpy(), fwd=-1.0)
-    assert_close_rel(q.grad.cpu().numpy(), dq, 2e-5, "dq")
-    assert_close_rel(k.grad.cpu().numpy(), dk, 2e-5, "dk")
-    assert_close_rel(v.grad.cpu().numpy(), dv, 2e-5, "dv")
+    # atol: with a single key the softmax is constant and dq = dk = 0 exactly; fp32 leaves ~1e-6
+    assert_close_rel(q.grad.cpu().numpy(), dq, 2e-5, "dq", atol=1e-5)
+    assert_close_rel(k.grad.cpu().numpy(), dk, 2e-5, "dk", atol=1e-5)
+    assert_close_rel(v.grad.cpu().numpy(), dv, 2e-5, "dv", atol=1e-5)
 
 
 def _load(mod, prefix):
