@@ -1,0 +1,474 @@
+"""Style-token encoder: the reference's `src/model/encoder` API on the gfx950 ViT kernels.
+
+Own restatement (same parameter names, so reference checkpoints load unchanged) of
+  * `AsymmetricCroCoMulti`          src/model/encoder/backbone/backbone_croco_multiview.py:50-227
+  * `CroCoNet` trunk                src/model/encoder/backbone/croco/croco.py:21-128
+  * `PatchEmbedDust3R`              src/model/encoder/backbone/croco/patch_embed.py:19-29, blocks.py:226-238
+  * `TokenStylizer`                 src/model/encoder/token_stylizer/token_stylizer.py:36-154
+  * DPT heads (pts3d / gs / sh)     src/model/encoder/heads/{dpt_block,dpt_head,dpt_gs_head,dpt_gs_sh_head}.py
+  * `reg_dense_depth('exp')`        src/model/encoder/heads/postprocess.py:22-60
+  * `UnifiedGaussianAdapter`        src/model/encoder/common/gaussian_adapter.py:122-153, gaussians.py:8-44
+  * `EncoderNoPoSplatMultiTokenStyle.forward`  src/model/encoder/encoder_noposplat_multi_token_style.py:136-251
+  * `get_encoder`                   src/model/encoder/__init__.py:20-25
+Transformer blocks run on styl3r_amd.vit (fp32-MFMA flash attention with fused RoPE); convolutions,
+Linear and LayerNorm go through torch (MIOpen / hipBLASLt) in fp32 like the reference
+(heads under autocast(enabled=False), encoder_noposplat_multi_token_style.py:150).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Literal, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .decoder import Gaussians
+from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
+
+inf = float("inf")
+
+CROCO_PARAMS = {
+    # backbone_croco_multiview.py:21-32 / token_stylizer.py croco_params
+    "ViTLarge_BaseDecoder": dict(enc_depth=24, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=768, enc_num_heads=16,
+                                 dec_num_heads=12, pos_embed="RoPE100", img_size=(512, 512)),
+}
+
+
+# --------------------------------------------------------------------------- config (field names = the YAML spec)
+@dataclass
+class BackboneCrocoCfg:
+    name: Literal["croco", "croco_multi"] = "croco_multi"
+    model: str = "ViTLarge_BaseDecoder"
+    patch_embed_cls: str = "PatchEmbedDust3R"
+    asymmetry_decoder: bool = True
+    intrinsics_embed_loc: Literal["encoder", "decoder", "none"] = "encoder"
+    intrinsics_embed_degree: int = 4
+    intrinsics_embed_type: Literal["pixelwise", "linear", "token"] = "token"
+
+
+@dataclass
+class TokenStylizerCfg:
+    model: str = "ViTLarge_BaseDecoder"
+    patch_embed_cls: str = "PatchEmbedDust3R"
+    pretrained_weights: str = ""
+
+
+@dataclass
+class GaussianAdapterCfg:
+    gaussian_scale_min: float = 0.5
+    gaussian_scale_max: float = 15.0
+    sh_degree: int = 0
+
+
+@dataclass
+class OpacityMappingCfg:
+    initial: float = 0.0
+    final: float = 0.0
+    warm_up: int = 1
+
+
+@dataclass
+class EncoderNoPoSplatTokenStyleCfg:
+    name: str = "noposplat_multi_token_style"
+    d_feature: int = 128
+    num_monocular_samples: int = 32
+    backbone: BackboneCrocoCfg = field(default_factory=BackboneCrocoCfg)
+    token_stylizer: TokenStylizerCfg = field(default_factory=TokenStylizerCfg)
+    gaussian_adapter: GaussianAdapterCfg = field(default_factory=GaussianAdapterCfg)
+    opacity_mapping: OpacityMappingCfg = field(default_factory=OpacityMappingCfg)
+    apply_bounds_shim: bool = True
+    gaussians_per_pixel: int = 1
+    num_surfaces: int = 1
+    gs_params_head_type: str = "dpt_gs"
+    gs_sh_head_type: str = "dpt"
+    input_mean: tuple = (0.5, 0.5, 0.5)
+    input_std: tuple = (0.5, 0.5, 0.5)
+    pretrained_weights: str = ""
+    pose_free: bool = True
+    stylized: bool = True
+
+
+# --------------------------------------------------------------------------- trunk
+class PatchEmbedDust3R(nn.Module):
+    def __init__(self, img_size, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x: Tensor):
+        B, C, H, W = x.shape
+        assert H % self.patch_size[0] == 0 and W % self.patch_size[1] == 0, "image size must be a multiple of the patch size"
+        x = self.proj(x)
+        h, w = x.shape[2], x.shape[3]
+        pos = torch.cartesian_prod(torch.arange(h, device=x.device), torch.arange(w, device=x.device))
+        pos = pos.view(1, h * w, 2).expand(B, -1, 2).clone()
+        return x.flatten(2).transpose(1, 2), pos
+
+
+class CrocoTrunk(nn.Module):
+    """Parameter layout of CroCoNet with RoPE positional embedding (croco.py:21-99)."""
+
+    def __init__(self, enc_depth, dec_depth, enc_embed_dim, dec_embed_dim, enc_num_heads, dec_num_heads, pos_embed,
+                 img_size, mlp_ratio=4, norm_im2_in_dec=True, max_pos=64):
+        super().__init__()
+        assert pos_embed.startswith("RoPE")
+        self.rope = RopeCfg(float(pos_embed[len("RoPE"):]), max_pos=max_pos)
+        self.patch_embed = PatchEmbedDust3R(img_size, 16, 3, enc_embed_dim)
+        self.enc_depth, self.enc_embed_dim = enc_depth, enc_embed_dim
+        self.enc_blocks = nn.ModuleList([Block(enc_embed_dim, enc_num_heads, mlp_ratio, qkv_bias=True, norm_layer=LayerNorm6,
+                                               rope=self.rope) for _ in range(enc_depth)])
+        self.enc_norm = LayerNorm6(enc_embed_dim)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, dec_embed_dim))
+        self.dec_depth, self.dec_embed_dim = dec_depth, dec_embed_dim
+        self.decoder_embed = nn.Linear(enc_embed_dim, dec_embed_dim, bias=True)
+        self.dec_blocks = nn.ModuleList([DecoderBlock(dec_embed_dim, dec_num_heads, mlp_ratio=mlp_ratio, qkv_bias=True,
+                                                      norm_layer=LayerNorm6, norm_mem=norm_im2_in_dec, rope=self.rope)
+                                         for _ in range(dec_depth)])
+        self.dec_norm = LayerNorm6(dec_embed_dim)
+        self.depth_mode, self.conf_mode = ("exp", -inf, inf), None
+
+    @property
+    def patch_size(self) -> int:
+        return 16
+
+    @property
+    def d_out(self) -> int:
+        return 1024
+
+
+class AsymmetricCroCoMulti(CrocoTrunk):
+    def __init__(self, cfg: BackboneCrocoCfg, d_in: int = 3, params: Optional[dict] = None):
+        super().__init__(**(params or CROCO_PARAMS[cfg.model]))
+        assert cfg.intrinsics_embed_loc == "encoder" and cfg.intrinsics_embed_type == "token", \
+            "only the 'token' intrinsics embedding of config/model/encoder/backbone/croco.yaml is built"
+        if cfg.asymmetry_decoder:
+            self.dec_blocks2 = copy.deepcopy(self.dec_blocks)
+        self.intrinsic_encoder = nn.Linear(9, 1024)
+
+    def load_state_dict(self, ckpt, **kw):
+        ckpt = dict(ckpt)
+        if not any(k.startswith("dec_blocks2") for k in ckpt):      # DUSt3R/MASt3R checkpoints (:99-106)
+            for k, v in list(ckpt.items()):
+                if k.startswith("dec_blocks"):
+                    ckpt[k.replace("dec_blocks", "dec_blocks2")] = v
+        return super().load_state_dict(ckpt, **kw)
+
+    def _encode_image(self, image: Tensor, intrinsics_token: Tensor):
+        x, pos = self.patch_embed(image)
+        x = torch.cat((x, intrinsics_token), dim=1)
+        extra = pos[:, 0:1, :].clone()
+        extra[:, :, 0] += pos[:, -1, 0].unsqueeze(-1) + 1            # the token sits at (rows, 0)  (:131-135)
+        pos = torch.cat((pos, extra), dim=1)
+        for blk in self.enc_blocks:
+            x = blk(x, pos)
+        return self.enc_norm(x), pos
+
+    @staticmethod
+    def _other_views(x: Tensor) -> Tensor:
+        """(b,v,l,c) -> (b,v,(v-1)*l,c): for each view the tokens of all OTHER views, in view order (:159-165)."""
+        b, v, l, c = x.shape
+        out = []
+        for i in range(v):
+            out.append(torch.cat([x[:, j] for j in range(v) if j != i], dim=1))
+        return torch.stack(out, dim=1)
+
+    def _decoder(self, feat: Tensor, pos: Tensor):
+        b, v, l, c = feat.shape
+        outs = [feat]
+        cur = self.decoder_embed(feat)
+        pos_ctx = self._other_views(pos)
+        for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
+            ctx = self._other_views(cur)
+            f1, _ = blk1(cur[:, 0].contiguous(), ctx[:, 0].contiguous(), pos[:, 0].contiguous(), pos_ctx[:, 0].contiguous())
+            f2, _ = blk2(cur[:, 1:].reshape(b * (v - 1), l, -1), ctx[:, 1:].reshape(b * (v - 1), ctx.shape[2], -1),
+                         pos[:, 1:].reshape(b * (v - 1), l, 2), pos_ctx[:, 1:].reshape(b * (v - 1), pos_ctx.shape[2], 2))
+            cur = torch.cat((f1.unsqueeze(1), f2.view(b, v - 1, l, -1)), dim=1)
+            outs.append(cur)
+        outs[-1] = self.dec_norm(outs[-1])
+        return outs
+
+    def forward(self, context: dict):
+        b, v, _, h, w = context["image"].shape
+        images = context["image"].reshape(b * v, -1, h, w)
+        token = self.intrinsic_encoder(context["intrinsics"].flatten(2)).reshape(b * v, 1, -1)
+        feat, pos = self._encode_image(images, token)
+        feat = feat.view(b, v, feat.shape[1], -1)
+        pos = pos.view(b, v, pos.shape[1], 2)
+        dec_feat = [t[:, :, :-1] for t in self._decoder(feat, pos)]   # strip the intrinsics token (:222-225)
+        shape = torch.tensor([h, w]).repeat(b, v, 1)
+        return feat, pos, dec_feat, shape, context["image"]
+
+
+class TokenStylizer(CrocoTrunk):
+    def __init__(self, cfg: TokenStylizerCfg, params: Optional[dict] = None):
+        super().__init__(**(params or CROCO_PARAMS[cfg.model]))
+
+    def forward(self, style: dict, content_feat: Tensor, content_pos: Tensor):
+        x, spos = self.patch_embed(style["image"])
+        for blk in self.enc_blocks:
+            x = blk(x, spos)
+        style_feat = self.decoder_embed(self.enc_norm(x))
+        b, v, l, c = content_feat.shape
+        outs = [content_feat]
+        cf = self.decoder_embed(content_feat.reshape(b, v * l, c))
+        cpos = content_pos.reshape(b, v * l, 2)
+        for blk in self.dec_blocks:
+            cf, _ = blk(cf, style_feat, cpos, spos)
+            outs.append(cf.view(b, v, l, -1))
+        outs[-1] = self.dec_norm(cf).view(b, v, l, -1)
+        return [t[:, :, :-1] for t in outs]                            # drop the last (intrinsics) token per view (:151-152)
+
+
+# --------------------------------------------------------------------------- DPT heads
+class _ResidualConvUnit(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+
+    def forward(self, x):
+        out = self.conv1(F.relu(x))
+        out = self.conv2(F.relu(out))
+        return out + x
+
+
+class _FusionBlock(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.out_conv = nn.Conv2d(features, features, 1, bias=True)
+        self.resConfUnit1 = _ResidualConvUnit(features)
+        self.resConfUnit2 = _ResidualConvUnit(features)
+
+    def forward(self, x, skip=None):
+        if skip is not None:
+            x = x + self.resConfUnit1(skip)
+        x = self.resConfUnit2(x)
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        return self.out_conv(x)
+
+
+class _Up2(nn.Module):
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+class DPTAdapter(nn.Module):
+    """DPTOutputAdapter_fix of the three head files; `kind` selects the head variant."""
+
+    def __init__(self, num_channels, dim_tokens, hooks, kind: Literal["pts3d", "gs", "sh"], feature_dim=256, last_dim=128,
+                 layer_dims=(96, 192, 384, 768)):
+        super().__init__()
+        self.hooks, self.kind = list(hooks), kind
+        sc = nn.Module()
+        sc.layer1_rn = nn.Conv2d(layer_dims[0], feature_dim, 3, 1, 1, bias=False)
+        sc.layer2_rn = nn.Conv2d(layer_dims[1], feature_dim, 3, 1, 1, bias=False)
+        sc.layer3_rn = nn.Conv2d(layer_dims[2], feature_dim, 3, 1, 1, bias=False)
+        sc.layer4_rn = nn.Conv2d(layer_dims[3], feature_dim, 3, 1, 1, bias=False)
+        sc.layer_rn = nn.ModuleList([sc.layer1_rn, sc.layer2_rn, sc.layer3_rn, sc.layer4_rn])   # same tensors, both key sets
+        sc.refinenet1, sc.refinenet2 = _FusionBlock(feature_dim), _FusionBlock(feature_dim)
+        sc.refinenet3, sc.refinenet4 = _FusionBlock(feature_dim), _FusionBlock(feature_dim)
+        self.scratch = sc
+        if kind == "pts3d":     # 'regression' head (dpt_block.py:313-321)
+            self.head = nn.Sequential(nn.Conv2d(feature_dim, feature_dim // 2, 3, 1, 1), _Up2(),
+                                      nn.Conv2d(feature_dim // 2, last_dim, 3, 1, 1), nn.ReLU(True),
+                                      nn.Conv2d(last_dim, num_channels, 1))
+        else:                   # 'gs_params' head (:332-340)
+            self.head = nn.Sequential(nn.Conv2d(feature_dim, feature_dim, 3, padding=1, bias=False), nn.Identity(),
+                                      nn.ReLU(True), nn.Dropout(0.1, False), nn.Conv2d(feature_dim, num_channels, 1))
+        d = list(dim_tokens)
+        self.act_postprocess = nn.ModuleList([
+            nn.Sequential(nn.Conv2d(d[0], layer_dims[0], 1), nn.ConvTranspose2d(layer_dims[0], layer_dims[0], 4, 4)),
+            nn.Sequential(nn.Conv2d(d[1], layer_dims[1], 1), nn.ConvTranspose2d(layer_dims[1], layer_dims[1], 2, 2)),
+            nn.Sequential(nn.Conv2d(d[2], layer_dims[2], 1)),
+            nn.Sequential(nn.Conv2d(d[3], layer_dims[3], 1), nn.Conv2d(layer_dims[3], layer_dims[3], 3, 2, 1)),
+        ])
+        if kind == "gs":
+            self.input_merger = nn.Sequential(nn.Conv2d(3, 256, 7, 1, 3), nn.ReLU())
+
+    def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None) -> Tensor:
+        H, W = image_size
+        nh, nw = H // 16, W // 16
+        layers = [tokens[h] for h in self.hooks]
+        layers = [t.transpose(1, 2).reshape(t.shape[0], t.shape[2], nh, nw) for t in layers]
+        layers = [self.act_postprocess[i](t) for i, t in enumerate(layers)]
+        layers = [self.scratch.layer_rn[i](t) for i, t in enumerate(layers)]
+        p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]]
+        p3 = self.scratch.refinenet3(p4, layers[2])
+        p2 = self.scratch.refinenet2(p3, layers[1])
+        p1 = self.scratch.refinenet1(p2, layers[0])
+        if self.kind == "gs":
+            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True) + self.input_merger(imgs)
+        elif self.kind == "sh":
+            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True)
+        return self.head(p1)
+
+
+def reg_dense_depth_exp(xyz: Tensor) -> Tensor:
+    """mode ('exp', -inf, inf): unit direction x expm1(norm)  (postprocess.py:44-57)."""
+    d = xyz.norm(dim=-1, keepdim=True)
+    return xyz / d.clip(min=1e-8) * d.expm1()
+
+
+class PixelwiseTaskWithDPT(nn.Module):
+    def __init__(self, num_channels, net: CrocoTrunk, kind):
+        super().__init__()
+        l2 = net.dec_depth
+        assert l2 > 9
+        ed, dd = net.enc_embed_dim, net.dec_embed_dim
+        self.kind = kind
+        self.dpt = DPTAdapter(num_channels, [ed, dd, dd, dd], [0, l2 * 2 // 4, l2 * 3 // 4, l2], kind)
+
+    def forward(self, tokens, image_size, imgs=None):
+        out = self.dpt(tokens, image_size, imgs)
+        if self.kind == "pts3d":
+            return {"pts3d": reg_dense_depth_exp(out.permute(0, 2, 3, 1))}
+        return out
+
+
+def head_factory(head_type, output_mode, net, has_conf=False, out_nchan=3):
+    """heads/__init__.py:13-27 (the variants the style encoders use)."""
+    assert not has_conf
+    if head_type == "dpt" and output_mode == "pts3d":
+        return PixelwiseTaskWithDPT(3, net, "pts3d")
+    if head_type == "dpt_gs" and output_mode == "gs_params":
+        return PixelwiseTaskWithDPT(out_nchan, net, "gs")
+    if head_type == "dpt_gs_sh" and output_mode == "gs_params":
+        return PixelwiseTaskWithDPT(out_nchan, net, "sh")
+    raise NotImplementedError(f"unexpected {head_type=} and {output_mode=}")
+
+
+# --------------------------------------------------------------------------- Gaussian adapter
+def quaternion_to_matrix(q: Tensor, eps: float = 1e-8) -> Tensor:
+    i, j, k, r = torch.unbind(q, dim=-1)                     # xyzw order (gaussians.py:13)
+    two_s = 2 / ((q * q).sum(dim=-1) + eps)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(*q.shape[:-1], 3, 3)
+
+
+def build_covariance(scale: Tensor, rotation_xyzw: Tensor) -> Tensor:
+    S = scale.diag_embed()
+    R = quaternion_to_matrix(rotation_xyzw)
+    return R @ S @ S.transpose(-1, -2) @ R.transpose(-1, -2)
+
+
+@dataclass
+class AdapterGaussians:
+    means: Tensor
+    covariances: Tensor
+    scales: Tensor
+    rotations: Tensor
+    harmonics: Tensor
+    opacities: Tensor
+
+
+class UnifiedGaussianAdapter(nn.Module):
+    def __init__(self, cfg: GaussianAdapterCfg):
+        super().__init__()
+        self.cfg = cfg
+        mask = torch.ones((self.d_sh,), dtype=torch.float32)
+        for degree in range(1, cfg.sh_degree + 1):
+            mask[degree ** 2:(degree + 1) ** 2] = 0.1 * 0.25 ** degree
+        self.register_buffer("sh_mask", mask, persistent=False)
+
+    @property
+    def d_sh(self) -> int:
+        return (self.cfg.sh_degree + 1) ** 2
+
+    @property
+    def d_in(self) -> int:
+        return 7 + 3 * self.d_sh
+
+    def forward(self, means, depths, opacities, raw_gaussians, eps: float = 1e-8) -> AdapterGaussians:
+        scales, rotations, sh = raw_gaussians.split((3, 4, 3 * self.d_sh), dim=-1)
+        scales = (0.001 * F.softplus(scales)).clamp_max(0.3)
+        rotations = rotations / (rotations.norm(dim=-1, keepdim=True) + eps)
+        sh = sh.reshape(*sh.shape[:-1], 3, self.d_sh)
+        sh = sh.broadcast_to((*opacities.shape, 3, self.d_sh)) * self.sh_mask
+        return AdapterGaussians(means, build_covariance(scales, rotations), scales,
+                                rotations.broadcast_to((*scales.shape[:-1], 4)), sh, opacities)
+
+
+# --------------------------------------------------------------------------- encoder
+class EncoderNoPoSplatMultiTokenStyle(nn.Module):
+    def __init__(self, cfg: EncoderNoPoSplatTokenStyleCfg, trunk_params: Optional[dict] = None):
+        super().__init__()
+        self.cfg = cfg
+        assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
+        self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
+        self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
+        self.patch_size = 16
+        self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
+        d_sh3 = 3 * self.gaussian_adapter.d_sh
+        self.downstream_head1 = head_factory("dpt", "pts3d", self.backbone)
+        self.downstream_head2 = head_factory("dpt", "pts3d", self.backbone)
+        self.gaussian_param_head = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
+        self.gaussian_param_head2 = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
+        self.stylized = cfg.stylized
+        self.token_stylizer = TokenStylizer(cfg.token_stylizer, trunk_params)
+        self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
+
+    def map_pdf_to_opacity(self, pdf: Tensor, global_step: int) -> Tensor:
+        cfg = self.cfg.opacity_mapping
+        x = cfg.initial + min(global_step / cfg.warm_up, 1) * (cfg.final - cfg.initial)
+        exponent = 2 ** x
+        return 0.5 * (1 - (1 - pdf) ** exponent + pdf ** (1 / exponent))
+
+    def forward(self, context: dict, style: dict, global_step: int = 0,
+                visualization_dump: Optional[dict] = None) -> Gaussians:
+        b, v, _, h, w = context["image"].shape
+        enc_feat, enc_pos, dec_feat, shape, images = self.backbone(context)
+        sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
+
+        with torch.autocast("cuda", enabled=False):
+            pts, params, appearance = [], [], []
+            for i in range(v):
+                head = self.downstream_head1 if i == 0 else self.downstream_head2
+                pts.append(head([t[:, i].float() for t in dec_feat], (h, w))["pts3d"])
+            for i in range(v):
+                head = self.gaussian_param_head if i == 0 else self.gaussian_param_head2
+                out = head([t[:, i].float() for t in dec_feat], (h, w), images[:, i, :3])
+                params.append(out.flatten(2).transpose(1, 2))
+            for i in range(v):
+                out = self.gaussian_appearance_head([t[:, i].float() for t in sty_feat], (h, w))
+                appearance.append(out.flatten(2).transpose(1, 2))
+
+        pts_all = torch.stack(pts, dim=1).reshape(b, v, h * w, 1, 3)              # (b v r srf xyz)
+        depths = pts_all[..., -1].unsqueeze(-1)
+        d_sh3 = 3 * self.gaussian_adapter.d_sh
+        raw = torch.cat((torch.stack(params, dim=1)[..., :self.raw_gs_dim - d_sh3], torch.stack(appearance, dim=1)), dim=-1)
+        raw = raw.reshape(b, v, h * w, 1, -1)                                     # (b v r srf c)
+        densities = raw[..., 0].sigmoid().unsqueeze(-1)
+        g = self.gaussian_adapter(pts_all.unsqueeze(-2), depths, self.map_pdf_to_opacity(densities, global_step),
+                                  raw[..., 1:].unsqueeze(-2))
+        if visualization_dump is not None:
+            visualization_dump["depth"] = depths.reshape(b, v, h, w, 1, 1)
+            visualization_dump["scales"] = g.scales.reshape(b, -1, 3)
+            visualization_dump["rotations"] = g.rotations.reshape(b, -1, 4)
+            visualization_dump["means"] = g.means.reshape(b, v, h, w, 1, 3)
+            visualization_dump["opacities"] = g.opacities.reshape(b, v, h, w, 1, 1)
+        return Gaussians(g.means.reshape(b, -1, 3), g.covariances.reshape(b, -1, 3, 3),
+                         g.harmonics.reshape(b, -1, 3, self.gaussian_adapter.d_sh), g.opacities.reshape(b, -1))
+
+    def get_data_shim(self):
+        mean = torch.tensor(self.cfg.input_mean).view(1, 1, 3, 1, 1)
+        std = torch.tensor(self.cfg.input_std).view(1, 1, 3, 1, 1)
+
+        def data_shim(batch):      # apply_normalize_shim (src/dataset/shims/normalize_shim.py:21-27)
+            for key in ("context", "target"):
+                if key in batch and "image" in batch[key]:
+                    img = batch[key]["image"]
+                    batch[key] = {**batch[key], "image": (img - mean.to(img)) / std.to(img)}
+            return batch
+        return data_shim
+
+
+ENCODERS = {"noposplat_multi_token_style": EncoderNoPoSplatMultiTokenStyle}
+
+
+def get_encoder(cfg: EncoderNoPoSplatTokenStyleCfg):
+    """src/model/encoder/__init__.py:20-25: returns (encoder, visualizer=None)."""
+    return ENCODERS[cfg.name](cfg), None

@@ -34,3 +34,26 @@ def random_scene(G, seed=0, z_range=(2.0, 6.0), spread=1.2, scale=(0.02, 0.12), 
     M = (sh_degree + 1) ** 2
     shs = rng.normal(size=(G, M, 3)) * (0.5 / np.sqrt(np.arange(M) + 1.0))[None, :, None]
     return means, cov6, opac, shs
+
+
+def deterministic_init_(module, scale=1.0):
+    """Name-keyed deterministic parameters, shared by the fixture generator (applied to the REFERENCE
+    model) and the tests (applied to this repo's model): identical state_dict keys => identical weights,
+    so a 100M-parameter state_dict never has to be stored."""
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name in sorted(sd.keys()):
+            t = sd[name]
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            if t.dim() >= 2:
+                fan_in = t[0].numel()
+                val = torch.randn(t.shape, generator=g) * (scale / fan_in ** 0.5)
+            elif name.endswith("weight"):          # LayerNorm gains
+                val = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+            else:
+                val = 0.02 * torch.randn(t.shape, generator=g)
+            t.copy_(val.to(t.device))
+    return module

@@ -1,0 +1,68 @@
+"""Encoder against golden vectors captured from the reference's own
+EncoderNoPoSplatMultiTokenStyle (tests/golden/make_encoder_fixtures.py)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import deterministic_init_
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "encoder_tiny.npz")
+TINY = dict(enc_depth=1, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
+            pos_embed="RoPE100", img_size=(512, 512))
+
+
+def _build(sh_degree):
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg, GaussianAdapterCfg
+    cfg = EncoderNoPoSplatTokenStyleCfg(gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, sh_degree))
+    return EncoderNoPoSplatMultiTokenStyle(cfg, trunk_params=TINY).eval()
+
+
+@pytest.mark.parametrize("tag,sh_degree", [("sh0", 0), ("sh1", 1)])
+def test_state_dict_keys_and_parameter_count_match_reference(tag, sh_degree):
+    """drop-in checkpoint compatibility: identical key set (incl. the duplicated scratch.layer_rn aliases)"""
+    m = _build(sh_degree)
+    assert sorted(m.state_dict().keys()) == list(G[f"{tag}_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(G[f"{tag}_nparams"])
+
+
+def test_full_size_key_layout():
+    """the real ViT-L / ViT-B layout of SURVEY 8b without allocating it"""
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    with torch.device("meta"):
+        m = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg())
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 1_049_635_033
+    assert sd["backbone.patch_embed.proj.weight"].shape == (1024, 3, 16, 16)
+    assert sd["backbone.enc_blocks.23.attn.qkv.weight"].shape == (3072, 1024)
+    assert sd["backbone.dec_blocks2.11.cross_attn.projk.weight"].shape == (768, 768)
+    assert sd["backbone.intrinsic_encoder.weight"].shape == (1024, 9)
+    assert sd["gaussian_param_head.dpt.input_merger.0.weight"].shape == (256, 3, 7, 7)
+    assert sd["gaussian_param_head.dpt.head.4.weight"].shape[0] == 8
+    assert "downstream_head1.dpt.scratch.layer_rn.0.weight" in sd and "downstream_head1.dpt.scratch.layer1_rn.weight" in sd
+    assert "token_stylizer.dec_blocks.0.norm_y.weight" in sd and not any(k.startswith("token_stylizer.dec_blocks2") for k in sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,sh_degree", [("sh0", 0), ("sh1", 1)])
+def test_encoder_forward_backward_matches_reference(tag, sh_degree):
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(_build(sh_degree)).to(dev)
+    T = lambda k: torch.tensor(G[f"{tag}_{k}"], device=dev)
+    img = T("image").requires_grad_(True)
+    dump = {}
+    gs = m(dict(image=img, intrinsics=T("intrinsics")), dict(image=T("style")), global_step=0, visualization_dump=dump)
+    assert gs.means.shape == (1, 3 * 32 * 48, 3) and gs.harmonics.shape[-1] == (sh_degree + 1) ** 2
+    assert_close_rel(gs.means.detach().cpu().numpy(), G[f"{tag}_means"], 1e-4, "means")
+    assert_close_rel(gs.covariances.detach().cpu().numpy(), G[f"{tag}_cov"], 1e-4, "covariances")
+    assert_close_rel(gs.harmonics.detach().cpu().numpy(), G[f"{tag}_sh"], 1e-4, "harmonics")
+    assert_close_rel(gs.opacities.detach().cpu().numpy(), G[f"{tag}_opac"], 1e-4, "opacities")
+    assert_close_rel(dump["scales"].detach().cpu().numpy(), G[f"{tag}_dump_scales"], 1e-4, "visualization_dump scales")
+    loss = (gs.means * T("w0")).sum() + 1e4 * (gs.covariances * T("w1")).sum() + (gs.harmonics * T("w2")).sum() + \
+        (gs.opacities * T("w3")).sum()
+    loss.backward()
+    assert_close_rel(img.grad.cpu().numpy(), G[f"{tag}_gimage"], 5e-4, "d image")
+    got = m.token_stylizer.dec_blocks[3].cross_attn.projk.weight.grad
+    assert_close_rel(got.cpu().numpy(), G[f"{tag}_g_sty_projk"], 5e-4, "d token_stylizer projk")
