@@ -11,6 +11,8 @@
  *   vit_attention_fwd <- xformers.ops.memory_efficient_attention(q, k, v, scale, p=0)
  *                        call sites blocks.py:129,195 (fp32, (B,N,H,64), no mask)
  *   vit_attention_bwd <- its autograd backward
+ *   vit_linear_fwd    <- nn.Linear (+ nn.GELU / residual add) of Mlp / Attention / Block,
+ *                        blocks.py:76-82,100,131,149-152
  */
 #ifndef VIT_OPS_H
 #define VIT_OPS_H
@@ -70,6 +72,15 @@ int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, cons
 int vit_attention_bwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, const float *out,
                       const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta_ws,
                       void *stream);
+
+/*
+ * Fused fp32 Linear: out (M,N) = [residual (M,N) +] act( x (M,K) . w^T + bias ), w (N,K) row-major as
+ * nn.Linear stores it (blocks.py: qkv / proj / fc1 / fc2 / projq / projk / projv).  act: 0 identity,
+ * 1 exact (erf) GELU = nn.GELU() default (blocks.py:64).  bias, residual, pre may be NULL; `pre`
+ * receives the pre-activation (x w^T + bias) for the backward.  K % 16 == 0; all tensors contiguous.
+ */
+int vit_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre,
+                   int M, int N, int K, int act, void *stream);
 
 const char *vit_version(void);
 const char *vit_last_error(void);

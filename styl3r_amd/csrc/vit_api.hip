@@ -11,6 +11,8 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
                   hipStream_t stream);
 int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *out, const float *lse,
                   const float *dout, float *dq, float *dk, float *dv, float *delta_ws, hipStream_t stream);
+int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
+               int K, int act, hipStream_t stream);
 }  // namespace vit
 
 #define VIT_EXPORT extern "C" __attribute__((visibility("default")))
@@ -36,6 +38,12 @@ VIT_EXPORT int vit_attention_bwd(const VitAttnArgs *a, const float *q, const flo
 {
     if (!a) return VIT_EINVAL;
     return vit::attention_bwd(*a, q, k, v, out, lse, dout, dq, dk, dv, delta_ws, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out,
+                              float *pre, int M, int N, int K, int act, void *stream)
+{
+    return vit::linear_fwd(x, w, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

@@ -1,0 +1,132 @@
+// vit_gemm.hip -- fp32 Linear with fused epilogue for the ViT blocks on gfx950.
+//
+//     out = [residual +] act( x (M,K) . w^T (N,K) + bias (N) ),   act in {identity, exact GELU}
+//
+// The reference computes these layers in fp32 (TF32 on NVIDIA, blocks.py:61-82,97-134); gfx950 has no
+// reduced-precision fp32 path, so the contraction runs on the exact-f32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (157 TF peak = 1/16 of bf16).  128x128 output tile per workgroup, 4 wavefronts
+// in a 2x2 arrangement of 64x64 sub-tiles (2x2 MFMA tiles of 32x32 each), K consumed 16 at a time
+// through double-buffered LDS tiles stored K-MAJOR ([k][m] / [k][n]) so that both MFMA operand reads
+// (lane = row) are unit-stride and conflict-free; the next K-slab is prefetched into registers while the
+// current one feeds the MFMAs.  Epilogue in registers: + bias (lane = output column), exact erf GELU,
+// + residual, optional second store of the pre-activation for the backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vit_ops.h"
+
+namespace vit {
+extern thread_local hipError_t g_last_hip_error;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;   // LDT: padded row length of the k-major tiles
+
+__device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int ACT>
+__global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, const float *__restrict__ w,
+                                                const float *__restrict__ bias, const float *__restrict__ residual,
+                                                float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+{
+    __shared__ float sA[2][BK * LDT], sB[2][BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs, so give each XCD a
+    // contiguous strip of tiles that share the same rows of x (L2 reuse)
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    if (ntiles % 8 == 0) bid = (bid % 8) * (ntiles / 8) + bid / 8;
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // loader mapping: 4 lanes cover one 64-byte row segment (16 floats); 64 rows per pass, 2 passes
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = lrow + 64 * p;
+            const int gm = m0 + r, gn = n0 + r;
+            ra[p] = gm < M ? *reinterpret_cast<const float4 *>(x + (int64_t)gm * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[p] = gn < N ? *reinterpret_cast<const float4 *>(w + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = lrow + 64 * p;
+            float *a = sA[buf] + lk * LDT + r, *b = sB[buf] + lk * LDT + r;
+            a[0] = ra[p].x; a[LDT] = ra[p].y; a[2 * LDT] = ra[p].z; a[3 * LDT] = ra[p].w;
+            b[0] = rb[p].x; b[LDT] = rb[p].y; b[2 * LDT] = rb[p].z; b[3 * LDT] = rb[p].w;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const float *a = sA[buf] + half * LDT + wm * 64 + col;   // A[m = wm*64 + 32 i + col][k = 2 s + half]
+        const float *b = sB[buf] + half * LDT + wn * 64 + col;   // W[n = wn*64 + 32 j + col][k]
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float a0 = a[2 * s * LDT], a1 = a[2 * s * LDT + 32];
+            const float b0 = b[2 * s * LDT], b1 = b[2 * s * LDT + 32];
+            // D[i = m][j = n]: A-operand = x rows, B-operand = W rows -> lane = output column n (coalesced row stores)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // acc[i][j]: lane column = n = n0 + wn*64 + 32 j + col ; register r = row m = m0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
+    // -> every store instruction writes two 128-byte row segments; bias is lane-local
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + 32 * j + col;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const int64_t o = (int64_t)m * N + n;
+                float t = acc[i][j][r] + bv;
+                if (pre) pre[o] = t;
+                if (ACT == 1) t = gelu_exact(t);
+                if (residual) t += residual[o];
+                out[o] = t;
+            }
+        }
+    }
+}
+
+int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
+               int K, int act, hipStream_t stream)
+{
+    if (!x || !w || !out) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || act < 0 || act > 1) return VIT_EINVAL;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    (void)hipGetLastError();
+    if (act == 1) hipLaunchKernelGGL(k_linear<1>, dim3(tiles), dim3(256), 0, stream, x, w, bias, residual, out, pre, M, N, K);
+    else hipLaunchKernelGGL(k_linear<0>, dim3(tiles), dim3(256), 0, stream, x, w, bias, residual, out, pre, M, N, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+}  // namespace vit

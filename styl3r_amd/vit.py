@@ -17,7 +17,20 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from .vit_ops import memory_efficient_attention
+from .vit_ops import fused_linear, memory_efficient_attention
+
+# Linear layers of the blocks run on the fused fp32-MFMA kernel (bias / exact GELU / residual in the
+# epilogue); set to False to route them through torch.nn.functional.linear (hipBLASLt) instead.
+USE_FUSED_LINEAR = True
+
+
+def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+    if USE_FUSED_LINEAR and x.is_cuda and layer.in_features % 16 == 0:
+        return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu)
+    y = torch.nn.functional.linear(x, layer.weight, layer.bias)
+    if gelu:
+        y = torch.nn.functional.gelu(y)
+    return y if residual is None else residual + y
 
 
 class RopeCfg:
@@ -37,8 +50,11 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
 
-    def forward(self, x: Tensor) -> Tensor:
-        return self.fc2(self.act(self.fc1(x)))
+    def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
+            return _linear(self.fc2, _linear(self.fc1, x, gelu=True), residual=residual)
+        y = self.fc2(self.act(self.fc1(x)))
+        return y if residual is None else residual + y
 
 
 class Attention(nn.Module):
@@ -51,16 +67,16 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.rope = rope
 
-    def forward(self, x: Tensor, xpos: Tensor) -> Tensor:
+    def forward(self, x: Tensor, xpos: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         B, N, C = x.shape
-        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv = _linear(self.qkv, x).view(B, N, 3, self.num_heads, C // self.num_heads)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B,N,H,64) views, no copies
         if self.rope is not None:
             o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=xpos, kpos=xpos, rope_base=self.rope.freq,
                                            max_pos=self.rope.max_pos)
         else:
             o = memory_efficient_attention(q, k, v, scale=self.scale)
-        return self.proj(o.reshape(B, N, C))
+        return _linear(self.proj, o.reshape(B, N, C), residual=residual)
 
 
 class Block(nn.Module):
@@ -74,8 +90,8 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def forward(self, x: Tensor, xpos: Tensor) -> Tensor:
-        x = x + self.attn(self.norm1(x), xpos)
-        x = x + self.mlp(self.norm2(x))
+        x = self.attn(self.norm1(x), xpos, residual=x)        # x + attn(...): residual add in the proj epilogue
+        x = self.mlp(self.norm2(x), residual=x)
         return x
 
 
@@ -91,18 +107,19 @@ class CrossAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.rope = rope
 
-    def forward(self, query: Tensor, key: Tensor, value: Tensor, qpos: Tensor, kpos: Tensor) -> Tensor:
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, qpos: Tensor, kpos: Tensor,
+                residual: Optional[Tensor] = None) -> Tensor:
         B, Nq, C = query.shape
         H = self.num_heads
-        q = self.projq(query).view(B, Nq, H, C // H)
-        k = self.projk(key).view(B, key.shape[1], H, C // H)
-        v = self.projv(value).view(B, value.shape[1], H, C // H)
+        q = _linear(self.projq, query).view(B, Nq, H, C // H)
+        k = _linear(self.projk, key).view(B, key.shape[1], H, C // H)
+        v = _linear(self.projv, value).view(B, value.shape[1], H, C // H)
         if self.rope is not None:
             o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=qpos, kpos=kpos, rope_base=self.rope.freq,
                                            max_pos=self.rope.max_pos)
         else:
             o = memory_efficient_attention(q, k, v, scale=self.scale)
-        return self.proj(o.reshape(B, Nq, C))
+        return _linear(self.proj, o.reshape(B, Nq, C), residual=residual)
 
 
 class DecoderBlock(nn.Module):
@@ -120,10 +137,10 @@ class DecoderBlock(nn.Module):
         self.norm_y = norm_layer(dim) if norm_mem else nn.Identity()
 
     def forward(self, x: Tensor, y: Tensor, xpos: Tensor, ypos: Tensor):
-        x = x + self.attn(self.norm1(x), xpos)
+        x = self.attn(self.norm1(x), xpos, residual=x)
         y_ = self.norm_y(y)
-        x = x + self.cross_attn(self.norm2(x), y_, y_, xpos, ypos)
-        x = x + self.mlp(self.norm3(x))
+        x = self.cross_attn(self.norm2(x), y_, y_, xpos, ypos, residual=x)
+        x = self.mlp(self.norm3(x), residual=x)
         return x, y
 
 

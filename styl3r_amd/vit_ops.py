@@ -21,8 +21,8 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_api.hip"]
-EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_version", "vit_last_error")
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_api.hip"]
+EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -68,6 +68,8 @@ def load() -> C.CDLL:
     if hasattr(lib, "vit_attention_bwd"):
         lib.vit_attention_bwd.argtypes = [C.POINTER(VitAttnArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.vit_attention_bwd.restype = C.c_int
+    lib.vit_linear_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -226,3 +228,51 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
     if scale is None:
         scale = q.shape[-1] ** -0.5
     return _Attention.apply(q, k, v, float(scale), qpos, kpos, rope_base, max_pos)
+
+
+# ---------------------------------------------------------------------------
+# fused Linear (+ GELU / + residual)
+# ---------------------------------------------------------------------------
+class _FusedLinear(torch.autograd.Function):
+    """forward on the fp32-MFMA kernel; the backward GEMMs (dX = dY W, dW = dY^T X) are plain library
+    GEMMs through torch / hipBLASLt."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act):
+        _need_gpu(x, "linear")
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous().float()
+        M, K = x2.shape
+        N = weight.shape[0]
+        w = weight.contiguous().float()
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        need_pre = act == 1 and (x.requires_grad or weight.requires_grad)
+        pre = torch.empty_like(out) if need_pre else None
+        res2 = residual.reshape(-1, N).contiguous().float() if residual is not None else None
+        b = bias.contiguous().float() if bias is not None else None
+        rc = load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                   res2.data_ptr() if res2 is not None else None, out.data_ptr(),
+                                   pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
+        _check(rc, "vit_linear_fwd")
+        ctx.save_for_backward(x2, w, pre)
+        ctx.meta = (shp, bias is not None, residual is not None, act)
+        return out.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, pre = ctx.saved_tensors
+        shp, has_bias, has_res, act = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1])
+        g_res = g if has_res else None
+        if act == 1:
+            g2 = torch.ops.aten.gelu_backward(g2.contiguous(), pre, approximate="none")
+        dx = (g2 @ w).reshape(shp)
+        dw = g2.t() @ x2
+        db = g2.sum(0) if has_bias else None
+        return dx, dw, db, g_res, None
+
+
+def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+                 gelu: bool = False) -> Tensor:
+    """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd)."""
+    return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0)

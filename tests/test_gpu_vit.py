@@ -143,3 +143,30 @@ def test_blocks_match_reference_modules():
                   lambda m, i: m(i["q"], i["kv"], i["kv"], i["qpos"], i["kpos"]), ["q", "kv", "qpos", "kpos"])
     _check_module("dec", vit.DecoderBlock(128, 2, 1.0, qkv_bias=True, norm_layer=vit.LayerNorm6, rope=rope),
                   lambda m, i: m(i["x"], i["y"], i["xpos"], i["ypos"]), ["x", "y", "xpos", "ypos"])
+
+
+@pytest.mark.parametrize("M,N,K,gelu,res", [(300, 200, 64, True, False), (514, 3072, 1024, False, False),
+                                             (257, 768, 3072, False, True), (1, 9, 16, True, True), (5140, 1024, 1024, True, True)])
+def test_fused_linear_vs_fp64(M, N, K, gelu, res):
+    from styl3r_amd.vit_ops import fused_linear
+    g = torch.Generator(DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV, generator=g, requires_grad=True)
+    r = torch.randn(M, N, device=DEV, generator=g, requires_grad=True) if res else None
+    y = fused_linear(x, w, b, residual=r, gelu=gelu)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    rd = r.detach().double().requires_grad_(True) if res else None
+    ref = torch.nn.functional.linear(xd, wd, bd)
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    if res:
+        ref = ref + rd
+    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6, "fused linear fwd")
+    gy = torch.randn(M, N, device=DEV, generator=g)
+    (y * gy).sum().backward(); (ref * gy.double()).sum().backward()
+    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 1e-5, "dx")
+    assert_close_rel(w.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "dw")
+    assert_close_rel(b.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "db")
+    if res:
+        assert_close_rel(r.grad.cpu().numpy(), rd.grad.cpu().numpy(), 1e-6, "dres")
