@@ -1,0 +1,92 @@
+"""Data-parallel gradient exchange for the hot path: one process per GPU, bucketed gradient
+all-reduce over RCCL/xGMI, overlapped with the backward.
+
+The reference gets this from Lightning's `strategy="ddp_find_unused_parameters_true"`
+(src/main_style.py:104-108): torch DDP, 25 MB buckets, a per-step unused-parameter graph scan.
+Here the graph is static, so the bucket map is built once (no scan): parameters are packed in
+REVERSE registration order (= autograd readiness: DPT heads -> decoders -> encoders) into
+flat fp32 buckets that the gradients are accumulated INTO (p.grad is a view of its bucket: no
+pack/unpack copies); a bucket is reduced the moment its last gradient lands, on RCCL's own stream,
+while the backward keeps running.  xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU):
+large buckets (default 64 MiB) keep every link busy and amortise the launch latency of the collective.
+Parameters that never receive a gradient (mask_token) are reduced as zeros at `finish()`.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+from torch import nn
+
+
+class BucketedGradReducer:
+    def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20):
+        self.dist = dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
+        order = list(reversed(self.params))
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for p in order:
+            nb = p.numel() * 4
+            if cur and cur_bytes + nb > bucket_bytes:
+                self.buckets.append(self._make_bucket(cur)); cur, cur_bytes = [], 0
+            cur.append(p); cur_bytes += nb
+        if cur:
+            self.buckets.append(self._make_bucket(cur))
+        self._handles: list = []
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    @staticmethod
+    def _make_bucket(params):
+        dev, n = params[0].device, sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for p in params:
+            views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
+        return dict(params=list(params), flat=flat, views=views, pending=len(params), launched=False)
+
+    def _make_hook(self, bi):
+        def hook(p):
+            b = self.buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        b["launched"] = True
+        if self.dist is not None and self.world > 1:
+            self._handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def prepare(self):
+        """call before backward: zero the buckets and point every p.grad at its bucket slice."""
+        self._handles.clear()
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"], b["launched"] = len(b["params"]), False
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+
+    def finish(self):
+        """call after backward: reduce the buckets whose gradients never all arrived, wait, average."""
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        if self.world > 1:
+            for b in self.buckets:
+                b["flat"].mul_(1.0 / self.world)
+
+    def bucket_sizes_bytes(self) -> List[int]:
+        return [b["flat"].numel() * 4 for b in self.buckets]
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
