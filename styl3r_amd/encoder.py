@@ -90,6 +90,21 @@ class EncoderNoPoSplatTokenStyleCfg:
     stylized: bool = True
 
 
+class _PackGrad(torch.autograd.Function):
+    """Identity whose backward hands a PACKED gradient to the producing convolution.  The heads' outputs are
+    consumed through transposed views ("b d h w -> b (h w) d"), so their gradients arrive as non-contiguous
+    NHWC-like views; MIOpen sends such tensors to naive_conv_* kernels (hundreds of ms per call on gfx950,
+    profiles/r01d_train_step_kernel_stats.md) instead of its MFMA solvers."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
 # --------------------------------------------------------------------------- trunk
 class PatchEmbedDust3R(nn.Module):
     def __init__(self, img_size, patch_size=16, in_chans=3, embed_dim=768):
@@ -100,7 +115,7 @@ class PatchEmbedDust3R(nn.Module):
     def forward(self, x: Tensor):
         B, C, H, W = x.shape
         assert H % self.patch_size[0] == 0 and W % self.patch_size[1] == 0, "image size must be a multiple of the patch size"
-        x = self.proj(x)
+        x = _PackGrad.apply(self.proj(x))
         h, w = x.shape[2], x.shape[3]
         pos = torch.cartesian_prod(torch.arange(h, device=x.device), torch.arange(w, device=x.device))
         pos = pos.view(1, h * w, 2).expand(B, -1, 2).clone()
@@ -291,18 +306,19 @@ class DPTAdapter(nn.Module):
         H, W = image_size
         nh, nw = H // 16, W // 16
         layers = [tokens[h] for h in self.hooks]
-        layers = [t.transpose(1, 2).reshape(t.shape[0], t.shape[2], nh, nw) for t in layers]
+        layers = [t.transpose(1, 2).reshape(t.shape[0], t.shape[2], nh, nw).contiguous() for t in layers]
         layers = [self.act_postprocess[i](t) for i, t in enumerate(layers)]
         layers = [self.scratch.layer_rn[i](t) for i, t in enumerate(layers)]
-        p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]]
+        # (.contiguous(): MIOpen sends non-packed views -- this crop, the per-view image slice -- to naive_conv_* kernels)
+        p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]].contiguous()
         p3 = self.scratch.refinenet3(p4, layers[2])
         p2 = self.scratch.refinenet2(p3, layers[1])
         p1 = self.scratch.refinenet1(p2, layers[0])
         if self.kind == "gs":
-            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True) + self.input_merger(imgs)
+            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True) + self.input_merger(imgs.contiguous())
         elif self.kind == "sh":
             p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True)
-        return self.head(p1)
+        return _PackGrad.apply(self.head(p1))
 
 
 def reg_dense_depth_exp(xyz: Tensor) -> Tensor:
