@@ -130,6 +130,15 @@ int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means, 
                  float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau, void *stream);
 
 /*
+ * Camera set-up of `render_cuda` (cuda_splatting.py:65-88) for V views in ONE launch: the 1/near rescale
+ * of make_scale_invariant, get_fov (projection.py:247-261), get_projection_matrix (:16-43), inverse(c2w)^T
+ * and view @ proj, written as GsrView[V].  Replaces ~100 tiny device ops of the torch formulation.
+ *   c2w (V,4,4) camera-to-world, K (V,3,3) normalised intrinsics, near/far (V), bg (V,3) -- device, row-major.
+ */
+int gsr_build_views(const float *c2w, const float *K, const float *near, const float *far, const float *bg, int32_t V,
+                    int32_t scale_invariant, GsrView *out, void *stream);
+
+/*
  * Optional per-stage timing with hipEvents recorded on the caller's stream
  * between the kernels of gsr_forward / gsr_backward (bench.py's live roofline
  * measurement).  A profile holds event pairs for `max_calls` forward and

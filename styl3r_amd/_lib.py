@@ -65,7 +65,7 @@ GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7
 STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
-           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error")
+           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error", "gsr_build_views")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
           -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
 
@@ -95,6 +95,8 @@ def load() -> C.CDLL:
     lib.gsr_backward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_backward.restype = C.c_int
     lib.gsr_version.restype = C.c_char_p
+    lib.gsr_build_views.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
+    lib.gsr_build_views.restype = C.c_int
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_profile_create.argtypes = [C.c_int]
     lib.gsr_profile_create.restype = C.c_void_p

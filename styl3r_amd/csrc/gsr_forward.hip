@@ -372,6 +372,9 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (power > 0.f) continue;
                 const float alpha = fminf(0.99f, b.y * __expf(power));
+#if defined(GSR_EXP) && GSR_EXP == 3
+                atomicAdd(ws.tile_cursor + 0, 1u); if (alpha >= (1.f / 255.f)) atomicAdd(ws.tile_cursor + 1, 1u);
+#endif
                 if (alpha < (1.f / 255.f)) continue;
                 const float test_T = Tr[k] * (1.f - alpha);
                 if (test_T < 0.0001f) { done[k] = true; continue; }

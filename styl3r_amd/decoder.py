@@ -71,9 +71,27 @@ def prepare_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Ten
     return pack_views(view, full, proj_raw, extrinsics[:, :3, 3], tan_x, tan_y, background, scale)
 
 
+def build_views_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                    scale_invariant: bool) -> Tensor:
+    """Same result as `prepare_views` (to a few ulp: different 4x4 inverse / no torch intermediates) from ONE
+    kernel (`gsr_build_views`) instead of ~100 tiny device ops; the per-step default of the decoder."""
+    import ctypes as C
+    from . import _lib
+    n = extrinsics.shape[0]
+    f = lambda t: t.detach().contiguous().float()
+    e, k, nr, fr, bg = f(extrinsics), f(intrinsics), f(near), f(far), f(background)
+    out = torch.empty((n, _lib.GSR_VIEW_FLOATS), dtype=torch.float32, device=e.device)
+    rc = _lib.load().gsr_build_views(e.data_ptr(), k.data_ptr(), nr.data_ptr(), fr.data_ptr(), bg.data_ptr(), n,
+                                     1 if scale_invariant else 0, out.data_ptr(),
+                                     C.c_void_p(torch.cuda.current_stream(e.device).cuda_stream))
+    _lib.check(rc, "gsr_build_views")
+    return out
+
+
 def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
                gaussians: Gaussians, views_per_scene: int, scale_invariant: bool = True, use_sh: bool = True,
-               cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None):
+               cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None,
+               torch_view_setup: bool = False):
     """Batched counterpart of `render_cuda`: (b*v) cameras, b un-replicated Gaussian sets.
     Returns (color (b*v,3,h,w), depth (b*v,h,w))."""
     n = gaussians.harmonics.shape[-1]
@@ -82,7 +100,11 @@ def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor
     # cuda_splatting.py:118,126 passes covariances[:, triu]; the kernels read that upper triangle straight from
     # the (b,g,3,3) tensor (GSR_FLAG_COV9) and write its gradient there, so no gather / index_put kernels run.
     cov6 = gaussians.covariances
-    views = prepare_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    # cameras carry no gradient in the reference either (pose gradients flow through theta / rho)
+    if torch_view_setup or not extrinsics.is_cuda:
+        views = prepare_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    else:
+        views = build_views_hip(extrinsics, intrinsics, near, far, background_color, scale_invariant)
     colors = shs if use_sh else shs[:, :, 0, :].contiguous()
     out = rasterize_views(gaussians.means, cov6, gaussians.opacities, colors, views, image_shape, views_per_scene,
                           sh_degree=degree, use_sh=use_sh, theta=cam_rot_delta, rho=cam_trans_delta)
@@ -96,6 +118,9 @@ class DecoderSplattingHIP(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.make_scale_invariant = cfg.make_scale_invariant
+        # True: build the cameras with the reference's torch op sequence (prepare_views, bit-identical to
+        # render_cuda on the same device) instead of the single gsr_build_views kernel (a few ulp apart)
+        self.torch_view_setup = False
         self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
                              persistent=False)
 
@@ -107,7 +132,7 @@ class DecoderSplattingHIP(nn.Module):
         color, depth = render_hip(
             flat(extrinsics), flat(intrinsics), flat(near), flat(far), image_shape,
             self.background_color[None].expand(b * v, 3), gaussians, v,
-            scale_invariant=self.make_scale_invariant,
+            scale_invariant=self.make_scale_invariant, torch_view_setup=self.torch_view_setup,
             cam_rot_delta=flat(cam_rot_delta) if cam_rot_delta is not None else None,
             cam_trans_delta=flat(cam_trans_delta) if cam_trans_delta is not None else None)
         h, w = image_shape

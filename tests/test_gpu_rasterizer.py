@@ -193,6 +193,7 @@ def test_batched_decoder_matches_per_view_dropin_and_oracle():
     g = Gaussians(st("means").requires_grad_(True), st("covariances").requires_grad_(True),
                   st("harmonics").requires_grad_(True), st("opacities").requires_grad_(True))
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.2, 0.1, 0.3], True)).to(dev)
+    dec.torch_view_setup = True     # same cameras, bit for bit, as the per-view path below
     delta_r = torch.zeros(2, 3, 3, device=dev, requires_grad=True)
     delta_t = torch.zeros(2, 3, 3, device=dev, requires_grad=True)
     out = dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (64, 64),
@@ -227,6 +228,10 @@ def test_batched_decoder_matches_per_view_dropin_and_oracle():
     for a, b_, name in zip(grads, [t.grad for t in g2] + [dr2.grad, dt2.grad],
                            ["means", "cov", "sh", "opac", "theta", "rho"]):
         assert_close_rel(a.cpu().numpy(), b_.cpu().numpy(), 2e-5, f"batched vs per-view d{name}")
+    # default camera path (one gsr_build_views kernel): same image to the path's fp32 noise
+    dec.torch_view_setup = False
+    out2 = dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (64, 64))
+    assert_close_rel(out2.color.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-4, "hip view setup vs torch view setup")
 
 
 def test_full_size_workload_parity():
@@ -241,3 +246,21 @@ def test_full_size_workload_parity():
     cam = dict(H=256, W=256, tanfovx=row[51], tanfovy=row[52], view=row[0:16].reshape(4, 4), proj=row[16:32].reshape(4, 4),
                proj_raw=row[32:48].reshape(4, 4), campos=row[48:51])
     _check_forward(sc.means.numpy() * s, cov6, sc.opacities.numpy(), cam, shs=sc.harmonics.numpy().transpose(0, 2, 1))
+
+
+def test_build_views_kernel_matches_torch_view_setup():
+    """gsr_build_views (one kernel) == prepare_views (the reference's torch op sequence) to a few ulp"""
+    from styl3r_amd.decoder import build_views_hip, prepare_views
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    n = 37
+    A = torch.randn(n, 3, 3, generator=g); Q, _ = torch.linalg.qr(A)
+    ext = torch.eye(4).repeat(n, 1, 1); ext[:, :3, :3] = Q; ext[:, :3, 3] = torch.randn(n, 3, generator=g) * 2
+    K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]]).repeat(n, 1, 1) + 0.05 * torch.rand(n, 3, 3, generator=g)
+    K[:, 2] = torch.tensor([0, 0, 1.0])
+    near = 0.05 + torch.rand(n, generator=g); far = 20 + 100 * torch.rand(n, generator=g)
+    bg = torch.rand(n, 3, generator=g)
+    for si in (True, False):
+        ref = prepare_views(ext, K, near, far, bg, si).numpy()
+        got = build_views_hip(ext.to(dev), K.to(dev), near.to(dev), far.to(dev), bg.to(dev), si).cpu().numpy()
+        np.testing.assert_allclose(got[:, :57], ref[:, :57], rtol=2e-6, atol=2e-6)
