@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             const float4 b = s_q[j * 3 + 1];                // C, opacity, depth, id
             const float4 c = s_q[j * 3 + 2];                // r, g, b, quad
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
+            if (quad == 0) continue;   // footprint misses the tile: nothing to evaluate, nothing to reduce
             float s[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) s[i] = 0.f;

@@ -324,13 +324,19 @@ __device__ inline float row_allsum(float v)
 }
 __device__ inline void wave_reduce10(const float *a, float *out)
 {
-    float b[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) b[i] = swap_add32(a[i], a[i + 5]);   // lanes<32: a_i, lanes>=32: a_{i+5}
-    float c0 = swap_add16(b[0], b[1]);   // rows: a0 a1 a5 a6
-    float c1 = swap_add16(b[2], b[3]);   // rows: a2 a3 a7 a8
-    float c2 = swap_add16(b[4], 0.f);    // rows: a4 -  a9 -
-    out[0] = row_allsum(c0); out[1] = row_allsum(c1); out[2] = row_allsum(c2);
+    // level 1: five v_permlane32_swap back to back (independent registers: one pair of wait states covers all five)
+    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], y0 = a[5], y1 = a[6], y2 = a[7], y3 = a[8], y4 = a[9];
+    asm volatile("v_nop\n\tv_nop\n\t"
+                 "v_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
+                 "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4));
+    float b0 = x0 + y0, b1 = x1 + y1, b2 = x2 + y2, b3 = x3 + y3, b4 = x4 + y4;   // lanes<32: a_i, lanes>=32: a_{i+5}
+    // level 2: rows.  (b0,b1) -> a0 a1 a5 a6 ; (b2,b3) -> a2 a3 a7 a8 ; (b4,0) -> a4 - a9 -
+    float z = 0.f;
+    asm volatile("v_nop\n\tv_nop\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5"
+                 : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(z));
+    out[0] = row_allsum(b0 + b1); out[1] = row_allsum(b2 + b3); out[2] = row_allsum(b4 + z);
 }
 // which of the ten values a lane publishes after wave_reduce10: lanes 16r+s, s<3 -> value index, else -1
 __device__ inline int reduce10_slot(int lane)
