@@ -96,15 +96,18 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (!(quad & (1u << k))) continue;  // scalar branch
-                if (entry >= last[k]) continue;
+                if (!(quad & (1u << k))) continue;  // scalar branch: the only control flow of the evaluation
+                // Straight-line, predicated by `valid`: an invalid (pixel, splat) pair runs with alpha = G = 0, which
+                // leaves T unchanged, contributes exactly 0 to every sum and keeps the recurrence equivalent
+                // (accu' = la*lu + (1-la)*accu, then la = 0 makes the next step reproduce accu').
                 const float dx = a.x - fx[k], dy = a.y - fy[k];
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                if (power > 0.f) continue;
-                const float Gv = __expf(power);
-                const float alpha = fminf(0.99f, b.y * Gv);
-                if (alpha < (1.f / 255.f)) continue;
-                any = true;
+                const float Graw = __expf(fminf(power, 0.f));
+                const float araw = fminf(0.99f, b.y * Graw);
+                const bool valid = (entry < last[k]) && (power <= 0.f) && (araw >= (1.f / 255.f));
+                any |= valid;
+                const float alpha = valid ? araw : 0.f;
+                const float Gv = valid ? Graw : 0.f;
                 const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp) for both 1/(1-alpha) uses
                 Tr[k] *= inv;
                 const float w = alpha * Tr[k];
