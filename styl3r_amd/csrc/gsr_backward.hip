@@ -160,6 +160,9 @@ __device__ inline float block_sum_256(float v, float *s_tmp, int tid)
 }
 
 #pragma clang fp contract(off)
+// DEG: active SH degree 0..4, or -1 for precomputed colours.  A template parameter so that the SH tables and the
+// per-coefficient accumulators are fully unrolled register arrays (degree 0 carries none of the degree-4 baggage).
+template <int DEG>
 __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView *__restrict__ views,
                                                         const float *__restrict__ means, const float *__restrict__ cov6,
                                                         const float *__restrict__ shs, Ptrs ws,
@@ -177,13 +180,14 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
     float S0[6];
     const bool cov9 = (d.flags & GSR_FLAG_COV9) != 0;
     load_cov(cov6, sg, cov9, S0);
-    const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
+    constexpr int NC = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
     const int ncol = d.M > 0 ? 3 * d.M : 3;
     float *dsh = dL_dshs + sg * (size_t)ncol;
+    float dsh_acc[3 * NC];            // summed over the scene's views in registers, stored once
+#pragma unroll
+    for (int k = 0; k < 3 * NC; ++k) dsh_acc[k] = 0.f;
 
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dop = 0.f;
-    if (valid)
-        for (int k = 0; k < ncol; ++k) dsh[k] = 0.f;
 
     for (int j = 0; j < d.Vt; ++j) {
         const int v = b * d.Vt + j;
@@ -210,34 +214,37 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
             float dm[3] = {0.f, 0.f, 0.f};
 
             // ---- colour ----
-            if (d.M > 0) {
+            if (DEG >= 0) {
                 float ddx = m[0] - vw.campos[0], ddy = m[1] - vw.campos[1], ddz = m[2] - vw.campos[2];
                 float len = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
                 float x = ddx / len, y = ddy / len, z = ddz / len;
-                float bs[25], bx[25], by[25], bz[25];
-                sh_basis(d.sh_degree, x, y, z, bs);
-                if (d.sh_degree > 0) sh_basis_grad(d.sh_degree, x, y, z, bx, by, bz);
-                const float *sh = shs + sg * 3 * (size_t)d.M;
-                float dLdx = 0.f, dLdy = 0.f, dLdz = 0.f;
-                for (int c = 0; c < 3; ++c) {
-                    float gcol = ((aux >> c) & 1u) ? 0.f : gr[GR_RGB + c];
-                    for (int k = 0; k < ncoef; ++k) {
-                        dsh[3 * k + c] += bs[k] * gcol;
-                        if (d.sh_degree > 0) {
-                            dLdx += bx[k] * sh[3 * k + c] * gcol;
-                            dLdy += by[k] * sh[3 * k + c] * gcol;
-                            dLdz += bz[k] * sh[3 * k + c] * gcol;
-                        }
+                float bs[NC];
+                sh_basis(DEG < 0 ? 0 : DEG, x, y, z, bs);
+                float gcol[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gcol[c] = ((aux >> c) & 1u) ? 0.f : gr[GR_RGB + c];
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dsh_acc[3 * k + c] += bs[k] * gcol[c];
+                if (DEG > 0) {
+                    float bx[NC], by[NC], bz[NC];
+                    sh_basis_grad(DEG < 0 ? 0 : DEG, x, y, z, bx, by, bz);
+                    const float *sh = shs + sg * 3 * (size_t)d.M;
+                    float dLdx = 0.f, dLdy = 0.f, dLdz = 0.f;
+#pragma unroll
+                    for (int k = 1; k < NC; ++k) {
+                        const float t = sh[3 * k] * gcol[0] + sh[3 * k + 1] * gcol[1] + sh[3 * k + 2] * gcol[2];
+                        dLdx += bx[k] * t; dLdy += by[k] * t; dLdz += bz[k] * t;
                     }
-                }
-                if (d.sh_degree > 0) {
                     float dot = x * dLdx + y * dLdy + z * dLdz;
                     dm[0] += (dLdx - x * dot) / len;
                     dm[1] += (dLdy - y * dot) / len;
                     dm[2] += (dLdz - z * dot) / len;
                 }
             } else {
-                for (int c = 0; c < 3; ++c) dsh[c] += gr[GR_RGB + c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dsh_acc[c] += gr[GR_RGB + c];
             }
 
             // ---- conic -> cov2D ----
@@ -373,6 +380,9 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
             for (int k = 0; k < 6; ++k) dL_dcov6[6 * sg + k] = dcov[k];
         }
         dL_dopac[sg] = dop;
+#pragma unroll
+        for (int k = 0; k < 3 * NC; ++k) dsh[k] = dsh_acc[k];
+        for (int k = 3 * NC; k < ncol; ++k) dsh[k] = 0.f;      // coefficients above the active degree
     }
 }
 #pragma clang fp contract(fast)
@@ -401,8 +411,18 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
     hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
     tm.end(GSR_STAGE_COMPOSITE_BWD); tm.begin(GSR_STAGE_PREPROCESS_BWD);
-    hipLaunchKernelGGL(k_preprocess_bwd, dim3((d.G + 255) / 256, d.B), dim3(256), 0, stream, d, views, means, cov6, shs,
-                       ws, dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau);
+    const dim3 gG((d.G + 255) / 256, d.B);
+#define GSR_LAUNCH_K7(DEG) hipLaunchKernelGGL(k_preprocess_bwd<DEG>, gG, dim3(256), 0, stream, d, views, means, cov6, shs, ws, \
+                                              dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau)
+    switch (d.M > 0 ? d.sh_degree : -1) {
+        case -1: GSR_LAUNCH_K7(-1); break;
+        case 0: GSR_LAUNCH_K7(0); break;
+        case 1: GSR_LAUNCH_K7(1); break;
+        case 2: GSR_LAUNCH_K7(2); break;
+        case 3: GSR_LAUNCH_K7(3); break;
+        default: GSR_LAUNCH_K7(4); break;
+    }
+#undef GSR_LAUNCH_K7
     tm.end(GSR_STAGE_PREPROCESS_BWD);
     return launch_status();
 }

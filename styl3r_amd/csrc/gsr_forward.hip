@@ -27,6 +27,7 @@ namespace gsr {
 
 // ------------------------------------------------------------------ K1
 #pragma clang fp contract(off)
+template <int DEG>   // active SH degree 0..4, -1 = precomputed colours: the SH table is an unrolled register array
 __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__restrict__ views,
                                                     const float *__restrict__ means, const float *__restrict__ cov6,
                                                     const float *__restrict__ opac, const float *__restrict__ shs,
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
     load_cov(cov6, sg, (d.flags & GSR_FLAG_COV9) != 0, S0);
     const float op = opac[sg];
     const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
-    const int ncoef = (d.sh_degree + 1) * (d.sh_degree + 1);
+    constexpr int NC = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
 
     for (int j = 0; j < d.Vt; ++j) {
         const int v = b * d.Vt + j;
@@ -84,18 +85,19 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
             }
         }
         if (ok) {
-            if (d.M > 0) {
+            if (DEG >= 0) {
                 float dx = m[0] - vw.campos[0], dy = m[1] - vw.campos[1], dz = m[2] - vw.campos[2];
                 float len = sqrtf(dx * dx + dy * dy + dz * dz);
                 float x = dx / len, y = dy / len, z = dz / len;
-                float bs[25];
-                sh_basis(d.sh_degree, x, y, z, bs);
+                float bs[NC];
+                sh_basis(DEG < 0 ? 0 : DEG, x, y, z, bs);
                 const float *sh = shs + sg * 3 * (size_t)d.M;
                 float col[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     float acc = bs[0] * sh[c];
-                    for (int k = 1; k < ncoef; ++k) acc = acc + bs[k] * sh[3 * k + c];
+#pragma unroll
+                    for (int k = 1; k < NC; ++k) acc = acc + bs[k] * sh[3 * k + c];
                     acc = acc + 0.5f;
                     if (acc < 0.f) clampbits |= (1u << c);
                     col[c] = fmaxf(acc, 0.f);
@@ -481,7 +483,16 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
 
     const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
     tm.begin(GSR_STAGE_PREPROCESS);
-    hipLaunchKernelGGL(k_preprocess, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii);
+#define GSR_LAUNCH_K1(DEG) hipLaunchKernelGGL(k_preprocess<DEG>, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii)
+    switch (d.M > 0 ? d.sh_degree : -1) {
+        case -1: GSR_LAUNCH_K1(-1); break;
+        case 0: GSR_LAUNCH_K1(0); break;
+        case 1: GSR_LAUNCH_K1(1); break;
+        case 2: GSR_LAUNCH_K1(2); break;
+        case 3: GSR_LAUNCH_K1(3); break;
+        default: GSR_LAUNCH_K1(4); break;
+    }
+#undef GSR_LAUNCH_K1
     tm.end(GSR_STAGE_PREPROCESS); tm.begin(GSR_STAGE_SCAN);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status);
     tm.end(GSR_STAGE_SCAN); tm.begin(GSR_STAGE_SCATTER);

@@ -127,7 +127,7 @@ def test_capacity_overflow_retry():
         rz._CAP_HINT.clear(); rz._CAP_HINT.update(old)
 
 
-def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), sh_degree=0, pose=False, seed=0):
+def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), sh_degree=0, pose=False, seed=0, f64_rel=2e-4):
     dev = torch.device("cuda:0")
     theta = torch.zeros(3, device=dev, requires_grad=True) if pose else None
     rho = torch.zeros(3, device=dev, requires_grad=True) if pose else None
@@ -150,7 +150,7 @@ def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0),
         assert np.isfinite(v).all(), k
         # the fp32 oracle restates the GPU arithmetic; the fp64 oracle is the gradient authority
         assert_close_rel(v, res["f32"][k], 1e-4, f"d{k} vs f32 oracle")
-        assert_close_rel(v, res["f64"][k], 2e-4, f"d{k} vs f64 oracle")
+        assert_close_rel(v, res["f64"][k], f64_rel, f"d{k} vs f64 oracle")
     if pose:
         assert_close_rel(rho.grad.cpu().numpy(), res["f64"]["rho"], 2e-4, "d rho")
         assert_close_rel(theta.grad.cpu().numpy(), res["f64"]["theta"], 2e-4, "d theta")
@@ -264,3 +264,22 @@ def test_build_views_kernel_matches_torch_view_setup():
         ref = prepare_views(ext, K, near, far, bg, si).numpy()
         got = build_views_hip(ext.to(dev), K.to(dev), near.to(dev), far.to(dev), bg.to(dev), si).cpu().numpy()
         np.testing.assert_allclose(got[:, :57], ref[:, :57], rtol=2e-6, atol=2e-6)
+
+
+def test_c5_stress_shapes_parity():
+    """BASELINE config 5 shapes: 512x512 (1024 tiles), sh_degree 4 (d_sh = 25), 4 context views' worth of Gaussians
+    subsampled to 4 x 128 x 128 = 65 536 so the oracle finishes in seconds; one view, forward + backward."""
+    from styl3r_amd.decoder import prepare_views
+    from styl3r_amd.scenes import make_scene
+    sc = make_scene(n_ctx=4, grid_hw=(128, 128), n_views=2, image_hw=(512, 512), sh_degree=4, seed=77)
+    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(2, 3), True).numpy()
+    row = views[0]; s = np.float32(row[56])
+    cov = sc.covariances.numpy()
+    cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1) * (s * s)
+    cam = dict(H=512, W=512, tanfovx=row[51], tanfovy=row[52], view=row[0:16].reshape(4, 4), proj=row[16:32].reshape(4, 4),
+               proj_raw=row[32:48].reshape(4, 4), campos=row[48:51])
+    means = sc.means.numpy() * s
+    shs = sc.harmonics.numpy().transpose(0, 2, 1)
+    _check_forward(means, cov6, sc.opacities.numpy(), cam, shs=shs, sh_degree=4)
+    # fp32 itself (GPU and the fp32 oracle alike) sits ~5e-4 from fp64 on this 512^2 / degree-4 case
+    _check_backward(means[::8], cov6[::8], sc.opacities.numpy()[::8], cam, shs=shs[::8], sh_degree=4, f64_rel=2e-3)
