@@ -19,7 +19,10 @@ namespace vit {
 extern thread_local hipError_t g_last_hip_error;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;   // LDT: padded row length of the k-major tiles
+#ifndef VIT_BK
+#define VIT_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = VIT_BK, LDT = 132;   // LDT: padded row length of the k-major tiles
 
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -41,13 +44,14 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // loader mapping: 4 lanes cover one 64-byte row segment (16 floats); 64 rows per pass, 2 passes
-    const int lrow = tid >> 2, lk = (tid & 3) * 4;
-    float4 ra[2], rb[2];
+    // loader mapping: BK/4 lanes cover one row segment of BK floats; 1024/BK rows per pass, BM*BK/1024 passes
+    constexpr int LPR = BK / 4, RPP = 256 / LPR, NP = BM / RPP;
+    const int lrow = tid / LPR, lk = (tid % LPR) * 4;
+    float4 ra[NP], rb[NP];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = lrow + 64 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int r = lrow + RPP * p;
             const int gm = m0 + r, gn = n0 + r;
             ra[p] = gm < M ? *reinterpret_cast<const float4 *>(x + (int64_t)gm * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
             rb[p] = gn < N ? *reinterpret_cast<const float4 *>(w + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -55,8 +59,8 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int r = lrow + 64 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int r = lrow + RPP * p;
             float *a = sA[buf] + lk * LDT + r, *b = sB[buf] + lk * LDT + r;
             a[0] = ra[p].x; a[LDT] = ra[p].y; a[2 * LDT] = ra[p].z; a[3 * LDT] = ra[p].w;
             b[0] = rb[p].x; b[LDT] = rb[p].y; b[2 * LDT] = rb[p].z; b[3 * LDT] = rb[p].w;
@@ -78,15 +82,21 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
         if (kt + 1 < nk) gload((kt + 1) * BK);
         const float *a = sA[buf] + half * LDT + wm * 64 + col;   // A[m = wm*64 + 32 i + col][k = 2 s + half]
         const float *b = sB[buf] + half * LDT + wn * 64 + col;   // W[n = wn*64 + 32 j + col][k]
+        // fragment reads run one k-step ahead of the MFMAs that consume them
+        float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            const float a0 = a[2 * s * LDT], a1 = a[2 * s * LDT + 32];
-            const float b0 = b[2 * s * LDT], b1 = b[2 * s * LDT + 32];
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (s + 1 < BK / 2) {
+                na0 = a[2 * (s + 1) * LDT]; na1 = a[2 * (s + 1) * LDT + 32];
+                nb0 = b[2 * (s + 1) * LDT]; nb1 = b[2 * (s + 1) * LDT + 32];
+            }
             // D[i = m][j = n]: A-operand = x rows, B-operand = W rows -> lane = output column n (coalesced row stores)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();

@@ -19,7 +19,11 @@ from styl3r_amd.train import TrainStep
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
+ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
 args = ap.parse_args()
+if args.torch_linear:
+    from styl3r_amd import vit as _vit
+    _vit.USE_FUSED_LINEAR = False
 rank, local_rank, world = dist_utils.env_world()
 torch.cuda.set_device(local_rank); dev = torch.device("cuda", local_rank)
 dist = dist_utils.init_distributed("nccl", dev)
