@@ -1,0 +1,130 @@
+"""Loss consumers of the rendered RGB: same interface `loss(prediction, batch, gaussians, step)`.
+
+Mirrors
+  * `LossMse`        src/loss/loss_mse.py:22-31
+  * `LossStyle`      src/loss/loss_style.py:25-79   (VGG19 relu1_1 / 2_1 / 3_1 / 4_1 mean-std style + content)
+  * `IdentityLoss`   src/loss/loss_identity.py:13-52
+  * `VGGEncoder`, `calc_mean_std`   src/test/vgg_model.py:19-28,79-98
+torchvision is not installed and the ImageNet VGG19 weights cannot be downloaded: `VGGEncoder` rebuilds the
+`vgg19().features[:21]` stack with torchvision's parameter names (`N.weight`, N in 0,2,5,7,10,12,14,16,19), so
+`load_vgg19_features(state_dict)` accepts the stock `vgg19-dcbb9e9d.pth` when it is available; until then the
+weights are random and only the arithmetic is testable.  LPIPS (loss_lpips.py) needs its own learned weights too
+and is not built.  The convolutions run on MIOpen in fp32.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+_VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512]   # features[:21] ends after relu4_1
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def calc_mean_std(x: Tensor, eps: float = 1e-8):
+    """channel-wise instance mean / (unbiased) std over the flattened spatial dims -> (N, C, 1) each."""
+    f = x.flatten(2)
+    return f.mean(dim=-1, keepdim=True), f.std(dim=-1, keepdim=True) + eps
+
+
+class VGGEncoder(nn.Module):
+    """h1..h4 = relu1_1, relu2_1, relu3_1, relu4_1 of VGG19 (slices [:2], [2:7], [7:12], [12:21])."""
+
+    def __init__(self):
+        super().__init__()
+        layers, c_in = [], 3
+        for v in _VGG19_CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(c_in, v, 3, padding=1), nn.ReLU(inplace=False)]
+                c_in = v
+        self.features = nn.Sequential(*layers)
+        assert len(self.features) == 21
+        self.requires_grad_(False)
+
+    def load_vgg19_features(self, state_dict: dict):
+        """accepts torchvision's vgg19 state dict (`features.N.*`) or the bare `features` dict (`N.*`)."""
+        sd = {k[len("features."):] if k.startswith("features.") else k: v for k, v in state_dict.items()}
+        return self.features.load_state_dict({k: v for k, v in sd.items() if int(k.split(".")[0]) < 21}, strict=True)
+
+    def forward(self, images: Tensor, output_last_feature: bool = False):
+        h1 = self.features[:2](images)
+        h2 = self.features[2:7](h1)
+        h3 = self.features[7:12](h2)
+        h4 = self.features[12:21](h3)
+        return h4 if output_last_feature else (h1, h2, h3, h4)
+
+
+def _imagenet_normalize(x: Tensor) -> Tensor:
+    mean = torch.tensor(IMAGENET_MEAN, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=x.device, dtype=x.dtype).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+@dataclass
+class LossMseCfg:
+    weight: float = 1.0
+
+
+class LossMse(nn.Module):
+    def __init__(self, cfg: LossMseCfg = LossMseCfg()):
+        super().__init__()
+        self.cfg = cfg
+
+    def forward(self, prediction, batch, gaussians=None, global_step: int = 0) -> Tensor:
+        delta = prediction.color - batch["target"]["image"]
+        return self.cfg.weight * (delta ** 2).mean()
+
+
+@dataclass
+class LossStyleCfg:
+    style_weight: float = 10.0
+
+
+class LossStyle(nn.Module):
+    def __init__(self, cfg: LossStyleCfg = LossStyleCfg(), vgg: VGGEncoder | None = None):
+        super().__init__()
+        self.cfg = cfg
+        self.vgg = vgg or VGGEncoder()
+
+    def forward(self, prediction, batch, gaussians=None, global_step: int = 0) -> Tensor:
+        b, v = batch["target"]["image"].shape[:2]
+        flat = lambda t: t.reshape(b * v, *t.shape[2:])
+        target = _imagenet_normalize(flat(batch["target"]["image"]))
+        pred = _imagenet_normalize(flat(prediction.color))
+        style = _imagenet_normalize(batch["style"]["image"])
+        style = style[:, None].expand(b, v, *style.shape[1:]).reshape(b * v, *style.shape[1:])
+        fp, ft, fs = self.vgg(pred), self.vgg(target), self.vgg(style)
+        content = F.mse_loss(fp[-2], ft[-2]) + F.mse_loss(fp[-1], ft[-1])
+        style_loss = 0
+        for a, s in zip(fp, fs):
+            am, astd = calc_mean_std(a)
+            sm, sstd = calc_mean_std(s)
+            style_loss = style_loss + F.mse_loss(am, sm) + F.mse_loss(astd, sstd)
+        return content + self.cfg.style_weight * style_loss
+
+
+class IdentityLoss(nn.Module):
+    def __init__(self, weight_1: float = 70, weight_2: float = 1, vgg: VGGEncoder | None = None):
+        super().__init__()
+        self.weight_1, self.weight_2 = weight_1, weight_2
+        self.vgg = vgg or VGGEncoder()
+
+    def forward(self, prediction, batch, gaussians=None, global_step: int = 0) -> Tensor:
+        b, v = batch["target"]["image"].shape[:2]
+        target = batch["target"]["image"].reshape(b * v, *batch["target"]["image"].shape[2:])
+        pred = prediction.color.reshape(b * v, *prediction.color.shape[2:])
+        l1 = F.mse_loss(pred, target)
+        fp, ft = self.vgg(_imagenet_normalize(pred)), self.vgg(_imagenet_normalize(target))
+        l2 = sum(F.mse_loss(a, t) for a, t in zip(fp, ft))
+        return l1 * self.weight_1 + l2 * self.weight_2
+
+
+def compute_psnr(ground_truth: Tensor, predicted: Tensor) -> Tensor:
+    """src/evaluation/metrics.py:11-20 (per image, inputs in [0,1])."""
+    mse = ((ground_truth.clip(0, 1) - predicted.clip(0, 1)) ** 2).flatten(1).mean(dim=1)
+    return -10 * mse.log10()
