@@ -96,3 +96,30 @@ def test_view_setup_matches_reference_render_cuda(tag, scale_inv):
         assert np.array_equal(GOLD[f"{tag}_in_sh"].transpose(0, 2, 1), GOLD[p + "shs"])
         assert np.array_equal(GOLD[f"{tag}_in_opac"][:, None], GOLD[p + "opacities"])
         assert int(GOLD[p + "sh_degree"]) == 1
+
+
+def test_vit_library_exports_every_declared_symbol():
+    from styl3r_amd import vit_ops
+    vit_ops.build_library()
+    lib = vit_ops.load()
+    header = (ROOT / "include/vit_ops.h").read_text()
+    declared = set(re.findall(r"\b(vit_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(vit_ops.EXPORTS), declared ^ set(vit_ops.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vit_version().decode().startswith("vit-hip gfx950")
+    # argument validation happens before any launch (no GPU needed)
+    assert lib.vit_rope2d(None, None, None, None, 1, 1, 1, 64, 4, 0, 0, 0, 1.0, None) == -1
+    assert lib.vit_linear_fwd(None, None, None, None, None, None, 1, 1, 16, 0, None) == -1
+    a = vit_ops.VitAttnArgs(); a.B = a.H = a.Nq = a.Nk = 1
+    assert lib.vit_attention_fwd(C.byref(a), None, None, None, None, None, None) == -1
+
+
+def test_vit_ops_reject_cpu_tensors():
+    from styl3r_amd import vit_ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vit_ops.memory_efficient_attention(torch.zeros(1, 2, 1, 64), torch.zeros(1, 2, 1, 64), torch.zeros(1, 2, 1, 64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vit_ops.RoPE2D()(torch.zeros(1, 1, 2, 64), torch.zeros(1, 2, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vit_ops.fused_linear(torch.zeros(2, 16), torch.zeros(4, 16))
