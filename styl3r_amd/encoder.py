@@ -343,6 +343,16 @@ class PixelwiseTaskWithDPT(nn.Module):
         return out
 
 
+def landscape_mean_head(head, tokens, h: int, w: int) -> Tensor:
+    """`transpose_to_landscape(head, activate=True)` (croco/misc.py:71-111) as it behaves with PatchEmbedDust3R:
+    a landscape / square batch goes straight through; for a portrait batch the wrapper calls the head with the true
+    (h, w) and then TRANSPOSES the result, so the points are flattened in transposed pixel order (the wrapper was
+    written for ManyAR_PatchEmbed, which feeds portrait images transposed).  Styl3R's data is square or landscape;
+    the portrait branch is mirrored only so that results stay identical to the reference on any input."""
+    pts = head(tokens, (h, w))["pts3d"]
+    return pts if w >= h else pts.swapaxes(1, 2)
+
+
 def head_factory(head_type, output_mode, net, has_conf=False, out_nchan=3):
     """heads/__init__.py:13-27 (the variants the style encoders use)."""
     assert not has_conf
@@ -443,7 +453,7 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
             pts, params, appearance = [], [], []
             for i in range(v):
                 head = self.downstream_head1 if i == 0 else self.downstream_head2
-                pts.append(head([t[:, i].float() for t in dec_feat], (h, w))["pts3d"])
+                pts.append(landscape_mean_head(head, [t[:, i].float() for t in dec_feat], h, w))
             for i in range(v):
                 head = self.gaussian_param_head if i == 0 else self.gaussian_param_head2
                 out = head([t[:, i].float() for t in dec_feat], (h, w), images[:, i, :3])
@@ -482,7 +492,73 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         return data_shim
 
 
-ENCODERS = {"noposplat_multi_token_style": EncoderNoPoSplatMultiTokenStyle}
+@dataclass
+class EncoderNoPoSplatCfg:
+    """encoder_noposplat.py:41-57 (the non-style variant of config/main.yaml and re10k_dl3dv_512x512.yaml)."""
+    name: str = "noposplat_multi"
+    d_feature: int = 128
+    num_monocular_samples: int = 32
+    backbone: BackboneCrocoCfg = field(default_factory=BackboneCrocoCfg)
+    gaussian_adapter: GaussianAdapterCfg = field(default_factory=GaussianAdapterCfg)
+    opacity_mapping: OpacityMappingCfg = field(default_factory=OpacityMappingCfg)
+    apply_bounds_shim: bool = True
+    gaussians_per_pixel: int = 1
+    num_surfaces: int = 1
+    gs_params_head_type: str = "dpt_gs"
+    input_mean: tuple = (0.5, 0.5, 0.5)
+    input_std: tuple = (0.5, 0.5, 0.5)
+    pretrained_weights: str = ""
+    pose_free: bool = True
+
+
+class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
+    """`EncoderNoPoSplatMulti` / `EncoderNoPoSplat` (encoder_noposplat_multi.py:125-215, encoder_noposplat.py:139-235):
+    no style branch, ONE dpt_gs head per view group emits all 1 + 7 + 3 d_sh raw channels, and the call signature
+    has no `style` argument (driven by src/main.py / ModelWrapper).  The 2-view `noposplat` encoder is the v = 2 case
+    of the same computation (its AsymmetricCroCo backbone has the identical parameter layout)."""
+
+    def __init__(self, cfg: EncoderNoPoSplatCfg, trunk_params: Optional[dict] = None):
+        nn.Module.__init__(self)
+        self.cfg = cfg
+        assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
+        self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
+        self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
+        self.patch_size = 16
+        self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
+        self.downstream_head1 = head_factory("dpt", "pts3d", self.backbone)
+        self.downstream_head2 = head_factory("dpt", "pts3d", self.backbone)
+        self.gaussian_param_head = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+        self.gaussian_param_head2 = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+
+    def forward(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None) -> Gaussians:
+        b, v, _, h, w = context["image"].shape
+        _, _, dec_feat, _, images = self.backbone(context)
+        with torch.autocast("cuda", enabled=False):
+            pts, params = [], []
+            for i in range(v):
+                head = self.downstream_head1 if i == 0 else self.downstream_head2
+                pts.append(landscape_mean_head(head, [t[:, i].float() for t in dec_feat], h, w))
+            for i in range(v):
+                head = self.gaussian_param_head if i == 0 else self.gaussian_param_head2
+                params.append(head([t[:, i].float() for t in dec_feat], (h, w), images[:, i, :3]).flatten(2).transpose(1, 2))
+        pts_all = torch.stack(pts, dim=1).reshape(b, v, h * w, 1, 3)
+        depths = pts_all[..., -1].unsqueeze(-1)
+        raw = torch.stack(params, dim=1).reshape(b, v, h * w, 1, -1)
+        densities = raw[..., 0].sigmoid().unsqueeze(-1)
+        g = self.gaussian_adapter(pts_all.unsqueeze(-2), depths, self.map_pdf_to_opacity(densities, global_step),
+                                  raw[..., 1:].unsqueeze(-2))
+        if visualization_dump is not None:
+            visualization_dump["depth"] = depths.reshape(b, v, h, w, 1, 1)
+            visualization_dump["scales"] = g.scales.reshape(b, -1, 3)
+            visualization_dump["rotations"] = g.rotations.reshape(b, -1, 4)
+            visualization_dump["means"] = g.means.reshape(b, v, h, w, 1, 3)
+            visualization_dump["opacities"] = g.opacities.reshape(b, v, h, w, 1, 1)
+        return Gaussians(g.means.reshape(b, -1, 3), g.covariances.reshape(b, -1, 3, 3),
+                         g.harmonics.reshape(b, -1, 3, self.gaussian_adapter.d_sh), g.opacities.reshape(b, -1))
+
+
+ENCODERS = {"noposplat_multi_token_style": EncoderNoPoSplatMultiTokenStyle, "noposplat_multi": EncoderNoPoSplatMulti,
+            "noposplat": EncoderNoPoSplatMulti}
 
 
 def get_encoder(cfg: EncoderNoPoSplatTokenStyleCfg):

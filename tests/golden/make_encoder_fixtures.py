@@ -95,5 +95,30 @@ for tag, sh_degree in (("sh0", 0), ("sh1", 1)):
     # one parameter gradient deep in the stylizer (reaches it only through the SH head)
     out[f"{tag}_g_sty_projk"] = model.token_stylizer.dec_blocks[3].cross_attn.projk.weight.grad.numpy()
     print(tag, "params", int(out[f"{tag}_nparams"]), "means", gs.means.shape, float(gs.means.abs().mean()))
+# ---- non-style variant: EncoderNoPoSplat on the 2-view AsymmetricCroCo backbone (config 5's encoder; the reference's
+# EncoderNoPoSplatMulti no longer runs against its own backbone, which now returns five values), sh_degree 1 ----------
+enp = importlib.import_module("src.model.encoder.encoder_noposplat")
+bc.croco_params["ViTLarge_BaseDecoder"] = dict(TINY)
+cfg = enp.EncoderNoPoSplatCfg(
+    name="noposplat", d_feature=128, num_monocular_samples=32,
+    backbone=bc.BackboneCrocoCfg(name="croco", model="ViTLarge_BaseDecoder", patch_embed_cls="PatchEmbedDust3R",
+                                 asymmetry_decoder=True, intrinsics_embed_loc="encoder", intrinsics_embed_degree=4,
+                                 intrinsics_embed_type="token"),
+    visualizer=viz.EncoderVisualizerEpipolarCfg(8, 256, False), gaussian_adapter=ga.GaussianAdapterCfg(0.5, 15.0, 1),
+    apply_bounds_shim=True, opacity_mapping=enp.OpacityMappingCfg(0.0, 0.0, 1), gaussians_per_pixel=1, num_surfaces=1,
+    gs_params_head_type="dpt_gs")
+model = enp.EncoderNoPoSplat(cfg).eval()
+deterministic_init_(model)
+g = torch.Generator().manual_seed(23)
+img = (torch.rand(1, 2, 3, 48, 32, generator=g) * 2 - 1).requires_grad_(True)
+K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]]).repeat(1, 2, 1, 1) + 0.01 * torch.rand(1, 2, 3, 3, generator=g)
+gs = model(dict(image=img, intrinsics=K), global_step=0)
+w = [torch.randn(t.shape, generator=g) for t in (gs.means, gs.covariances, gs.harmonics, gs.opacities)]
+((gs.means * w[0]).sum() + 1e4 * (gs.covariances * w[1]).sum() + (gs.harmonics * w[2]).sum() + (gs.opacities * w[3]).sum()).backward()
+out.update(np_image=img.detach().numpy(), np_intrinsics=K.numpy(), np_means=gs.means.detach().numpy(), np_cov=gs.covariances.detach().numpy(),
+           np_sh=gs.harmonics.detach().numpy(), np_opac=gs.opacities.detach().numpy(), np_gimage=img.grad.numpy(),
+           np_w0=w[0].numpy(), np_w1=w[1].numpy(), np_w2=w[2].numpy(), np_w3=w[3].numpy(),
+           np_keys=np.array(sorted(model.state_dict().keys())), np_nparams=np.array(sum(p.numel() for p in model.parameters())))
+print("noposplat params", int(out["np_nparams"]), gs.means.shape)
 np.savez_compressed(ROOT / "tests/golden/encoder_tiny.npz", **out)
 print("wrote", len(out))

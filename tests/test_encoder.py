@@ -68,3 +68,33 @@ def test_encoder_forward_backward_matches_reference(tag, sh_degree):
     assert_close_rel(img.grad.cpu().numpy(), G[f"{tag}_gimage"], 2e-3, "d image")
     got = m.token_stylizer.dec_blocks[3].cross_attn.projk.weight.grad
     assert_close_rel(got.cpu().numpy(), G[f"{tag}_g_sty_projk"], 2e-3, "d token_stylizer projk")
+
+
+def _build_noposplat():
+    from styl3r_amd.encoder import EncoderNoPoSplatCfg, EncoderNoPoSplatMulti, GaussianAdapterCfg
+    return EncoderNoPoSplatMulti(EncoderNoPoSplatCfg(gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 1)), trunk_params=TINY).eval()
+
+
+def test_noposplat_variant_keys_match_reference():
+    m = _build_noposplat()
+    assert sorted(m.state_dict().keys()) == list(G["np_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(G["np_nparams"])
+    from styl3r_amd.encoder import ENCODERS
+    assert ENCODERS["noposplat"] is ENCODERS["noposplat_multi"]
+
+
+@pytest.mark.gpu
+def test_noposplat_variant_matches_reference():
+    """the non-style encoder of BASELINE config 5 (`forward(context, global_step, visualization_dump)`, 83-channel gs head)"""
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(_build_noposplat()).to(dev)
+    T = lambda k: torch.tensor(G[f"np_{k}"], device=dev)
+    img = T("image").requires_grad_(True)
+    gs = m(dict(image=img, intrinsics=T("intrinsics")), global_step=0)
+    assert gs.harmonics.shape == (1, 2 * 48 * 32, 3, 4)
+    for name, t in (("means", gs.means), ("cov", gs.covariances), ("sh", gs.harmonics), ("opac", gs.opacities)):
+        assert_close_rel(t.detach().cpu().numpy(), G[f"np_{name}"], 1e-4, name)
+    ((gs.means * T("w0")).sum() + 1e4 * (gs.covariances * T("w1")).sum() + (gs.harmonics * T("w2")).sum() +
+     (gs.opacities * T("w3")).sum()).backward()
+    assert_close_rel(img.grad.cpu().numpy(), G["np_gimage"], 2e-3, "d image")
