@@ -111,6 +111,38 @@ def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor
     return out.image, out.depth
 
 
+def render_hip_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor, image_shape,
+                            background_color: Tensor, gaussians: Gaussians, views_per_scene: int,
+                            fov_degrees: float = 0.1, use_sh: bool = True, dump: Optional[dict] = None) -> Tensor:
+    """`render_cuda_orthographic` (cuda_splatting.py:136-227, validation visualisations): a fake orthographic
+    projection = camera moved back along -z with a tiny field of view.  (n,4,4) c2w, (n,) width/height/near/far in
+    world units -> colour (n,3,h,w)."""
+    n_coef = gaussians.harmonics.shape[-1]
+    degree = isqrt(n_coef) - 1
+    shs = gaussians.harmonics.permute(0, 1, 3, 2).contiguous()
+    dev = extrinsics.device
+    fov_x = torch.tensor(fov_degrees, device=dev).deg2rad()
+    tan_fov_x = (0.5 * fov_x).tan()
+    distance_to_near = (0.5 * width) / tan_fov_x
+    tan_fov_y = 0.5 * height / distance_to_near
+    fov_y = (2 * tan_fov_y).atan()
+    near = near + distance_to_near
+    far = far + distance_to_near
+    move_back = torch.eye(4, dtype=torch.float32, device=dev)[None].repeat(extrinsics.shape[0], 1, 1)
+    move_back[:, 2, 3] = -distance_to_near
+    extrinsics = extrinsics @ move_back
+    if dump is not None:
+        dump.update(extrinsics=extrinsics, fov_x=fov_x, fov_y=fov_y, near=near, far=far)
+    b = extrinsics.shape[0]
+    proj_raw = get_projection_matrix(near, far, fov_x.expand(b), fov_y).transpose(1, 2)
+    view = extrinsics.inverse().transpose(1, 2)
+    views = pack_views(view, view @ proj_raw, proj_raw, extrinsics[:, :3, 3], tan_fov_x.expand(b), tan_fov_y, background_color)
+    colors = shs if use_sh else shs[:, :, 0, :].contiguous()
+    out = rasterize_views(gaussians.means, gaussians.covariances, gaussians.opacities, colors, views, image_shape,
+                          views_per_scene, sh_degree=degree, use_sh=use_sh)
+    return out.image
+
+
 class DecoderSplattingHIP(nn.Module):
     """Same constructor cfg / forward signature / DecoderOutput as DecoderSplattingCUDA."""
 

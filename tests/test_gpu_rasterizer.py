@@ -283,3 +283,32 @@ def test_c5_stress_shapes_parity():
     _check_forward(means, cov6, sc.opacities.numpy(), cam, shs=shs, sh_degree=4)
     # fp32 itself (GPU and the fp32 oracle alike) sits ~5e-4 from fp64 on this 512^2 / degree-4 case
     _check_backward(means[::8], cov6[::8], sc.opacities.numpy()[::8], cam, shs=shs[::8], sh_degree=4, f64_rel=2e-3)
+
+
+def test_orthographic_renderer_matches_oracle():
+    """render_cuda_orthographic's camera construction (cuda_splatting.py:136-196) through the HIP path vs the oracle"""
+    from oracle.gsr_oracle import Oracle
+    from styl3r_amd.camera import get_projection_matrix
+    from styl3r_amd.decoder import Gaussians, render_hip_orthographic
+    from styl3r_amd.scenes import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(n_ctx=1, grid_hw=(64, 64), n_views=1, image_hw=(64, 64), seed=9)
+    g = Gaussians(sc.means[None].to(dev), sc.covariances[None].to(dev), sc.harmonics[None].to(dev), sc.opacities[None].to(dev))
+    ext = torch.eye(4)[None]; ext[0, 2, 3] = -1.0
+    width = torch.tensor([6.0]); height = torch.tensor([6.0]); near = torch.tensor([0.5]); far = torch.tensor([20.0])
+    dump = {}
+    img = render_hip_orthographic(ext.to(dev), width.to(dev), height.to(dev), near.to(dev), far.to(dev), (64, 64),
+                                  torch.zeros(1, 3, device=dev), g, 1, dump=dump)
+    assert img.shape == (1, 3, 64, 64) and img.abs().sum() > 0
+    # oracle with the dumped camera
+    e = dump["extrinsics"][0].cpu(); n2, f2 = dump["near"].cpu(), dump["far"].cpu()
+    fx, fy = dump["fov_x"].cpu(), dump["fov_y"].cpu()
+    P = get_projection_matrix(n2, f2, fx.expand(1), fy)[0].T
+    V = e.inverse().T
+    cov = sc.covariances.numpy()
+    cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+    st, _ = Oracle("f32").forward(sc.means.numpy(), cov6, sc.opacities.numpy(), shs=sc.harmonics.numpy().transpose(0, 2, 1), H=64, W=64,
+                                  tanfovx=float((0.5 * fx).tan()), tanfovy=float((0.5 * fy).tan()[0]), bg=(0, 0, 0), view=V.numpy(),
+                                  proj=(V @ P).numpy(), proj_raw=P.numpy(), campos=e[:3, 3].numpy())
+    ok = st.fragile == 0
+    assert_close_rel(img[0].cpu().numpy()[:, ok], st.image[:, ok], 2e-4, "orthographic image")
