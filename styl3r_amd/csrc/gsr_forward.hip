@@ -298,11 +298,15 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
     if (n <= SORT_LDS_KEYS) {
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
+#if !(defined(GSR_EXP) && GSR_EXP == 5)
         if (n > 1) bitonic_sort_block(s_key, n, tid, 256);
+#endif
         for (uint32_t i = tid; i < n; i += 256) {
             const uint32_t id = (uint32_t)(s_key[i] & 0xffffffffull);
             ws.point_list[start + i] = id;
+#if !(defined(GSR_EXP) && GSR_EXP == 4)
             emit_queue(recs, ws.queue + start + i, id, ox, oy);
+#endif
         }
     } else {
         // oversize bucket: same network, in place in global memory (one workgroup owns the
