@@ -54,6 +54,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = blockIdx.x * QB + wave * QW;
     const int qi = min(q0 + col, a.Nq - 1);   // clamped: rows beyond Nq compute garbage that is never stored
+    const bool wave_active = q0 < a.Nq;       // N = 257 leaves most waves of the last workgroup without queries:
+                                              // they only help staging the K/V tiles and skip the MFMA work
     const float qscale = a.scale * 1.4426950408889634f;   // scores in the base-2 domain
 
     // ---- Q fragment: qf[s] = Q[qi][2s + half], optionally rotated, pre-scaled ----
@@ -85,50 +87,66 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
     const float *kb = k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
     const float *vb = v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
 
-    for (int k0 = 0; k0 < a.Nk; k0 += KT) {
-        __syncthreads();   // previous tile fully consumed
-        // ---- stage K (rotated if ROPE) and V ----
+    // K/V tiles travel global -> registers -> LDS; the loads of tile t+1 are issued right after tile t has been
+    // written to LDS, so their latency hides under tile t's MFMAs.
+    float kreg[4][4];
+    float4 vreg[4];
+    int kpy[4], kpx[4];
+    auto fetch = [&](int k0) {   // loads only: nothing here consumes a loaded value, so nothing waits for it
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = tid + 256 * it;
             const int key = item >> 4, dq = item & 15;
-            const int kg = k0 + key;
-            float uy = 0.f, vy = 0.f, ux = 0.f, vx = 0.f;
-            if (kg < a.Nk) {
-                const float *kr = kb + (int64_t)kg * a.k_sn;
-                uy = kr[dq]; vy = kr[16 + dq]; ux = kr[32 + dq]; vx = kr[48 + dq];
-                if (ROPE) {
-                    const int64_t py = a.kpos[((int64_t)b * a.Nk + kg) * 2 + 0], px = a.kpos[((int64_t)b * a.Nk + kg) * 2 + 1];
-                    const float cy = a.cos_tab[py * 16 + dq], sy = a.sin_tab[py * 16 + dq];
-                    const float cx = a.cos_tab[px * 16 + dq], sx = a.sin_tab[px * 16 + dq];
-                    const float t0 = uy * cy - vy * sy, t1 = vy * cy + uy * sy;
-                    const float t2 = ux * cx - vx * sx, t3 = vx * cx + ux * sx;
-                    uy = t0; vy = t1; ux = t2; vx = t3;
-                }
+            const int kg = min(k0 + key, a.Nk - 1);
+            const float *kr = kb + (int64_t)kg * a.k_sn;
+            kreg[it][0] = kr[dq]; kreg[it][1] = kr[16 + dq]; kreg[it][2] = kr[32 + dq]; kreg[it][3] = kr[48 + dq];
+            vreg[it] = *reinterpret_cast<const float4 *>(vb + (int64_t)kg * a.v_sn + 4 * dq);
+            if (ROPE) {
+                kpy[it] = (int)a.kpos[((int64_t)b * a.Nk + kg) * 2 + 0];
+                kpx[it] = (int)a.kpos[((int64_t)b * a.Nk + kg) * 2 + 1];
             }
-            float *dst = s_k + key * KSTR;
-            dst[dq] = uy; dst[16 + dq] = vy; dst[32 + dq] = ux; dst[48 + dq] = vx;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < a.Nk; k0 += KT) {
+        __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int item = tid + 256 * it;
-            const int key = item >> 4, c4 = item & 15;
-            const int kg = k0 + key;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kg < a.Nk) val = *reinterpret_cast<const float4 *>(vb + (int64_t)kg * a.v_sn + 4 * c4);
-            *reinterpret_cast<float4 *>(s_v + key * HD + 4 * c4) = val;
+            const int key = item >> 4, dq = item & 15;
+            const bool real = k0 + key < a.Nk;     // rows beyond Nk are written as zeros (and masked to -inf below)
+            float uy = real ? kreg[it][0] : 0.f, vy = real ? kreg[it][1] : 0.f;
+            float ux = real ? kreg[it][2] : 0.f, vx = real ? kreg[it][3] : 0.f;
+            if (ROPE) {
+                const float cy = a.cos_tab[kpy[it] * 16 + dq], sy = a.sin_tab[kpy[it] * 16 + dq];
+                const float cx = a.cos_tab[kpx[it] * 16 + dq], sx = a.sin_tab[kpx[it] * 16 + dq];
+                const float t0 = uy * cy - vy * sy, t1 = vy * cy + uy * sy;
+                const float t2 = ux * cx - vx * sx, t3 = vx * cx + ux * sx;
+                uy = t0; vy = t1; ux = t2; vx = t3;
+            }
+            float *dst = s_k + key * KSTR;
+            dst[dq] = uy; dst[16 + dq] = vy; dst[32 + dq] = ux; dst[48 + dq] = vx;
+            *reinterpret_cast<float4 *>(s_v + key * HD + 4 * dq) = real ? vreg[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
+        if (k0 + KT < a.Nk) fetch(k0 + KT);
+        if (!wave_active) continue;
+        const bool two = k0 + 32 < a.Nk;   // second 32-key block holds at least one real key
 
         // ---- S^T = K Q^T for the two 32-key blocks ----
         f32x16 st0 = {0}, st1 = {0};
         {
             const float *ka = s_k + col * KSTR + half;          // K[key = col][d = 2s + half]
             const float *kc = s_k + (32 + col) * KSTR + half;
+            if (two) {
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                st0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], st0, 0, 0, 0);
-                st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[2 * s], qf[s], st1, 0, 0, 0);
+                for (int s = 0; s < 32; ++s) {
+                    st0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], st0, 0, 0, 0);
+                    st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[2 * s], qf[s], st1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 32; ++s) st0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qf[s], st0, 0, 0, 0);
             }
         }
         // mask keys beyond Nk: element r of block kb is key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 half
@@ -168,9 +186,15 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
                 const float *va = s_v + key * HD + col;           // V[key][d = col (+32)]
                 o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], st0[r], o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], st0[r], o1, 0, 0, 0);
-                const float *vc = va + 32 * HD;
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0], st1[r], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[32], st1[r], o1, 0, 0, 0);
+            }
+            if (two) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float *vc = s_v + key * HD + col;
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0], st1[r], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[32], st1[r], o1, 0, 0, 0);
+                }
             }
         }
     }

@@ -136,13 +136,12 @@ __global__ void __launch_bounds__(256) k_attn_bwd_kv(VitAttnArgs a, const float 
     const int ki = min(key0 + col, a.Nk - 1);
     const float c2 = a.scale * LOG2E;
 
-    float kf[32], vf[32];
-    load_frag<ROPE>(kf, k + (int64_t)b * a.k_sb + (int64_t)ki * a.k_sn + (int64_t)h * a.k_sh, half,
+    float kfs[32], vf[32];      // K fragment pre-scaled by scale*log2(e): only S = Q K^T consumes it
+    load_frag<ROPE>(kfs, k + (int64_t)b * a.k_sb + (int64_t)ki * a.k_sn + (int64_t)h * a.k_sh, half,
                     ROPE ? a.kpos + ((int64_t)b * a.Nk + ki) * 2 : nullptr, a.cos_tab, a.sin_tab);
     load_frag<false>(vf, v + (int64_t)b * a.v_sb + (int64_t)ki * a.v_sn + (int64_t)h * a.v_sh, half, nullptr, nullptr, nullptr);
-    float kfs[32];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) kfs[s] = kf[s] * c2;
+    for (int s = 0; s < 32; ++s) kfs[s] *= c2;
 
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     const float *qb = q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
