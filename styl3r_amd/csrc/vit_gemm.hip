@@ -22,15 +22,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef VIT_BK
 #define VIT_BK 16
 #endif
-constexpr int BM = 128, BN = 128, BK = VIT_BK, LDT = 132;   // LDT: padded row length of the k-major tiles
+constexpr int BM = 128, BK = VIT_BK, LDT = 132;   // LDT: padded row length of the k-major tiles (BN = 64 * TN)
 
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int ACT>
+// TN = 32-column MFMA tiles per wavefront along N: TN = 2 -> 128x128 workgroup tile, TN = 1 -> 128x64 (more, smaller
+// tiles for N <= 1024 layers, whose 128x128 tiling leaves most CUs with one tile while a few carry two)
+template <int ACT, int TN>
 __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, const float *__restrict__ w,
                                                 const float *__restrict__ bias, const float *__restrict__ residual,
                                                 float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
 {
+    constexpr int BN = 64 * TN;
     __shared__ float sA[2][BK * LDT], sB[2][BK * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -45,33 +48,39 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
     const int m0 = tm * BM, n0 = tn * BN;
 
     // loader mapping: BK/4 lanes cover one row segment of BK floats; 1024/BK rows per pass, BM*BK/1024 passes
-    constexpr int LPR = BK / 4, RPP = 256 / LPR, NP = BM / RPP;
+    constexpr int LPR = BK / 4, RPP = 256 / LPR, NP = BM / RPP, NPB = BN / RPP;
     const int lrow = tid / LPR, lk = (tid % LPR) * 4;
-    float4 ra[NP], rb[NP];
+    float4 ra[NP], rb[NPB];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int r = lrow + RPP * p;
-            const int gm = m0 + r, gn = n0 + r;
+            const int gm = m0 + lrow + RPP * p;
             ra[p] = gm < M ? *reinterpret_cast<const float4 *>(x + (int64_t)gm * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            const int gn = n0 + lrow + RPP * p;
             rb[p] = gn < N ? *reinterpret_cast<const float4 *>(w + (int64_t)gn * K + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int r = lrow + RPP * p;
-            float *a = sA[buf] + lk * LDT + r, *b = sB[buf] + lk * LDT + r;
+            float *a = sA[buf] + lk * LDT + lrow + RPP * p;
             a[0] = ra[p].x; a[LDT] = ra[p].y; a[2 * LDT] = ra[p].z; a[3 * LDT] = ra[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            float *b = sB[buf] + lk * LDT + lrow + RPP * p;
             b[0] = rb[p].x; b[LDT] = rb[p].y; b[2 * LDT] = rb[p].z; b[3 * LDT] = rb[p].w;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
 
     gload(0);
     lstore(0);
@@ -81,21 +90,22 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
         const float *a = sA[buf] + half * LDT + wm * 64 + col;   // A[m = wm*64 + 32 i + col][k = 2 s + half]
-        const float *b = sB[buf] + half * LDT + wn * 64 + col;   // W[n = wn*64 + 32 j + col][k]
+        const float *b = sB[buf] + half * LDT + wn * (32 * TN) + col;   // W[n = wn*32*TN + 32 j + col][k]
         // fragment reads run one k-step ahead of the MFMAs that consume them
-        float a0 = a[0], a1 = a[32], b0 = b[0], b1 = b[32];
+        float a0 = a[0], a1 = a[32], b0 = b[0], b1 = TN > 1 ? b[32] : 0.f;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
             if (s + 1 < BK / 2) {
                 na0 = a[2 * (s + 1) * LDT]; na1 = a[2 * (s + 1) * LDT + 32];
-                nb0 = b[2 * (s + 1) * LDT]; nb1 = b[2 * (s + 1) * LDT + 32];
+                nb0 = b[2 * (s + 1) * LDT];
+                if (TN > 1) nb1 = b[2 * (s + 1) * LDT + 32];
             }
             // D[i = m][j = n]: A-operand = x rows, B-operand = W rows -> lane = output column n (coalesced row stores)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (TN > 1) acc[0][TN - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][TN - 1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            if (TN > 1) acc[1][TN - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][TN - 1], 0, 0, 0);
             a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
@@ -105,8 +115,8 @@ __global__ void __launch_bounds__(256) k_linear(const float *__restrict__ x, con
     // acc[i][j]: lane column = n = n0 + wn*64 + 32 j + col ; register r = row m = m0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
     // -> every store instruction writes two 128-byte row segments; bias is lane-local
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + 32 * j + col;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (32 * TN) + 32 * j + col;
         if (n >= N) continue;
         const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
@@ -131,10 +141,15 @@ int linear_fwd(const float *x, const float *w, const float *bias, const float *r
 {
     if (!x || !w || !out) return VIT_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || act < 0 || act > 1) return VIT_EINVAL;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // tile shape: 128x128 unless that leaves fewer than ~2.5 tiles per CU (256 CUs), then 128x64
+    const int tm = (M + BM - 1) / BM;
+    const bool narrow = tm * ((N + 127) / 128) < 640;
+    const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
     (void)hipGetLastError();
-    if (act == 1) hipLaunchKernelGGL(k_linear<1>, dim3(tiles), dim3(256), 0, stream, x, w, bias, residual, out, pre, M, N, K);
-    else hipLaunchKernelGGL(k_linear<0>, dim3(tiles), dim3(256), 0, stream, x, w, bias, residual, out, pre, M, N, K);
+#define VIT_LAUNCH_LINEAR(ACT, TN) hipLaunchKernelGGL((k_linear<ACT, TN>), dim3(tiles), dim3(256), 0, stream, x, w, bias, residual, out, pre, M, N, K)
+    if (act == 1) { if (narrow) VIT_LAUNCH_LINEAR(1, 1); else VIT_LAUNCH_LINEAR(1, 2); }
+    else { if (narrow) VIT_LAUNCH_LINEAR(0, 1); else VIT_LAUNCH_LINEAR(0, 2); }
+#undef VIT_LAUNCH_LINEAR
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
