@@ -269,11 +269,33 @@ __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *_
     uint32_t quad = 0;
     if (ext) {
         const float hx = (float)(ext & 0xffffu), hy = (float)(ext >> 16);
-        const float x0 = q0.x - hx, x1 = q0.x + hx, y0 = q0.y - hy, y1 = q0.y + hy;
-        const float fox = (float)ox, foy = (float)oy;
-        const bool L = x0 <= fox + 7.f && x1 >= fox, R = x1 >= fox + 8.f && x0 <= fox + 15.f;
-        const bool Tp = y0 <= foy + 7.f && y1 >= foy, Bm = y1 >= foy + 8.f && y0 <= foy + 15.f;
-        quad = (uint32_t)(L && Tp) | ((uint32_t)(R && Tp) << 1) | ((uint32_t)(L && Bm) << 2) | ((uint32_t)(R && Bm) << 3);
+        const float fox = (float)ox - q0.x, foy = (float)oy - q0.y;      // tile origin relative to the splat centre
+        // a quadrant can see the splat only if min over its pixel rectangle of d^T conic d <= 2 ln(255 opacity):
+        // bounding box first, then the exact minimum of the convex quadratic over the rectangle (centre inside -> 0,
+        // otherwise it sits on one of the four edges at the clamped 1-D minimiser).  Conservative by the 0.2 % margin.
+        const float A = q1.x, B = q1.y, C = q1.z;
+        const float lim = 2.0f * __logf(255.0f * q1.w) * 1.002f + 1e-3f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = fox + (float)((k & 1) * 8), x1 = x0 + 7.f;
+            const float y0 = foy + (float)((k >> 1) * 8), y1 = y0 + 7.f;
+            if (x0 > hx || x1 < -hx || y0 > hy || y1 < -hy) continue;
+            float best = 0.f;
+            if (!(x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f)) {
+                best = 3.0e38f;
+                const float iC = -B / C, iA = -B / A;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float xe = e ? x1 : x0;
+                    const float dy = fminf(fmaxf(iC * xe, y0), y1);
+                    best = fminf(best, A * xe * xe + 2.f * B * xe * dy + C * dy * dy);
+                    const float ye = e ? y1 : y0;
+                    const float dx = fminf(fmaxf(iA * ye, x0), x1);
+                    best = fminf(best, A * dx * dx + 2.f * B * dx * ye + C * ye * ye);
+                }
+            }
+            if (best <= lim) quad |= 1u << k;
+        }
     }
     float4 *o = reinterpret_cast<float4 *>(out);
     o[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
@@ -380,6 +402,9 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 const float alpha = fminf(0.99f, b.y * __expf(power));
 #if defined(GSR_EXP) && GSR_EXP == 3
                 atomicAdd(ws.tile_cursor + 0, 1u); if (alpha >= (1.f / 255.f)) atomicAdd(ws.tile_cursor + 1, 1u);
+#endif
+#if defined(GSR_EXP) && GSR_EXP == 6
+                { unsigned long long bm = __ballot(alpha >= (1.f / 255.f)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(ws.tile_cursor + 2, 1u); if (bm == 0) atomicAdd(ws.tile_cursor + 3, 1u); } }
 #endif
                 if (alpha < (1.f / 255.f)) continue;
                 const float test_T = Tr[k] * (1.f - alpha);

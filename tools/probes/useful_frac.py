@@ -11,6 +11,7 @@ dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0, 0, 0], True)).to
 rz.KEEP_DEBUG = True
 dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (256, 256))
 d = rz.LAST_DEBUG; L = d["layout"]
-cur = d["ws"][L.tile_cursor:L.tile_cursor + 8].view(torch.int32).cpu().numpy()
+cur = d["ws"][L.tile_cursor:L.tile_cursor + 16].view(torch.int32).cpu().numpy()
 R = d["num_pairs"]
 print("pairs R", R, "pixel evals past power test", cur[0], "alpha >= 1/255", cur[1], "useful frac", cur[1] / max(cur[0], 1), "evals per pair", cur[0] / R, "useful per pair", cur[1] / R)
+print("quadrant passes reaching the alpha test", cur[2], "with no lane >= 1/255", cur[3], "frac", cur[3] / max(cur[2], 1))
