@@ -5,9 +5,10 @@ The reference gets this from Lightning's `strategy="ddp_find_unused_parameters_t
 (src/main_style.py:104-108): torch DDP, 25 MB buckets, a per-step unused-parameter graph scan.
 Here the graph is static, so the bucket map is built once (no scan): parameters are packed in
 REVERSE registration order (= autograd readiness: DPT heads -> decoders -> encoders) into
-flat fp32 buckets that the gradients are accumulated INTO (p.grad is a view of its bucket: no
-pack/unpack copies); a bucket is reduced the moment its last gradient lands, on RCCL's own stream,
-while the backward keeps running.  xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU):
+flat fp32 buckets; when the last gradient of a bucket lands, ONE multi-tensor copy packs the bucket (instead of
+one accumulate kernel per parameter: ~1 800 tiny launches per step on the full encoder), p.grad is re-pointed
+at the bucket slices (the optimizer then reads the reduced values in place, no unpack) and the bucket is
+all-reduced on RCCL's own stream while the backward keeps running.  xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU):
 large buckets (default 64 MiB) keep every link busy and amortise the launch latency of the collective.
 Parameters that never receive a gradient (mask_token) are reduced as zeros at `finish()`.
 """
@@ -35,6 +36,7 @@ class BucketedGradReducer:
         if cur:
             self.buckets.append(self._make_bucket(cur))
         self._handles: list = []
+        self._armed = False
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -51,6 +53,8 @@ class BucketedGradReducer:
 
     def _make_hook(self, bi):
         def hook(p):
+            if not self._armed:                 # a backward outside prepare()/finish() is left alone
+                return
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -59,17 +63,23 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         b["launched"] = True
+        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
+        if have:
+            torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
+        for p, v in zip(b["params"], b["views"]):
+            p.grad = v
         if self.dist is not None and self.world > 1:
             self._handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def prepare(self):
-        """call before backward: zero the buckets and point every p.grad at its bucket slice."""
+        """call before backward: zero the buckets (parameters without a gradient reduce as zeros) and drop old grads."""
         self._handles.clear()
+        self._armed = True
         for b in self.buckets:
             b["flat"].zero_()
             b["pending"], b["launched"] = len(b["params"]), False
-            for p, v in zip(b["params"], b["views"]):
-                p.grad = v
+            for p in b["params"]:
+                p.grad = None
 
     def finish(self):
         """call after backward: reduce the buckets whose gradients never all arrived, wait, average."""
@@ -79,6 +89,7 @@ class BucketedGradReducer:
         for h in self._handles:
             h.wait()
         self._handles.clear()
+        self._armed = False
         if self.world > 1:
             for b in self.buckets:
                 b["flat"].mul_(1.0 / self.world)
