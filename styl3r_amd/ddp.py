@@ -75,8 +75,8 @@ class BucketedGradReducer:
         """call before backward: zero the buckets (parameters without a gradient reduce as zeros) and drop old grads."""
         self._handles.clear()
         self._armed = True
+        torch._foreach_zero_([b["flat"] for b in self.buckets])
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"], b["launched"] = len(b["params"]), False
             for p in b["params"]:
                 p.grad = None
@@ -91,8 +91,16 @@ class BucketedGradReducer:
         self._handles.clear()
         self._armed = False
         if self.world > 1:
-            for b in self.buckets:
-                b["flat"].mul_(1.0 / self.world)
+            torch._foreach_mul_([b["flat"] for b in self.buckets], 1.0 / self.world)
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ (L2, eps 1e-6, coefficient clamped to 1) evaluated on the flat buckets:
+        one norm + one scale per bucket instead of one per parameter.  Call after finish()."""
+        flats = [b["flat"] for b in self.buckets]
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(flats)))
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        torch._foreach_mul_(flats, coef)
+        return total
 
     def bucket_sizes_bytes(self) -> List[int]:
         return [b["flat"].numel() * 4 for b in self.buckets]

@@ -65,3 +65,23 @@ def test_reducer_single_process_is_identity():
     red = BucketedGradReducer(m.parameters(), None)
     red.prepare(); m(torch.ones(2, 4)).sum().backward(); red.finish()
     assert torch.allclose(m.weight.grad, torch.full((3, 4), 2.0))
+
+
+def test_flat_clip_matches_torch_clip():
+    import torch
+    from torch import nn
+    from styl3r_amd.ddp import BucketedGradReducer
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 4))
+    x = torch.randn(5, 8)
+    m(x).pow(2).sum().backward()
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 0.5)
+    want = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    red = BucketedGradReducer(m.parameters(), None, bucket_bytes=256)
+    red.prepare(); m(x).pow(2).sum().backward(); red.finish()
+    total = red.clip_grad_norm_(0.5)
+    assert total > 0.5
+    for p, w in zip(m.parameters(), want):
+        assert torch.allclose(p.grad, w, rtol=1e-6, atol=1e-8)
