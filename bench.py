@@ -112,6 +112,7 @@ def main():
 
     from styl3r_amd import _lib, rasterizer as rz
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.losses import mse_loss
     _lib.load()  # fail loudly if the HIP library is missing
 
     scenes, g, cams = build_batch(args, rank, dev)
@@ -127,7 +128,7 @@ def main():
         for t in (g.means, g.covariances, g.harmonics, g.opacities):
             t.grad = None
         out = dec.forward(g, cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (H, W))
-        loss = ((out.color - target) ** 2).mean()       # LossMse (src/loss/loss_mse.py:22-31)
+        loss = mse_loss(out.color, target)              # LossMse (src/loss/loss_mse.py:22-31) on gsr_mse_forward/backward
         loss.backward()
         return loss
 

@@ -71,6 +71,13 @@ typedef struct GsrDims {
 #define GSR_FLAG_COV9 2      /* cov6 / dL_dcov6 are full row-major 3x3 matrices (B,G,3,3): the kernels read the
                                 upper triangle and write the gradient there (lower triangle 0), which is what
                                 autograd produces for covariances[:, triu] (cuda_splatting.py:118,126) */
+#define GSR_FLAG_PHASE_BIN 4     /* gsr_forward: enqueue only preprocess + tile scan.  `status` is FINAL after them
+                                    (pair count, overflow), so the host can read it back while nothing expensive is
+                                    queued, grow the workspace if needed, and then ...                              */
+#define GSR_FLAG_PHASE_RENDER 8  /* ... call gsr_forward again with identical arguments + this flag: scatter, per-tile
+                                    sort and composite run on the workspace the PHASE_BIN call prepared.  The host
+                                    then returns with ~1 ms of GPU work still queued, which hides the launch latency
+                                    of everything it enqueues next (loss, backward).  Neither flag: all stages.     */
 
 /* status words written by gsr_forward (device int32[GSR_STATUS_WORDS]) */
 #define GSR_STATUS_WORDS 8
@@ -137,6 +144,20 @@ int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means, 
  */
 int gsr_build_views(const float *c2w, const float *K, const float *near, const float *far, const float *bg, int32_t V,
                     int32_t scale_invariant, GsrView *out, void *stream);
+
+/*
+ * MSE consumer of the rendered colour, `LossMse.forward` (src/loss/loss_mse.py:22-31):
+ *   loss = weight * mean((pred - target)^2)            -- one launch, deterministic (ticketed partial sums)
+ *   dL/dpred = (2 weight / n) * grad_loss[0] * (pred - target)   -- one launch, upstream gradient read on device
+ * pred/target/grad_pred: device fp32[n], 16-byte aligned; loss, grad_loss: device fp32[1];
+ * scratch: device buffer of gsr_mse_scratch_bytes() bytes, zeroed ONCE by the caller at allocation (the
+ * kernel re-arms it), not shared between streams.
+ */
+size_t gsr_mse_scratch_bytes(void);
+int gsr_mse_forward(const float *pred, const float *target, int64_t n, float weight, void *scratch, float *loss,
+                    void *stream);
+int gsr_mse_backward(const float *pred, const float *target, const float *grad_loss, int64_t n, float weight,
+                     float *grad_pred, void *stream);
 
 /*
  * Optional per-stage timing with hipEvents recorded on the caller's stream

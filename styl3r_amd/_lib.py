@@ -18,7 +18,7 @@ _LIBDIR = _PKG / "lib"
 # GSR_LIB_NAME / GSR_HIPCC_EXTRA: kernel-experiment builds (tools/ only); the product is libgsr_hip.so
 LIB_PATH = _LIBDIR / os.environ.get("GSR_LIB_NAME", "libgsr_hip.so")
 
-_SOURCES = ["gsr_forward.hip", "gsr_backward.hip", "gsr_api.hip"]
+_SOURCES = ["gsr_forward.hip", "gsr_backward.hip", "gsr_api.hip", "gsr_loss.hip"]
 _HEADERS = ["gsr_common.h", "../../include/gsr.h"]
 
 HIPCC_FLAGS = [
@@ -66,12 +66,15 @@ class GsrLayout(C.Structure):
 
 GSR_FLAG_NTOUCHED = 1
 GSR_FLAG_COV9 = 2
+GSR_FLAG_PHASE_BIN = 4
+GSR_FLAG_PHASE_RENDER = 8
 GSR_STATUS_WORDS = 8
 GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7
 STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
-           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error", "gsr_build_views")
+           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error", "gsr_build_views", "gsr_mse_scratch_bytes",
+           "gsr_mse_forward", "gsr_mse_backward")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
           -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
 
@@ -104,6 +107,12 @@ def load() -> C.CDLL:
     lib.gsr_build_views.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.gsr_build_views.restype = C.c_int
     lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_mse_scratch_bytes.argtypes = []
+    lib.gsr_mse_scratch_bytes.restype = C.c_size_t
+    lib.gsr_mse_forward.argtypes = [vp, vp, i64, C.c_float, vp, vp, vp]
+    lib.gsr_mse_forward.restype = C.c_int
+    lib.gsr_mse_backward.argtypes = [vp, vp, vp, i64, C.c_float, vp, vp]
+    lib.gsr_mse_backward.restype = C.c_int
     lib.gsr_profile_create.argtypes = [C.c_int]
     lib.gsr_profile_create.restype = C.c_void_p
     lib.gsr_profile_destroy.argtypes = [C.c_void_p]

@@ -74,11 +74,14 @@ inline bool hip_ok(hipError_t e)
 
 struct StageTimer {
     GsrProfile *p; int slot; hipStream_t s;
-    StageTimer(void *prof, bool fwd, hipStream_t stream) : p(static_cast<GsrProfile *>(prof)), slot(-1), s(stream)
+    // resume: second half of a two-phase forward (GSR_FLAG_PHASE_RENDER) -> keep writing into the slot the first half opened
+    StageTimer(void *prof, bool fwd, hipStream_t stream, bool resume = false)
+        : p(static_cast<GsrProfile *>(prof)), slot(-1), s(stream)
     {
         if (!p) return;
         int &n = fwd ? p->next_fwd : p->next_bwd;
-        if (n < p->max_calls) slot = n++;
+        if (resume) { if (n > 0 && n <= p->max_calls) slot = n - 1; }
+        else if (n < p->max_calls) slot = n++;
     }
     void begin(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 0), s); }
     void end(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 1), s); }

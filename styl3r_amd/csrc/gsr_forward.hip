@@ -505,12 +505,15 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     Ptrs ws = carve(workspace, L);
     const int V = d.B * d.Vt, gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
     (void)hipGetLastError();  // drop stale (non-sticky) errors of earlier runtime calls, e.g. hipErrorNotReady polls
-    StageTimer tm(d.profile, true, stream);
+    const bool bin = (d.flags & GSR_FLAG_PHASE_BIN) != 0, render = (d.flags & GSR_FLAG_PHASE_RENDER) != 0;
+    if (bin && render) return GSR_EINVAL;
+    StageTimer tm(d.profile, true, stream, render);
+    const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
+    if (render) goto render_phase;   // K1-K2 of this workspace were enqueued by the PHASE_BIN call
 
     if (!hip_ok(hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream))) return GSR_ELAUNCH;
     if (ntouch && !hip_ok(hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream))) return GSR_ELAUNCH;
 
-    const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
     tm.begin(GSR_STAGE_PREPROCESS);
 #define GSR_LAUNCH_K1(DEG) hipLaunchKernelGGL(k_preprocess<DEG>, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii)
     switch (d.M > 0 ? d.sh_degree : -1) {
@@ -524,7 +527,10 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
 #undef GSR_LAUNCH_K1
     tm.end(GSR_STAGE_PREPROCESS); tm.begin(GSR_STAGE_SCAN);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status);
-    tm.end(GSR_STAGE_SCAN); tm.begin(GSR_STAGE_SCATTER);
+    tm.end(GSR_STAGE_SCAN);
+    if (bin) return launch_status();  // status is final here: the host can size / retry before the heavy stages
+render_phase:
+    tm.begin(GSR_STAGE_SCATTER);
     hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
     tm.end(GSR_STAGE_SCATTER); tm.begin(GSR_STAGE_SORT);
     hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, d, ws);

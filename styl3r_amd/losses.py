@@ -70,14 +70,60 @@ class LossMseCfg:
     weight: float = 1.0
 
 
+_MSE_SCRATCH: dict = {}   # (device, stream) -> zero-initialised ticket/partials buffer of gsr_mse_forward
+
+
+class _MseHip(torch.autograd.Function):
+    """weight * mean((pred - target)^2) on libgsr_hip.so (include/gsr.h gsr_mse_forward/backward): 2 launches
+    instead of the 7 of the torch expression; the target needs no gradient (it is ground truth)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        pred, target = pred.contiguous(), target.contiguous()
+        dev = pred.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (dev.index, stream)
+        if key not in _MSE_SCRATCH:
+            _MSE_SCRATCH[key] = torch.zeros(lib.gsr_mse_scratch_bytes(), dtype=torch.uint8, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.gsr_mse_forward(pred.data_ptr(), target.data_ptr(), pred.numel(), float(weight),
+                                       _MSE_SCRATCH[key].data_ptr(), loss.data_ptr(), C.c_void_p(stream)), "gsr_mse_forward")
+        ctx.save_for_backward(pred, target)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from . import _lib
+        pred, target = ctx.saved_tensors
+        grad = torch.empty_like(pred)
+        g = g.contiguous().float()
+        _lib.check(_lib.load().gsr_mse_backward(pred.data_ptr(), target.data_ptr(), g.data_ptr(), pred.numel(), ctx.weight,
+                                                grad.data_ptr(), C.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream)),
+                   "gsr_mse_backward")
+        return grad, None, None
+
+
+def mse_loss(pred: Tensor, target: Tensor, weight: float = 1.0) -> Tensor:
+    """`weight * ((pred - target) ** 2).mean()` (loss_mse.py:27-31).  Device fp32 tensors with a ground-truth target go
+    through the fused HIP kernels (and raise if libgsr_hip.so is missing); anything else is the plain torch expression."""
+    if pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and not target.requires_grad \
+            and pred.shape == target.shape and pred.numel() > 0:
+        return _MseHip.apply(pred, target, weight)
+    return weight * ((pred - target) ** 2).mean()
+
+
 class LossMse(nn.Module):
     def __init__(self, cfg: LossMseCfg = LossMseCfg()):
         super().__init__()
         self.cfg = cfg
 
     def forward(self, prediction, batch, gaussians=None, global_step: int = 0) -> Tensor:
-        delta = prediction.color - batch["target"]["image"]
-        return self.cfg.weight * (delta ** 2).mean()
+        return mse_loss(prediction.color, batch["target"]["image"], self.cfg.weight)
 
 
 @dataclass

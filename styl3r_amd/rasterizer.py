@@ -23,7 +23,6 @@ from . import _lib
 # grow-only hint for the (tile, Gaussian) pair capacity, keyed by problem shape
 _CAP_HINT: dict = {}
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
-_EXPERIMENT_NOSYNC = bool(int(__import__("os").environ.get("GSR_EXPERIMENT_NOSYNC", "0")))
 KEEP_DEBUG = False
 LAST_DEBUG: dict = {}
 # bench.py sets PROFILE to a _lib.StageProfile to time every stage with hipEvents on the launch stream
@@ -89,16 +88,22 @@ class _Rasterize(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         key = (B, Vt, G, H, W)
         cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
-        while True:
-            L = _lib.workspace_layout(dims, cap)
-            ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
+        # Two-phase forward: preprocess + tile scan first; the pair count they produce is the only thing the host has
+        # to see (one 32-byte read-back, while nothing expensive is queued).  Scatter / sort / composite are enqueued
+        # after it, so this function returns with ~1 ms of GPU work still in flight and the host-side latency of
+        # whatever comes next (loss, autograd, gsr_backward) is hidden behind it.
+        def run(phase):
+            dims.flags = flags | phase
             rc = lib.gsr_forward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
                                  cap, _ptr(ws), L.total, _ptr(image), _ptr(depth), _ptr(opacity), _ptr(radii),
                                  _ptr(n_touched) if want_ntouched else None, _ptr(status), stream)
+            dims.flags = flags
             _lib.check(rc, "gsr_forward")
-            if _EXPERIMENT_NOSYNC and key in _CAP_HINT:   # tools-only experiment: measures the cost of the status read-back
-                st, R = None, cap
-                break
+
+        while True:
+            L = _lib.workspace_layout(dims, cap)
+            ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
+            run(_lib.GSR_FLAG_PHASE_BIN)
             st = status.cpu()
             R = (int(st[3]) << 32) | (int(st[0]) & 0xFFFFFFFF)
             if int(st[1]) == 0:
@@ -106,8 +111,8 @@ class _Rasterize(torch.autograd.Function):
             if R > 0xFFFFFFFF:
                 raise RuntimeError(f"gsr_forward: {R} (tile, Gaussian) pairs exceed the 2^32 list limit")
             cap = int(R * 1.25) + 1024
-        if st is not None:
-            _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
+        run(_lib.GSR_FLAG_PHASE_RENDER)
+        _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
         ctx.dims, ctx.cap, ctx.ws_bytes = dims, cap, L.total
         ctx.want_tau = theta is not None or rho is not None
         ctx.want_m2d = means2D is not None and means2D.requires_grad

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 
 from .ddp import BucketedGradReducer
+from .losses import mse_loss
 
 
 class TrainStep:
@@ -29,7 +30,7 @@ class TrainStep:
         g = self.encoder(ctx, style, 0)
         h, w = tgt["image"].shape[-2:]
         out = self.decoder.forward(g, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
-        loss = ((out.color - tgt["image"]) ** 2).mean()                   # LossMse
+        loss = mse_loss(out.color, tgt["image"])                          # LossMse
         loss.backward()
         self.reducer.finish()
         if self.clip is not None:                                         # Trainer(gradient_clip_val=0.5), main_style.py:110

@@ -312,3 +312,50 @@ def test_orthographic_renderer_matches_oracle():
                                   proj=(V @ P).numpy(), proj_raw=P.numpy(), campos=e[:3, 3].numpy())
     ok = st.fragile == 0
     assert_close_rel(img[0].cpu().numpy()[:, ok], st.image[:, ok], 2e-4, "orthographic image")
+
+
+def test_single_call_and_two_phase_forward_are_identical():
+    """include/gsr.h: gsr_forward without phase flags == GSR_FLAG_PHASE_BIN followed by GSR_FLAG_PHASE_RENDER (what
+    rasterizer.py issues), bit for bit, outputs and workspace; mixing both flags is rejected."""
+    import ctypes as C
+    from styl3r_amd import _lib
+    from styl3r_amd.scenes import make_scene
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    sc = make_scene(n_ctx=1, grid_hw=(64, 64), n_views=2, image_hw=(80, 112), seed=5)
+    from styl3r_amd.decoder import build_views_hip
+    means, cov, har, op = (t.to(dev)[None].contiguous() for t in (sc.means, sc.covariances, sc.harmonics, sc.opacities))
+    views = build_views_hip(sc.extrinsics.to(dev), sc.intrinsics.to(dev), sc.near.to(dev), sc.far.to(dev),
+                            torch.zeros(3, device=dev), False)
+    B, G, V, H, W = 1, means.shape[1], 2, 80, 112
+    shs = har.permute(0, 1, 3, 2).contiguous()
+    flags = _lib.GSR_FLAG_COV9
+    cap = 1 << 20
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    results = []
+    for phases in ((0,), (_lib.GSR_FLAG_PHASE_BIN, _lib.GSR_FLAG_PHASE_RENDER)):
+        dims = _lib.GsrDims(B, V, G, H, W, shs.shape[2], 0, flags, None)
+        L = _lib.workspace_layout(dims, cap)
+        ws = torch.zeros(L.total, dtype=torch.uint8, device=dev)
+        img = torch.zeros((V, 3, H, W), device=dev); dep = torch.zeros((V, H, W), device=dev); opa = torch.zeros((V, H, W), device=dev)
+        radii = torch.zeros((V, G), dtype=torch.int32, device=dev); status = torch.zeros(8, dtype=torch.int32, device=dev)
+        for ph in phases:
+            dims.flags = flags | ph
+            rc = lib.gsr_forward(C.byref(dims), views.data_ptr(), means.data_ptr(), cov.data_ptr(), op.data_ptr(), shs.data_ptr(),
+                                 cap, ws.data_ptr(), L.total, img.data_ptr(), dep.data_ptr(), opa.data_ptr(), radii.data_ptr(),
+                                 None, status.data_ptr(), stream)
+            assert rc == 0
+            if ph == _lib.GSR_FLAG_PHASE_BIN:
+                st = status.cpu()
+                assert int(st[1]) == 0 and int(st[0]) > 0          # status is final after the bin phase
+                assert float(img.abs().sum()) == 0.0               # nothing rendered yet
+        torch.cuda.synchronize()
+        results.append((img, dep, opa, radii, status.cpu(), ws[L.final_T:L.final_T + 4 * V * H * W].clone(),
+                        ws[L.n_contrib:L.n_contrib + 4 * V * H * W].clone(), ws[L.queue:L.queue + 48 * int(status[0])].clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    assert float(results[0][0].abs().sum()) > 0
+    dims.flags = flags | _lib.GSR_FLAG_PHASE_BIN | _lib.GSR_FLAG_PHASE_RENDER
+    assert lib.gsr_forward(C.byref(dims), views.data_ptr(), means.data_ptr(), cov.data_ptr(), op.data_ptr(), shs.data_ptr(),
+                           cap, ws.data_ptr(), L.total, img.data_ptr(), dep.data_ptr(), opa.data_ptr(), radii.data_ptr(),
+                           None, status.data_ptr(), stream) == -1

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Print the kernel timeline of ONE steady-state step from a rocprofv3 rocpd database: every kernel between two
+consecutive launches of an anchor kernel (default: the rasterizer's k_preprocess), with start offset, duration and
+the idle gap since the previous kernel ended.  Shows where the step time that is not kernel time goes.
+usage: python tools/rocpd_timeline.py <results.db> [anchor-substring] [out.md]"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+anchor = sys.argv[2] if len(sys.argv) > 2 else "k_preprocess<"
+cur = db.cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+idx = [i for i, r in enumerate(rows) if anchor in r[0] and "bwd" not in r[0]]
+if len(idx) < 3:
+    sys.exit(f"anchor {anchor!r} seen {len(idx)} times")
+a, b = idx[-3], idx[-2]                      # a full step away from both ends of the trace
+t0, prev_end, busy = rows[a][1], rows[a][1], 0
+lines = ["| # | kernel | start us | dur us | gap before us |", "|---|---|---|---|---|"]
+for i, (n, s, e) in enumerate(rows[a:b]):
+    short = n.split("(")[0][-70:]
+    lines.append(f"| {i} | `{short}` | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {max(0, s - prev_end) / 1e3:.1f} |")
+    busy += e - s
+    prev_end = max(prev_end, e)
+span = rows[b][1] - t0
+lines.append(f"\nstep span {span / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, idle {100 * (1 - busy / span):.1f} %")
+out = "\n".join(lines)
+print(out)
+if len(sys.argv) > 3:
+    open(sys.argv[3], "w").write(out + "\n")
