@@ -1,10 +1,10 @@
-"""Minimal train step over the hot path (encoder -> decoder -> MSE -> backward -> DP all-reduce ->
-clip -> AdamW), the part of `ModelWrapperStyle.training_step` / `configure_optimizers`
-(src/model/model_wrapper_style.py:118-315, 843-916) that the benchmark and the multi-GPU path need.
-Everything else of the LightningModule (logging, video, validation) is out of scope."""
+"""Train step over the hot path (encoder -> decoder -> losses -> backward -> DP all-reduce -> clip -> AdamW), the
+part of `ModelWrapperStyle.training_step` / `configure_optimizers` (src/model/model_wrapper_style.py:118-232,
+843-916) that the benchmarks and the multi-GPU path need.  Everything else of the LightningModule (logging,
+video, validation, distillation) is out of scope."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
@@ -13,27 +13,97 @@ from .ddp import BucketedGradReducer
 from .losses import mse_loss
 
 
+def select_trainable(encoder: nn.Module) -> Tuple[List[nn.Parameter], List[nn.Parameter], List[str]]:
+    """Parameter selection of `configure_optimizers` (model_wrapper_style.py:845-883), same substring rules on the same
+    parameter names.  Returns (new_params [lr], pretrained_params [lr * backbone_lr_multiplier], frozen names);
+    frozen parameters get `requires_grad = False` so nothing is tracked for them (`:866-868`).
+      stylized     : train `*stylizer.dec*` + `gaussian_appearance_head`; fine-tune the style encoder
+                     (`stylizer.enc*`, `stylizer.mask_token`, `stylizer.patch_embed`); freeze the rest.
+      not stylized : new = stylizer decoder, both Gaussian heads, intrinsic_encoder; everything else pretrained."""
+    new, pre, frozen = [], [], []
+    stylized = bool(getattr(encoder, "stylized", False))
+    for name, p in encoder.named_parameters():
+        if not p.requires_grad:
+            continue
+        if stylized:
+            if "stylizer.dec" in name or "gaussian_appearance_head" in name:
+                new.append(p)
+            elif "stylizer.enc" in name or "stylizer.mask_token" in name or "stylizer.patch_embed" in name:
+                pre.append(p)
+            else:
+                p.requires_grad = False
+                frozen.append(name)
+        else:
+            if ("stylizer.dec" in name or "gaussian_appearance_head" in name or "gaussian_param_head" in name
+                    or "intrinsic_encoder" in name):
+                new.append(p)
+            else:
+                pre.append(p)
+    return new, pre, frozen
+
+
+def make_optimizer(new: Sequence[nn.Parameter], pre: Sequence[nn.Parameter], lr: float = 2e-4,
+                   backbone_lr_multiplier: float = 0.1) -> torch.optim.Optimizer:
+    """AdamW(param_dicts, lr, weight_decay=0.05, betas=(0.9, 0.95)) of `:885-895`; on a GPU the single-pass fused
+    implementation (the foreach one makes ~10 passes over the 4.2 GB of parameter / moment state per step)."""
+    groups = [g for g in ({"params": list(new), "lr": lr}, {"params": list(pre), "lr": lr * backbone_lr_multiplier})
+              if g["params"]]
+    fused = any(p.is_cuda for g in groups for p in g["params"])
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95), fused=fused)
+
+
+def make_lr_scheduler(optimizer, warm_up_steps: int, max_steps: int, lr: float):
+    """LinearLR(1/warm_up .. 1) for `warm_up_steps`, then CosineAnnealingLR(T_max=max_steps, eta_min=0.1*lr) (`:896-906`)."""
+    warm = torch.optim.lr_scheduler.LinearLR(optimizer, 1 / warm_up_steps, 1, total_iters=warm_up_steps)
+    cos = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=max_steps, eta_min=lr * 0.1)
+    return torch.optim.lr_scheduler.SequentialLR(optimizer, schedulers=[warm, cos], milestones=[warm_up_steps])
+
+
 class TrainStep:
+    """One optimisation step.  `losses`: modules called as loss(prediction, batch, gaussians, global_step) and summed
+    (`:205-209`); default = MSE.  `identity_loss`: if given, a second encoder + decoder pass with style := context view 0
+    (`:211-229`).  `batch["style"]["image"]` is in [0,1] and mapped to [-1,1] for a stylized encoder (`:151-155`)."""
+
     def __init__(self, encoder: nn.Module, decoder: nn.Module, lr: float = 2e-4, dist=None, bucket_bytes: int = 64 << 20,
-                 clip: Optional[float] = 0.5):
+                 clip: Optional[float] = 0.5, losses: Optional[Sequence[nn.Module]] = None,
+                 identity_loss: Optional[nn.Module] = None, backbone_lr_multiplier: float = 0.1,
+                 warm_up_steps: Optional[int] = None, max_steps: int = 100_000):
         self.encoder, self.decoder, self.clip = encoder, decoder, clip
-        params = [p for p in encoder.parameters() if p.requires_grad]
-        # model_wrapper_style.py:898 (AdamW, default betas/eps/weight_decay); on a GPU the single-pass fused
-        # implementation: the foreach one makes ~10 passes over the 4.2 GB of parameter/moment state per step
-        self.optimizer = torch.optim.AdamW(params, lr=lr, fused=bool(params) and params[0].is_cuda)
-        self.reducer = BucketedGradReducer(params, dist, bucket_bytes)
+        self.losses, self.identity_loss = (list(losses) if losses is not None else None), identity_loss
+        new, pre, self.frozen_names = select_trainable(encoder)
+        self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier)
+        self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
+        # bucket order = reverse registration order of the trainable parameters (autograd readiness)
+        trainable = {id(p) for p in list(new) + list(pre)}
+        self.reducer = BucketedGradReducer([p for p in encoder.parameters() if id(p) in trainable], dist, bucket_bytes)
+        self.global_step = 0
+
+    def _render(self, ctx, style, tgt):
+        g = self.encoder(ctx, style, self.global_step)
+        h, w = tgt["image"].shape[-2:]
+        return g, self.decoder.forward(g, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
 
     def __call__(self, batch: dict) -> torch.Tensor:
         ctx, tgt = batch["context"], batch["target"]
-        style = batch.get("style") or {"image": ctx["image"][:, 0]}      # stylized=False: style := context view 0 (:149-150)
+        if getattr(self.encoder, "stylized", False) and "style" in batch:
+            style = {"image": (batch["style"]["image"] - 0.5) / 0.5}     # (0,1) -> (-1,1), `:151-155`
+        else:
+            style = {"image": ctx["image"][:, 0]}                         # stylized=False: style := context view 0 (`:149-150`)
         self.reducer.prepare()
-        g = self.encoder(ctx, style, 0)
-        h, w = tgt["image"].shape[-2:]
-        out = self.decoder.forward(g, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
-        loss = mse_loss(out.color, tgt["image"])                          # LossMse
-        loss.backward()
+        g, out = self._render(ctx, style, tgt)
+        if self.losses is None:
+            total = mse_loss(out.color, tgt["image"])                     # LossMse
+        else:
+            total = sum(fn(out, batch, g, self.global_step) for fn in self.losses)
+        if self.identity_loss is not None:
+            ig, iout = self._render(ctx, {"image": ctx["image"][:, 0]}, tgt)
+            total = total + self.identity_loss(iout, batch, ig, self.global_step)
+        total.backward()
         self.reducer.finish()
         if self.clip is not None:                                         # Trainer(gradient_clip_val=0.5), main_style.py:110
             self.reducer.clip_grad_norm_(self.clip)
         self.optimizer.step()
-        return loss.detach()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self.global_step += 1
+        return total.detach()

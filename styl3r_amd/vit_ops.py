@@ -266,9 +266,10 @@ class _FusedLinear(torch.autograd.Function):
         g_res = g if has_res else None
         if act == 1:
             g2 = torch.ops.aten.gelu_backward(g2.contiguous(), pre, approximate="none")
-        dx = (g2 @ w).reshape(shp)
-        dw = g2.t() @ x2
-        db = g2.sum(0) if has_bias else None
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = (g2 @ w).reshape(shp) if need_x else None
+        dw = g2.t() @ x2 if need_w else None              # frozen layers (style stage) skip the weight GEMM
+        db = g2.sum(0) if (has_bias and need_b) else None
         return dx, dw, db, g_res, None
 
 

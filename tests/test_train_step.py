@@ -1,0 +1,86 @@
+"""Train-step host logic: parameter selection / optimizer groups / LR schedule of `configure_optimizers`
+(src/model/model_wrapper_style.py:843-916), and (GPU) the two-pass style-stage step of `training_step` (:118-232)."""
+import pytest
+import torch
+
+from styl3r_amd.train import make_lr_scheduler, make_optimizer, select_trainable
+
+
+def _meta_encoder(stylized):
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    with torch.device("meta"):
+        return EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=stylized))
+
+
+def test_style_stage_selection_matches_reference_rules():
+    m = _meta_encoder(True)
+    new, pre, frozen = select_trainable(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert all("stylizer.dec" in names[id(p)] or "gaussian_appearance_head" in names[id(p)] for p in new)
+    assert all(any(k in names[id(p)] for k in ("stylizer.enc", "stylizer.mask_token", "stylizer.patch_embed")) for p in pre)
+    assert any(n.startswith("backbone.") for n in frozen) and any(n.startswith("downstream_head1") for n in frozen)
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n in set(frozen))
+    # the style stage trains the token stylizer + appearance head only: 1.75 GB of fp32 gradients
+    grad_bytes = 4 * sum(p.numel() for p in new + pre)
+    assert 1.70e9 < grad_bytes < 1.80e9, grad_bytes
+    assert len(new) + len(pre) + len(frozen) == sum(1 for _ in m.parameters())
+
+
+def test_nvs_stage_selection_trains_everything():
+    m = _meta_encoder(False)
+    new, pre, frozen = select_trainable(m)
+    assert not frozen and 4 * sum(p.numel() for p in new + pre) == 4 * 1_049_635_033
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert any("intrinsic_encoder" in names[id(p)] for p in new) and any("gaussian_param_head" in names[id(p)] for p in new)
+    assert all("backbone.enc_blocks" not in names[id(p)] for p in new)
+
+
+def test_optimizer_groups_and_schedule():
+    a, b = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+    opt = make_optimizer([a], [b], lr=2e-4, backbone_lr_multiplier=0.1)
+    assert [g["lr"] for g in opt.param_groups] == [2e-4, 2e-5]
+    assert all(g["weight_decay"] == 0.05 and tuple(g["betas"]) == (0.9, 0.95) for g in opt.param_groups)
+    sched = make_lr_scheduler(opt, warm_up_steps=10, max_steps=100, lr=2e-4)
+    lrs = []
+    for _ in range(60):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step(); sched.step()
+    assert abs(lrs[0] - 2e-5) < 1e-12 and abs(lrs[10] - 2e-4) < 1e-12       # linear warm-up from lr/warm_up_steps
+    assert all(x < y for x, y in zip(lrs[:10], lrs[1:11])) and all(x > y for x, y in zip(lrs[11:59], lrs[12:60]))
+    # as in the reference, eta_min = 0.1 * lr is shared by both groups: the backbone group stays at 2e-5
+    assert abs(opt.param_groups[1]["lr"] - 2e-5) < 1e-12
+
+
+@pytest.mark.gpu
+def test_style_stage_step_two_passes_on_gpu():
+    """C4 shape of the step: stylized encoder, VGG style loss + identity pass, frozen backbone (random-init VGG:
+    the torchvision weights are not available here)."""
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+    from styl3r_amd.scenes import make_scene
+    from styl3r_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tiny = dict(enc_depth=1, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
+                pos_embed="RoPE100", img_size=(512, 512))
+    enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=True), trunk_params=tiny).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    vgg = VGGEncoder().to(dev)
+    step = TrainStep(enc, dec, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), warm_up_steps=5, max_steps=50)
+    assert step.frozen_names and not enc.backbone.enc_blocks[0].attn.qkv.weight.requires_grad
+    b, v, vt, H = 1, 2, 2, 64
+    sc = make_scene(n_ctx=2, grid_hw=(8, 8), n_views=vt, image_hw=(H, H), seed=3)
+    ex = lambda t: t.to(dev)[None].expand(b, *t.shape).contiguous()
+    batch = dict(context=dict(image=torch.rand(b, v, 3, H, H, device=dev) * 2 - 1, intrinsics=ex(sc.intrinsics[:1].expand(v, 3, 3))),
+                 target=dict(image=torch.rand(b, vt, 3, H, H, device=dev), extrinsics=ex(sc.extrinsics), intrinsics=ex(sc.intrinsics),
+                             near=ex(sc.near), far=ex(sc.far)),
+                 style=dict(image=torch.rand(b, 3, H, H, device=dev)))
+    frozen_before = enc.backbone.enc_blocks[0].attn.qkv.weight.detach().clone()
+    train_before = enc.token_stylizer.dec_blocks[0].mlp.fc1.weight.detach().clone()
+    l0 = step(batch); l1 = step(batch)
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    assert torch.equal(enc.backbone.enc_blocks[0].attn.qkv.weight, frozen_before)
+    assert not torch.equal(enc.token_stylizer.dec_blocks[0].mlp.fc1.weight, train_before)
+    assert enc.backbone.enc_blocks[0].attn.qkv.weight.grad is None
+    assert step.global_step == 2

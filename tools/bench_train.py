@@ -20,6 +20,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
+ap.add_argument("--config", choices=["c3", "c4"], default="c3",
+                help="c3: NVS-pretrain, 2 ctx / 4 tgt views, MSE, everything trains.  c4: style stage, 4 ctx / 6 tgt views, "
+                     "VGG style loss + identity pass (two encoder/decoder passes), backbone frozen (random-init VGG: no weights here)")
 args = ap.parse_args()
 if args.torch_linear:
     from styl3r_amd import vit as _vit
@@ -30,25 +33,35 @@ dist = dist_utils.init_distributed("nccl", dev)
 torch.manual_seed(0)
 tiny = dict(enc_depth=2, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
             pos_embed="RoPE100", img_size=(512, 512)) if args.tiny else None
-enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(), trunk_params=tiny).to(dev)
+c4 = args.config == "c4"
+enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=c4), trunk_params=tiny).to(dev)
 # the reference's xavier init gives scales ~1e-3 softplus(0): keep default torch init (random weights, data=synthetic)
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
-step = TrainStep(enc, dec, dist=dist)
-b, v_ctx, v_tgt, H = args.scenes, 2, 4, 256
+if c4:
+    from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+    vgg = VGGEncoder().to(dev)
+    step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
+else:
+    step = TrainStep(enc, dec, dist=dist)
+b, v_ctx, v_tgt, H = args.scenes, (4 if c4 else 2), (6 if c4 else 4), 256
 g = torch.Generator(dev).manual_seed(1234 + rank)
-sc = make_scene(n_ctx=2, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
+sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
 K = sc.intrinsics[:1].to(dev)
 batch = dict(
     context=dict(image=torch.rand(b, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=K.expand(b, v_ctx, 3, 3).contiguous()),
     target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=sc.extrinsics.to(dev)[None].expand(b, -1, -1, -1).contiguous(),
                 intrinsics=sc.intrinsics.to(dev)[None].expand(b, -1, -1, -1).contiguous(), near=sc.near.to(dev)[None].expand(b, -1).contiguous(),
                 far=sc.far.to(dev)[None].expand(b, -1).contiguous()))
+if c4:
+    batch["style"] = dict(image=torch.rand(b, 3, H, H, device=dev, generator=g))
 for _ in range(args.warmup):
     step(batch)
 dt = dist_utils.timed_steps(lambda: step(batch), args.steps, lambda: torch.cuda.synchronize(dev), dist, dev)
 if rank == 0:
     nparam = sum(p.numel() for p in enc.parameters())
     print(json.dumps({"metric": "256x256 rendered views/sec, full train step (encoder+rasterizer fwd+bwd, AdamW, DP all-reduce)",
+                      "config": args.config + (" style stage: 4 ctx / 6 tgt views, VGG style + identity pass, backbone frozen" if c4 else
+                                               " NVS-pretrain: 2 ctx / 4 tgt views, MSE, all parameters train"),
                       "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.steps, world, dt), 3), "unit": "views/s",
                       "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "scenes_per_gpu": b, "params": nparam,
                       "grad_bytes": 4 * sum(p.numel() for p in enc.parameters() if p.requires_grad),
