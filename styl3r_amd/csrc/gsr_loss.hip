@@ -14,7 +14,7 @@
 
 namespace gsr {
 
-constexpr int MSE_BLOCK = 256, MSE_MAX_GROUPS = 1024;
+constexpr int MSE_BLOCK = 256, MSE_MAX_GROUPS = 4096;
 
 __device__ inline float block_sum_256(float v, float *sh)
 {

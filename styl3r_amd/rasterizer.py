@@ -84,7 +84,7 @@ class _Rasterize(torch.autograd.Function):
         opacity = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((V, G), dtype=torch.int32, device=dev)
         n_touched = torch.zeros((V, G) if want_ntouched else (1, 1), dtype=torch.int32, device=dev)
-        status = torch.zeros(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)
+        status = torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)   # fully written by the tile scan
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         key = (B, Vt, G, H, W)
         cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
@@ -119,6 +119,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.has = (theta is not None, rho is not None, means2D is not None)
         ctx.save_for_backward(means, cov6, colors, views, ws)
         ctx.mark_non_differentiable(radii, n_touched)
+        ctx.set_materialize_grads(False)   # unused outputs (depth, opacity) arrive as None instead of zero-filled tensors
         ctx.num_pairs = R
         if KEEP_DEBUG:
             LAST_DEBUG.update(ws=ws, layout=L, dims=dims, cap=cap, num_pairs=R, status=st)
@@ -131,7 +132,7 @@ class _Rasterize(torch.autograd.Function):
         dims = ctx.dims
         B, G, V = dims.B, dims.G, dims.B * dims.Vt
         dev = means.device
-        g_image = g_image.contiguous().float()
+        g_image = g_image.contiguous().float() if g_image is not None else torch.zeros((V, 3, dims.H, dims.W), dtype=torch.float32, device=dev)
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         d_means = torch.empty_like(means); d_cov6 = torch.empty_like(cov6)
         d_opac = torch.empty((B, G), dtype=torch.float32, device=dev)
