@@ -82,6 +82,21 @@ int vit_attention_bwd(const VitAttnArgs *a, const float *q, const float *k, cons
 int vit_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre,
                    int M, int N, int K, int act, void *stream);
 
+/*
+ * The same Linear at fp32 accuracy on the bf16 matrix cores ("bf16x6": every fp32 operand is split exactly into three
+ * bf16 pieces, the six leading partial products are accumulated in fp32; csrc/vit_gemm_x6.hip).  The weight is split
+ * once per optimizer step with vit_split_weight:
+ *   transpose = 0: w (rows = N, cols = K)  ->  packed weight for  out = x . w^T       (the forward, nn.Linear)
+ *   transpose = 1: w (rows = N, cols = K)  ->  packed w^T for     dX  = dY . w        (the input gradient):
+ *                  call vit_linear_x6_fwd(dY, packed, NULL, NULL, dX, NULL, M, K, N, 0)
+ * `packed` holds vit_split_weight_bytes(rows, cols) = 6 bytes per element, layout [out_row][k/8][piece][8] bf16.
+ * The contraction length must be a multiple of 16.
+ */
+size_t vit_split_weight_bytes(int rows, int cols);
+int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
+int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
+                      int M, int N, int K, int act, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

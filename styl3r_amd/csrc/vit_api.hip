@@ -13,6 +13,9 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
                   const float *dout, float *dq, float *dk, float *dv, float *delta_ws, hipStream_t stream);
 int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                int K, int act, hipStream_t stream);
+int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
+int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
+                  int K, int act, hipStream_t stream);
 }  // namespace vit
 
 #define VIT_EXPORT extern "C" __attribute__((visibility("default")))
@@ -44,6 +47,19 @@ VIT_EXPORT int vit_linear_fwd(const float *x, const float *w, const float *bias,
                               float *pre, int M, int N, int K, int act, void *stream)
 {
     return vit::linear_fwd(x, w, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT size_t vit_split_weight_bytes(int rows, int cols) { return (size_t)rows * (size_t)cols * 6; }
+
+VIT_EXPORT int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
+{
+    return vit::split_weight(w, packed, rows, cols, transpose, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out,
+                                 float *pre, int M, int N, int K, int act, void *stream)
+{
+    return vit::linear_x6_fwd(x, w_packed, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

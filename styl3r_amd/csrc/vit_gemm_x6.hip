@@ -1,0 +1,255 @@
+// vit_gemm_x6.hip -- fp32-accurate Linear on the bf16 matrix cores of gfx950 ("bf16x6" split arithmetic).
+//
+// gfx950 has no TF32/xf32 path and its exact-f32 MFMA runs at 1/16 of the bf16 rate (157 TF vs 2.5 PF).  An fp32
+// value splits EXACTLY into three bf16 pieces, a = a0 + a1 + a2 + O(2^-27 |a|) (each piece is the round-to-nearest
+// bf16 of the running residual; every residual is exactly representable in fp32), and a product of two bf16 values is
+// exact in fp32.  Keeping the six partial products whose weight is >= 2^-18 of the leading one,
+//     a.b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)          (dropped: a1 b2, a2 b1, a2 b2 <= 2^-26 |a||b|)
+// and accumulating them in the MFMA's fp32 accumulator reproduces an fp32 GEMM to fp32 rounding accuracy at 6 bf16
+// MFMAs per k-step: 16/6 = 2.7x the f32-MFMA peak (417 TF).  tests/test_gpu_vit.py measures the error of this path
+// and of the f32-MFMA path against an fp64 reference on the same inputs.
+//
+//     out (M,N) = [residual +] act( x (M,K) . w^T (N,K) + bias ),     w pre-split ONCE per optimizer step
+//
+// The weight is static inside a step, so it is split ahead of time (vit_split_weight) into the exact order the MFMA
+// B-operand wants: packed[n][k/8][piece][8] bf16, 48 contiguous bytes per (row, 8-wide k group).  Activations are
+// split while they are staged into LDS (v_cvt_pk_bf16_f32 + one subtract per piece).  The same kernel computes the
+// input gradient dX = dY . W from the pre-split TRANSPOSED weight (vit_split_weight with transpose = 1).
+//
+// 128 x (64 TN) output tile per workgroup, 4 wavefronts (2x2) of 64 x 32TN sub-tiles, v_mfma_f32_32x32x16_bf16,
+// K consumed 16 at a time; LDS rows are 112 bytes (6 x 16-B fragments + 16 pad) so the ds_read_b128 fragment reads of
+// 16 consecutive rows hit 64 distinct banks.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vit_ops.h"
+
+namespace vit {
+extern thread_local hipError_t g_last_hip_error;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace x6 {
+constexpr int BM = 128, BK = 16, ROWQ = 7;   // ROWQ: LDS row stride in 16-byte units (2 k-groups x 3 pieces + 1 pad)
+
+__device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// two fp32 values -> their three bf16 pieces, each packed (lo = first value)
+__device__ inline void split2(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
+    f32x2 f = {a, b};
+    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+    const f32x2 r1 = f - __builtin_convertvector(h0, f32x2);
+    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    p0 = __builtin_bit_cast(uint32_t, h0); p1 = __builtin_bit_cast(uint32_t, h1); p2 = __builtin_bit_cast(uint32_t, h2);
+}
+
+__device__ inline void split8(const float4 &lo, const float4 &hi, uint4 &q0, uint4 &q1, uint4 &q2)
+{
+    split2(lo.x, lo.y, q0.x, q1.x, q2.x);
+    split2(lo.z, lo.w, q0.y, q1.y, q2.y);
+    split2(hi.x, hi.y, q0.z, q1.z, q2.z);
+    split2(hi.z, hi.w, q0.w, q1.w, q2.w);
+}
+
+template <int ACT, int TN>
+__global__ void __launch_bounds__(256, 2) k_linear_x6(const float *__restrict__ x, const uint4 *__restrict__ wp,
+                                                      const float *__restrict__ bias, const float *__restrict__ residual,
+                                                      float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+{
+    constexpr int BN = 64 * TN;
+    __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    if (ntiles % 8 == 0) bid = (bid % 8) * (ntiles / 8) + bid / 8;   // XCD-aware: each XCD gets a contiguous strip of tiles
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // loader mapping: thread -> (tile row, 8-wide k group)
+    const int lrow = tid >> 1, kg = tid & 1;
+    const int KG = K >> 3;                                             // k groups per weight row
+    const bool a_ok = m0 + lrow < M, b_ok = lrow < BN && n0 + lrow < N;
+    const float *xa = x + (int64_t)(m0 + lrow) * K + kg * 8;
+    const uint4 *wb = wp + ((int64_t)(n0 + lrow) * KG + kg) * 3;
+    // two register stages: the global loads of slab k+2 are in flight while slab k feeds the MFMAs (one slab of MFMA work,
+    // ~0.35 us, is shorter than the L2/HBM latency, so a single stage leaves the wave waiting at every LDS store)
+    struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
+    Stage st0, st1;
+    const float4 fz = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint4 uz = make_uint4(0, 0, 0, 0);
+    st0.a0 = st0.a1 = st1.a0 = st1.a1 = fz;
+    st0.b0 = st0.b1 = st0.b2 = st1.b0 = st1.b1 = st1.b2 = uz;
+#define X6_GLOAD(S, k0)                                                                                              \
+    do {                                                                                                             \
+        if (a_ok) { S.a0 = *reinterpret_cast<const float4 *>(xa + (k0)); S.a1 = *reinterpret_cast<const float4 *>(xa + (k0) + 4); } \
+        if (b_ok) { const uint4 *p_ = wb + ((k0) >> 3) * 3; S.b0 = p_[0]; S.b1 = p_[1]; S.b2 = p_[2]; }                   \
+    } while (0)
+#define X6_LSTORE(buf, S)                                                                                            \
+    do {                                                                                                             \
+        uint4 q0_, q1_, q2_;                                                                                         \
+        split8(S.a0, S.a1, q0_, q1_, q2_);                                                                           \
+        uint4 *pa_ = sA[buf] + lrow * ROWQ + kg * 3;                                                                 \
+        pa_[0] = q0_; pa_[1] = q1_; pa_[2] = q2_;                                                                    \
+        if (lrow < BN) { uint4 *pb_ = sB[buf] + lrow * ROWQ + kg * 3; pb_[0] = S.b0; pb_[1] = S.b1; pb_[2] = S.b2; } \
+    } while (0)
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
+
+    auto compute = [&](int buf) {
+        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ + half * 3;          // rows wm*64 + 32 i + col, k group = half
+        const uint4 *b = sB[buf] + (wn * 32 * TN + col) * ROWQ + half * 3;
+        bf16x8 fa[2][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + p]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[j * 32 * ROWQ + p]);
+        // smallest partial products first
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+
+    const int nk = K / BK;
+    X6_GLOAD(st0, 0);
+    if (nk > 1) X6_GLOAD(st1, BK);
+    X6_LSTORE(0, st0);
+    if (nk > 2) X6_GLOAD(st0, 2 * BK);
+    __syncthreads();
+    // iteration kt: MFMAs on LDS buffer kt&1; stage (kt+1)&1 holds slab kt+1 -> LDS; its registers then take slab kt+3
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        compute(0);
+        X6_LSTORE(1, st1);
+        if (kt + 3 < nk) X6_GLOAD(st1, (kt + 3) * BK);
+        __syncthreads();
+        compute(1);
+        if (kt + 2 < nk) X6_LSTORE(0, st0);
+        if (kt + 4 < nk) X6_GLOAD(st0, (kt + 4) * BK);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);   // odd number of slabs
+#undef X6_GLOAD
+#undef X6_LSTORE
+
+    // acc[i][j]: lane column n = n0 + wn*32*TN + 32 j + col ; register r = row m0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (32 * TN) + 32 * j + col;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const int64_t o = (int64_t)m * N + n;
+                float t = acc[i][j][r] + bv;
+                if (pre) pre[o] = t;
+                if (ACT == 1) t = gelu_exact(t);
+                if (residual) t += residual[o];
+                out[o] = t;
+            }
+        }
+    }
+}
+
+// w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
+// transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
+// reads and the writes stay coalesced).
+__global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ w, uint4 *__restrict__ packed, int64_t groups)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-wide k group per thread
+    if (g >= groups) return;
+    const float4 lo = reinterpret_cast<const float4 *>(w)[g * 2], hi = reinterpret_cast<const float4 *>(w)[g * 2 + 1];
+    uint4 q0, q1, q2;
+    split8(lo, hi, q0, q1, q2);
+    packed[g * 3 + 0] = q0; packed[g * 3 + 1] = q1; packed[g * 3 + 2] = q2;
+}
+
+__global__ void __launch_bounds__(256) k_split_transposed(const float *__restrict__ w, uint4 *__restrict__ packed, int rows,
+                                                          int cols)
+{
+    // tile: 64 source rows (-> k of the output) x 32 source columns (-> output rows)
+    __shared__ float s[64][33];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int r = i >> 5, c = i & 31;
+        s[r][c] = (r0 + r < rows && c0 + c < cols) ? w[(int64_t)(r0 + r) * cols + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x >> 3, kg = threadIdx.x & 7;              // 32 output rows x 8 k groups
+    if (c0 + c >= cols || r0 + kg * 8 >= rows) return;
+    float4 lo = make_float4(s[kg * 8 + 0][c], s[kg * 8 + 1][c], s[kg * 8 + 2][c], s[kg * 8 + 3][c]);
+    float4 hi = make_float4(s[kg * 8 + 4][c], s[kg * 8 + 5][c], s[kg * 8 + 6][c], s[kg * 8 + 7][c]);
+    uint4 q0, q1, q2;
+    split8(lo, hi, q0, q1, q2);
+    uint4 *o = packed + ((int64_t)(c0 + c) * (rows >> 3) + (r0 >> 3) + kg) * 3;
+    o[0] = q0; o[1] = q1; o[2] = q2;
+}
+}  // namespace x6
+
+int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream)
+{
+    if (!w || !packed || rows <= 0 || cols <= 0) return VIT_EINVAL;
+    if ((transpose ? rows : cols) % 8 != 0) return VIT_EINVAL;
+    (void)hipGetLastError();
+    if (!transpose) {
+        const int64_t groups = (int64_t)rows * cols / 8;
+        hipLaunchKernelGGL(x6::k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, w,
+                           static_cast<uint4 *>(packed), groups);
+    } else {
+        hipLaunchKernelGGL(x6::k_split_transposed, dim3((cols + 31) / 32, (rows + 63) / 64), dim3(256), 0, stream, w,
+                           static_cast<uint4 *>(packed), rows, cols);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
+                  int K, int act, hipStream_t stream)
+{
+    if (!x || !wp || !out) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6::BK) != 0 || act < 0 || act > 1) return VIT_EINVAL;
+    const int tm = (M + x6::BM - 1) / x6::BM;
+    const bool narrow = tm * ((N + 127) / 128) < 640;
+    const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
+    const uint4 *w4 = static_cast<const uint4 *>(wp);
+    (void)hipGetLastError();
+#define VIT_LAUNCH_X6(ACT, TN) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
+    if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
+    else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
+#undef VIT_LAUNCH_X6
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+}  // namespace vit

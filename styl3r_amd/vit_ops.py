@@ -21,8 +21,9 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_api.hip"]
-EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_version", "vit_last_error")
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_api.hip"]
+EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -70,6 +71,12 @@ def load() -> C.CDLL:
         lib.vit_attention_bwd.restype = C.c_int
     lib.vit_linear_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_fwd.restype = C.c_int
+    lib.vit_split_weight_bytes.argtypes = [C.c_int, C.c_int]
+    lib.vit_split_weight_bytes.restype = C.c_size_t
+    lib.vit_split_weight.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_split_weight.restype = C.c_int
+    lib.vit_linear_x6_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_x6_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -233,9 +240,37 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
 # ---------------------------------------------------------------------------
 # fused Linear (+ GELU / + residual)
 # ---------------------------------------------------------------------------
+# Arithmetic of the fused Linear (both are fp32-accurate; tests/test_gpu_vit.py measures each against fp64):
+#   "f32"    v_mfma_f32_32x32x2_f32, exact fp32 products (157 TF peak)
+#   "bf16x6" every operand split exactly into 3 bf16 pieces, 6 leading partial products on v_mfma_f32_32x32x16_bf16
+#            with fp32 accumulation (417 TF peak-equivalent); forward and input-gradient GEMMs
+LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "f32")
+
+_SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weight._version, data_ptr, packed uint8 tensor)
+
+
+def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
+    """bf16x3 split of an nn.Linear weight (N,K) in MFMA operand order (include/vit_ops.h vit_split_weight); cached until
+    the parameter is modified in place (optimizer step) or replaced."""
+    key = (id(weight), transposed)
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
+        return hit[2]
+    lib = load()
+    N, K = weight.shape
+    w = weight.detach().contiguous().float()
+    packed = hit[2] if hit is not None and hit[2].numel() == lib.vit_split_weight_bytes(N, K) else \
+        torch.empty(lib.vit_split_weight_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    _check(lib.vit_split_weight(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
+           "vit_split_weight")
+    _SPLIT_CACHE[key] = (weight._version, weight.data_ptr(), packed)
+    return packed
+
+
 class _FusedLinear(torch.autograd.Function):
-    """forward on the fp32-MFMA kernel; the backward GEMMs (dX = dY W, dW = dY^T X) are plain library
-    GEMMs through torch / hipBLASLt."""
+    """forward on the hand-written MFMA kernels (f32 or bf16x6); backward: dX on the bf16x6 kernel with the pre-split
+    transposed weight when that mode is on, otherwise (and always for dW = dY^T X) plain library GEMMs through torch /
+    hipBLASLt."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act):
@@ -244,17 +279,21 @@ class _FusedLinear(torch.autograd.Function):
         x2 = x.reshape(-1, shp[-1]).contiguous().float()
         M, K = x2.shape
         N = weight.shape[0]
-        w = weight.contiguous().float()
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
         need_pre = act == 1 and (x.requires_grad or weight.requires_grad)
         pre = torch.empty_like(out) if need_pre else None
         res2 = residual.reshape(-1, N).contiguous().float() if residual is not None else None
         b = bias.contiguous().float() if bias is not None else None
-        rc = load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
-                                   res2.data_ptr() if res2 is not None else None, out.data_ptr(),
-                                   pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
-        _check(rc, "vit_linear_fwd")
+        x6 = LINEAR_MODE == "bf16x6"
+        w = weight.contiguous().float()
+        args = (b.data_ptr() if b is not None else None, res2.data_ptr() if res2 is not None else None, out.data_ptr(),
+                pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
+        if x6:
+            _check(load().vit_linear_x6_fwd(x2.data_ptr(), split_weight(weight).data_ptr(), *args), "vit_linear_x6_fwd")
+        else:
+            _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
         ctx.save_for_backward(x2, w, pre)
+        ctx.weight_ref = weight if x6 else None
         ctx.meta = (shp, bias is not None, residual is not None, act)
         return out.reshape(*shp[:-1], N)
 
@@ -267,7 +306,18 @@ class _FusedLinear(torch.autograd.Function):
         if act == 1:
             g2 = torch.ops.aten.gelu_backward(g2.contiguous(), pre, approximate="none")
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        dx = (g2 @ w).reshape(shp) if need_x else None
+        dx = None
+        if need_x:
+            N, K = w.shape
+            if ctx.weight_ref is not None and N % 16 == 0:
+                g2c = g2.contiguous().float()
+                dx = torch.empty((g2c.shape[0], K), dtype=torch.float32, device=g.device)
+                _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None, None,
+                                                dx.data_ptr(), None, g2c.shape[0], K, N, 0, _stream(g.device)),
+                       "vit_linear_x6_fwd (dX)")
+                dx = dx.reshape(shp)
+            else:
+                dx = (g2 @ w).reshape(shp)
         dw = g2.t() @ x2 if need_w else None              # frozen layers (style stage) skip the weight GEMM
         db = g2.sum(0) if (has_bias and need_b) else None
         return dx, dw, db, g_res, None

@@ -170,3 +170,60 @@ def test_fused_linear_vs_fp64(M, N, K, gelu, res):
     assert_close_rel(b.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "db")
     if res:
         assert_close_rel(r.grad.cpu().numpy(), rd.grad.cpu().numpy(), 1e-6, "dres")
+
+
+# ---------------------------------------------------------------------------
+# bf16x6 split arithmetic (csrc/vit_gemm_x6.hip): fp32 accuracy on the bf16 matrix cores
+# ---------------------------------------------------------------------------
+def _unpack_split(packed, rows, kcols):
+    """packed [rows][k/8][piece][8] bf16 -> three fp64 (rows, k) planes"""
+    raw = packed.view(torch.int16).view(rows, kcols // 8, 3, 8).to(torch.int32)
+    f = (raw << 16).view(torch.float32)
+    return [f[:, :, p, :].reshape(rows, kcols).double() for p in range(3)]
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_split_weight_is_exact_to_2pow26(transposed):
+    from styl3r_amd.vit_ops import split_weight
+    g = torch.Generator(DEV).manual_seed(11)
+    w = torch.randn(96, 80, device=DEV, generator=g) * torch.logspace(-6, 3, 80, device=DEV)[None]
+    packed = split_weight(w, transposed)
+    src = w.t().contiguous() if transposed else w
+    p0, p1, p2 = _unpack_split(packed, *src.shape)
+    err = (p0 + p1 + p2 - src.double()).abs()
+    assert float((err / src.double().abs().clamp_min(1e-300)).max()) <= 2.0 ** -25
+    assert float(((p0 - src.double()).abs() / src.double().abs()).max()) <= 2.0 ** -8     # piece 0 = RNE bf16
+    # cache: same tensor -> same buffer; in-place update -> re-split
+    assert split_weight(w, transposed).data_ptr() == packed.data_ptr()
+    w.mul_(2.0)
+    p0b = _unpack_split(split_weight(w, transposed), *src.shape)[0]
+    assert torch.equal(p0b, 2.0 * p0)
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(514, 1024, 1024, False), (300, 192, 4096, True), (1028, 3072, 1024, False), (77, 40, 64, False)])
+def test_bf16x6_linear_matches_fp64_like_the_f32_mfma_path(M, N, K, gelu, monkeypatch):
+    """error of the bf16x6 path vs an fp64 reference is of the order of the exact-f32 MFMA path's (both are fp32
+    roundoff: <= 2e-6 of the output scale), forward and input gradient"""
+    from styl3r_amd import vit_ops
+    g = torch.Generator(DEV).manual_seed(M * 7 + N)
+    x0 = torch.randn(M, K, device=DEV, generator=g)
+    w0 = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b0 = torch.randn(N, device=DEV, generator=g)
+    gy = torch.randn(M, N, device=DEV, generator=g)
+    xd, wd = x0.double().requires_grad_(True), w0.double()
+    ref = torch.nn.functional.linear(xd, wd, b0.double())
+    ref = torch.nn.functional.gelu(ref) if gelu else ref
+    (ref * gy.double()).sum().backward()
+    errs = {}
+    for mode in ("f32", "bf16x6"):
+        monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+        x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+        y = vit_ops.fused_linear(x, w, b0, gelu=gelu)
+        (y * gy).sum().backward()
+        ef = float((y.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        eb = float((x.grad.double() - xd.grad).abs().max() / xd.grad.abs().max())
+        errs[mode] = (ef, eb)
+    print("max-norm errors vs fp64 (fwd, dX):", errs)
+    for k in (0, 1):
+        assert errs["bf16x6"][k] <= 2e-6, errs
+        assert errs["bf16x6"][k] <= 3.0 * errs["f32"][k] + 2e-7, errs

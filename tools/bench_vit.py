@@ -33,12 +33,18 @@ for name, (B, H, Nq, Nk) in dict(enc_self=(20, 16, 257, 257), dec_cross=(20, 12,
     res["attn_" + name] = dict(fwd_ms=round(ms, 4), fwd_TF=round(fl / ms / 1e9, 1), bwd_ms=round(msb, 4),
                                bwd_TF=round(2.5 * fl / msb / 1e9, 1), torch_sdpa_fwd_ms=round(ms_t, 4))
 for name, (M, N, K, gelu) in dict(enc_qkv=(5140, 3072, 1024, False), enc_fc1=(5140, 4096, 1024, True), enc_fc2=(5140, 1024, 4096, False),
-                                  dec_fc1=(5140, 3072, 768, True)).items():
+                                  dec_fc1=(5140, 3072, 768, True), enc_proj=(5140, 1024, 1024, False),
+                                  infer_qkv=(514, 3072, 1024, False), infer_fc2=(514, 1024, 4096, False)).items():
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; b = torch.randn(N, device=dev)
+    vit_ops.LINEAR_MODE = "f32"
     ms = timeit(lambda: vit_ops.fused_linear(x, w, b, gelu=gelu))
+    vit_ops.LINEAR_MODE = "bf16x6"
+    ms6 = timeit(lambda: vit_ops.fused_linear(x, w, b, gelu=gelu))
+    vit_ops.LINEAR_MODE = "f32"
     ref = (lambda: torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b))) if gelu else (lambda: torch.nn.functional.linear(x, w, b))
     ms_t = timeit(ref)
-    res["linear_" + name] = dict(ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1), torch_ms=round(ms_t, 4),
+    res["linear_" + name] = dict(ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1), bf16x6_ms=round(ms6, 4),
+                                 bf16x6_TF=round(2 * M * N * K / ms6 / 1e9, 1), torch_ms=round(ms_t, 4),
                                  torch_TF=round(2 * M * N * K / ms_t / 1e9, 1))
 t = torch.randn(20, 16, 257, 64, device=dev); pos = torch.zeros(20, 257, 2, dtype=torch.int64, device=dev)
 rope = vit_ops.RoPE2D(100.0, max_pos=16)
