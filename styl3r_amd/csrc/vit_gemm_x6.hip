@@ -35,6 +35,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 namespace x6 {
 constexpr int BM = 128, BK = 16, ROWQ = 7;   // ROWQ: LDS row stride in 16-byte units (2 k-groups x 3 pieces + 1 pad)
 
+// Workgroup id -> output tile.  (1) Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own
+// L2: XCD x gets one CONTIGUOUS range of the tile sequence (exact partition for any tile count).  (2) The sequence
+// itself walks the tile grid in groups of GM row-tiles, column by column, so the ~64 tiles an XCD has in flight form
+// an ~8x8 block: every A row-panel and every B column-panel fetched into that L2 is reused ~8 times instead of the
+// 24x / 2.7x of a row-major walk (the B panels do not fit the 4 MB L2 and were re-streamed over the fabric).
+__device__ inline void tile_of_block(int bid, int tiles_m, int tiles_n, int &tm, int &tn)
+{
+#ifndef X6_GM
+#define X6_GM 8
+#endif
+    constexpr int GM = X6_GM;
+    const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int pid = xcd * q + min(xcd, r) + local;
+    const int per_group = GM * tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_group = pid - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+}
+
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // two fp32 values -> their three bf16 pieces, each packed (lo = first value)
@@ -69,37 +91,50 @@ __global__ void __launch_bounds__(256, 2) k_linear_x6(const float *__restrict__ 
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    if (ntiles % 8 == 0) bid = (bid % 8) * (ntiles / 8) + bid / 8;   // XCD-aware: each XCD gets a contiguous strip of tiles
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // loader mapping: thread -> (tile row, 8-wide k group)
     const int lrow = tid >> 1, kg = tid & 1;
     const int KG = K >> 3;                                             // k groups per weight row
-    const bool a_ok = m0 + lrow < M, b_ok = lrow < BN && n0 + lrow < N;
-    const float *xa = x + (int64_t)(m0 + lrow) * K + kg * 8;
-    const uint4 *wb = wp + ((int64_t)(n0 + lrow) * KG + kg) * 3;
+    // rows past M / N are CLAMPED, not predicated: their products land in accumulator rows / columns the epilogue never
+    // stores, and branch-free loads let the compiler count outstanding loads exactly (s_waitcnt vmcnt(5) instead of 0:
+    // the younger stage stays in flight across the LDS store of the older one)
+    const float *xa = x + (int64_t)min(m0 + lrow, M - 1) * K + kg * 8;
+    // B loader: 128-row tile -> thread = (row, k group), 3 pieces each.  64-row tile (TN = 1): thread = (row, k group,
+    // part): part 0 moves pieces 0 and 1, part 1 moves piece 2 (twice, same address): every thread issues the same two
+    // loads and two LDS stores, no predication
+    const int brow = TN == 2 ? lrow : (tid >> 2), bkg = TN == 2 ? kg : ((tid >> 1) & 1);
+    const int pc0 = TN == 2 ? 0 : ((tid & 1) ? 2 : 0), pc1 = TN == 2 ? 1 : ((tid & 1) ? 2 : 1);
+    const uint4 *wb = wp + ((int64_t)min(n0 + brow, N - 1) * KG + bkg) * 3;
     // two register stages: the global loads of slab k+2 are in flight while slab k feeds the MFMAs (one slab of MFMA work,
     // ~0.35 us, is shorter than the L2/HBM latency, so a single stage leaves the wave waiting at every LDS store)
+#if defined(X6_EXP) && X6_EXP == 1   // experiment: no split arithmetic
+#define X6_SPLIT8(lo, hi, q0, q1, q2) do { q0 = make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)); q1 = make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)); q2 = q0; } while (0)
+#else
+#define X6_SPLIT8(lo, hi, q0, q1, q2) split8(lo, hi, q0, q1, q2)
+#endif
     struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
     Stage st0, st1;
-    const float4 fz = make_float4(0.f, 0.f, 0.f, 0.f);
-    const uint4 uz = make_uint4(0, 0, 0, 0);
-    st0.a0 = st0.a1 = st1.a0 = st1.a1 = fz;
-    st0.b0 = st0.b1 = st0.b2 = st1.b0 = st1.b1 = st1.b2 = uz;
+    st0.b0 = st0.b1 = st0.b2 = st1.b0 = st1.b1 = st1.b2 = make_uint4(0, 0, 0, 0);
 #define X6_GLOAD(S, k0)                                                                                              \
     do {                                                                                                             \
-        if (a_ok) { S.a0 = *reinterpret_cast<const float4 *>(xa + (k0)); S.a1 = *reinterpret_cast<const float4 *>(xa + (k0) + 4); } \
-        if (b_ok) { const uint4 *p_ = wb + ((k0) >> 3) * 3; S.b0 = p_[0]; S.b1 = p_[1]; S.b2 = p_[2]; }                   \
+        const int k_ = min((k0), K - BK);   /* past the end: re-load the last slab (never consumed) */                \
+        S.a0 = *reinterpret_cast<const float4 *>(xa + k_); S.a1 = *reinterpret_cast<const float4 *>(xa + k_ + 4);     \
+        const uint4 *p_ = wb + (k_ >> 3) * 3;                                                                        \
+        S.b0 = p_[pc0]; S.b1 = p_[pc1];                                                                              \
+        if (TN == 2) S.b2 = p_[2];                                                                                   \
     } while (0)
 #define X6_LSTORE(buf, S)                                                                                            \
     do {                                                                                                             \
         uint4 q0_, q1_, q2_;                                                                                         \
-        split8(S.a0, S.a1, q0_, q1_, q2_);                                                                           \
+        X6_SPLIT8(S.a0, S.a1, q0_, q1_, q2_);                                                                        \
         uint4 *pa_ = sA[buf] + lrow * ROWQ + kg * 3;                                                                 \
         pa_[0] = q0_; pa_[1] = q1_; pa_[2] = q2_;                                                                    \
-        if (lrow < BN) { uint4 *pb_ = sB[buf] + lrow * ROWQ + kg * 3; pb_[0] = S.b0; pb_[1] = S.b1; pb_[2] = S.b2; } \
+        uint4 *pb_ = sB[buf] + brow * ROWQ + bkg * 3;                                                                \
+        pb_[pc0] = S.b0; pb_[pc1] = S.b1;                                                                            \
+        if (TN == 2) pb_[2] = S.b2;                                                                                  \
     } while (0)
 
     f32x16 acc[2][TN];
@@ -109,6 +144,20 @@ __global__ void __launch_bounds__(256, 2) k_linear_x6(const float *__restrict__ 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
 
     auto compute = [&](int buf) {
+#if defined(X6_EXP) && X6_EXP == 2   // experiment: only one of the 12 fragment reads per slab
+        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ + half * 3;
+        const bf16x8 f0 = __builtin_bit_cast(bf16x8, a[0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, f0, c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        return;
+#endif
         const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ + half * 3;          // rows wm*64 + 32 i + col, k group = half
         const uint4 *b = sB[buf] + (wn * 32 * TN + col) * ROWQ + half * 3;
         bf16x8 fa[2][3], fb[TN][3];
@@ -126,11 +175,13 @@ __global__ void __launch_bounds__(256, 2) k_linear_x6(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
+#if !(defined(X6_EXP) && X6_EXP == 4)
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+#endif
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
@@ -138,20 +189,24 @@ __global__ void __launch_bounds__(256, 2) k_linear_x6(const float *__restrict__ 
 
     const int nk = K / BK;
     X6_GLOAD(st0, 0);
-    if (nk > 1) X6_GLOAD(st1, BK);
+    X6_GLOAD(st1, BK);
     X6_LSTORE(0, st0);
-    if (nk > 2) X6_GLOAD(st0, 2 * BK);
+    X6_GLOAD(st0, 2 * BK);
     __syncthreads();
     // iteration kt: MFMAs on LDS buffer kt&1; stage (kt+1)&1 holds slab kt+1 -> LDS; its registers then take slab kt+3
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         compute(0);
         X6_LSTORE(1, st1);
-        if (kt + 3 < nk) X6_GLOAD(st1, (kt + 3) * BK);
+#if !(defined(X6_EXP) && X6_EXP == 3)
+        X6_GLOAD(st1, (kt + 3) * BK);
+#endif
         __syncthreads();
         compute(1);
-        if (kt + 2 < nk) X6_LSTORE(0, st0);
-        if (kt + 4 < nk) X6_GLOAD(st0, (kt + 4) * BK);
+        X6_LSTORE(0, st0);       // (the store after the last slab writes a buffer nobody reads)
+#if !(defined(X6_EXP) && X6_EXP == 3)
+        X6_GLOAD(st0, (kt + 4) * BK);
+#endif
         __syncthreads();
     }
     if (kt < nk) compute(0);   // odd number of slabs
