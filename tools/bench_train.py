@@ -66,6 +66,7 @@ if rank == 0:
                       "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "scenes_per_gpu": b, "params": nparam,
                       "grad_bytes": 4 * sum(p.numel() for p in enc.parameters() if p.requires_grad),
                       "buckets": len(step.reducer.buckets), "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
-                      "dtype": "f32", "data": "synthetic, random-init weights"}))
+                      "dtype": "f32", "linear_arithmetic": __import__("styl3r_amd.vit_ops", fromlist=["x"]).LINEAR_MODE
+                      if not args.torch_linear else "hipBLASLt f32", "data": "synthetic, random-init weights"}))
 if dist is not None:
     dist.barrier(); dist.destroy_process_group()

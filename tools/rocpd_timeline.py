@@ -2,10 +2,12 @@
 """Print the kernel timeline of ONE steady-state step from a rocprofv3 rocpd database: every kernel between two
 consecutive launches of an anchor kernel (default: the rasterizer's k_preprocess), with start offset, duration and
 the idle gap since the previous kernel ended.  Shows where the step time that is not kernel time goes.
-usage: python tools/rocpd_timeline.py <results.db> [anchor-substring] [out.md]"""
+usage: python tools/rocpd_timeline.py <results.db> [anchor-substring] [out.md] [--agg]   (--agg: one row per kernel name)"""
 import sqlite3
 import sys
 
+AGG = "--agg" in sys.argv
+if AGG: sys.argv.remove("--agg")
 db = sqlite3.connect(sys.argv[1])
 anchor = sys.argv[2] if len(sys.argv) > 2 else "k_preprocess<"
 cur = db.cursor()
@@ -24,6 +26,14 @@ for i, (n, s, e) in enumerate(rows[a:b]):
     busy += e - s
     prev_end = max(prev_end, e)
 span = rows[b][1] - t0
+if AGG:
+    import collections
+    agg = collections.defaultdict(lambda: [0, 0])
+    for n, s_, e in rows[a:b]:
+        agg[n][0] += 1; agg[n][1] += e - s_
+    lines = ["| kernel | calls/step | ms/step | % of span |", "|---|---|---|---|"]
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+        lines.append(f"| `{n[:110]}` | {c} | {t / 1e6:.3f} | {100 * t / span:.1f} |")
 lines.append(f"\nstep span {span / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, idle {100 * (1 - busy / span):.1f} %")
 out = "\n".join(lines)
 print(out)
