@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import weakref
 from pathlib import Path
 from typing import Optional
 
@@ -248,25 +249,35 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
 #            cross terms 3 * 2^-26 relative), at 1.5-1.7x the throughput
 LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")
 
-_SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weight._version, data_ptr, packed uint8 tensor)
+_SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
 
 
 def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of an nn.Linear weight (N,K) in MFMA operand order (include/vit_ops.h vit_split_weight); cached until
-    the parameter is modified in place (optimizer step) or replaced."""
+    the parameter is modified in place (optimizer step, load_state_dict: both bump `_version`) or replaced.  The entry
+    holds a weak reference: a new tensor that happens to reuse a dead one's id / address never hits it.  Writes through
+    `weight.data` bypass the version counter -- call `invalidate_split_cache()` after such surgery."""
     key = (id(weight), transposed)
     hit = _SPLIT_CACHE.get(key)
-    if hit is not None and hit[0] == weight._version and hit[1] == weight.data_ptr():
-        return hit[2]
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
     lib = load()
     N, K = weight.shape
     w = weight.detach().contiguous().float()
-    packed = hit[2] if hit is not None and hit[2].numel() == lib.vit_split_weight_bytes(N, K) else \
-        torch.empty(lib.vit_split_weight_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    nbytes = lib.vit_split_weight_bytes(N, K)
+    reuse = hit is not None and hit[0]() is weight and hit[3].numel() == nbytes
+    packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     _check(lib.vit_split_weight(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight")
-    _SPLIT_CACHE[key] = (weight._version, weight.data_ptr(), packed)
+    if len(_SPLIT_CACHE) > 4096:                                   # entries of dead tensors (tests, re-built models)
+        for k in [k for k, v in _SPLIT_CACHE.items() if v[0]() is None]:
+            del _SPLIT_CACHE[k]
+    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
     return packed
+
+
+def invalidate_split_cache() -> None:
+    _SPLIT_CACHE.clear()
 
 
 class _FusedLinear(torch.autograd.Function):

@@ -227,3 +227,13 @@ def test_bf16x6_linear_matches_fp64_like_the_f32_mfma_path(M, N, K, gelu, monkey
     for k in (0, 1):
         assert errs["bf16x6"][k] <= 2e-6, errs
         assert errs["bf16x6"][k] <= 3.0 * errs["f32"][k] + 2e-7, errs
+
+
+def test_split_cache_never_serves_a_dead_tensors_entry():
+    """a new weight that reuses a freed one's Python id / device address (version 0 again) must be split afresh"""
+    from styl3r_amd.vit_ops import split_weight
+    for i in range(6):
+        w = torch.full((32, 64), float(i + 1), device=DEV)
+        p0 = _unpack_split(split_weight(w), 32, 64)[0]
+        assert float(p0[0, 0]) == float(i + 1)
+        del w, p0
