@@ -100,6 +100,7 @@ typedef struct GsrLayout {
     size_t n_contrib;    /* uint32[V*H*W] */
     size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */
     size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
+    size_t tile_order;   /* uint32[V*T]     (view*T + tile) ids, longest list first: launch order of the composite kernels */
     size_t total;        /* total bytes */
 } GsrLayout;
 

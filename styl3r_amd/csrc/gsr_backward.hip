@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     __shared__ float4 s_q[64 * 3];
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
-    const int tile = blockIdx.x, v = blockIdx.y;
+    const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists are launched first
+    const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const int lane = threadIdx.x;
     const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
     const size_t P = (size_t)d.H * d.W;

@@ -34,7 +34,7 @@ static_assert(sizeof(QueueRec) == 48, "QueueRec must be 48 bytes");
 
 struct Ptrs {             // carved workspace
     SplatRec *records;
-    uint32_t *tile_count, *tile_offset, *tile_cursor;
+    uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;
     unsigned long long *pairs;
     uint32_t *point_list;
     QueueRec *queue;

@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     __shared__ uint32_t s_max[16];
+    __shared__ uint32_t s_bin[256], s_shift;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) s_carry = 0;
     uint32_t mx = 0;
@@ -188,6 +189,25 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
         int ovf = (R > (unsigned long long)capacity || R > 0xffffffffull) ? 1 : 0;
         int32_t st[GSR_STATUS_WORDS] = {(int32_t)(R & 0xffffffffull), ovf, (int32_t)m, (int32_t)(R >> 32), 0, 0, 0, 0};
         for (int k = 0; k < GSR_STATUS_WORDS; ++k) { status[k] = st[k]; ws.status[k] = st[k]; }
+        uint32_t sh = 0;                       // 256 length classes covering [0, m]
+        while ((m >> sh) > 255u) ++sh;
+        s_shift = sh;
+    }
+    // Launch order of the composite kernels: longest lists first (counting sort into 256 length classes), so the
+    // workgroups that take longest start first and the tail of K5 / K6 is made of short tiles (LPT scheduling).
+    if (tid < 256) s_bin[tid] = 0u;
+    __syncthreads();
+    const uint32_t sh = s_shift;
+    for (int i = tid; i < n; i += 1024) atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
+    __syncthreads();
+    if (tid == 0) {                            // exclusive scan of 256 bins: trivial next to the launch latency
+        uint32_t acc = 0;
+        for (int b = 0; b < 256; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t pos = atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
+        ws.tile_order[pos] = (uint32_t)i;
     }
 }
 
@@ -356,7 +376,8 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     __shared__ float4 s_q[64 * 3];
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
-    const int tile = blockIdx.x, v = blockIdx.y;
+    const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists are launched first
+    const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const int lane = threadIdx.x;
     const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
 
@@ -468,6 +489,7 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.n_contrib = take(V * P * 4);
     L.grad_rec = take(V * d.G * 12 * 4);
     L.status = take(GSR_STATUS_WORDS * 4);
+    L.tile_order = take(V * T * 4);
     L.total = off;
     return GSR_OK;
 }
@@ -487,6 +509,7 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.n_contrib = reinterpret_cast<uint32_t *>(p + L.n_contrib);
     w.grad_rec = reinterpret_cast<float *>(p + L.grad_rec);
     w.status = reinterpret_cast<int32_t *>(p + L.status);
+    w.tile_order = reinterpret_cast<uint32_t *>(p + L.tile_order);
     return w;
 }
 
