@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
     if (ws.status[GSR_ST_OVERFLOW]) return;
     __shared__ unsigned long long s_key[SORT_LDS_KEYS];
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
-    const int tile = blockIdx.x, v = blockIdx.y;
+    const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists first (as K5 / K6)
+    const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
     const uint32_t n = ws.tile_offset[t + 1] - start;
