@@ -275,24 +275,31 @@ __device__ inline uint32_t wave_agg_inc(uint32_t *__restrict__ counters, uint32_
 {
     const int lane = threadIdx.x & 63;
     unsigned long long todo = __ballot(valid);
-    uint32_t slot = 0;
+    // pass 1 (registers only): group the lanes by target; every lane learns its group's leader, size and its rank
+    int my_leader = lane;
+    uint32_t cnt = 0, rank = 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
         const bool mine = valid && t == tl;
         const unsigned long long m = __ballot(mine);
-        uint32_t base = 0;
-        if (lane == leader) {
-            if (SLOT) base = atomicAdd(counters + tl, (uint32_t)__popcll(m));
-            else atomicAdd(counters + tl, (uint32_t)__popcll(m));
-        }
-        if (SLOT) {
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (mine) slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (mine) {
+            my_leader = leader;
+            cnt = (uint32_t)__popcll(m);
+            rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         }
         todo &= ~m;
     }
-    return slot;
+    // pass 2: ONE atomic instruction, executed by all group leaders at once (one memory round trip per call instead
+    // of one per distinct target), then every member fetches its leader's base
+    uint32_t base = 0;
+    if (valid && lane == my_leader) {
+        if (SLOT) base = atomicAdd(counters + t, cnt);
+        else atomicAdd(counters + t, cnt);
+    }
+    if (!SLOT) return 0;
+    base = (uint32_t)__shfl((int)base, my_leader, 64);
+    return base + rank;
 }
 
 // ---- ten-value wave reduction for the composite backward ------------------------
