@@ -22,6 +22,8 @@ from . import _lib
 
 # grow-only hint for the (tile, Gaussian) pair capacity, keyed by problem shape
 _CAP_HINT: dict = {}
+# per device: (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward
+_STATUS_HOST: dict = {}
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
 KEEP_DEBUG = False
 LAST_DEBUG: dict = {}
@@ -89,9 +91,10 @@ class _Rasterize(torch.autograd.Function):
         key = (B, Vt, G, H, W)
         cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
         # Two-phase forward: preprocess + tile scan first; the pair count they produce is the only thing the host has
-        # to see (one 32-byte read-back, while nothing expensive is queued).  Scatter / sort / composite are enqueued
-        # after it, so this function returns with ~1 ms of GPU work still in flight and the host-side latency of
-        # whatever comes next (loss, autograd, gsr_backward) is hidden behind it.
+        # to see.  It is copied to pinned host memory right behind the scan and the render phase (scatter / sort /
+        # composite) is enqueued OPTIMISTICALLY behind that copy, so the GPU never waits for the host; the host then
+        # spins on the copy's event (ready ~0.1 ms after launch, while the render phase is still running).  On overflow
+        # the render kernels have exited early (they test the flag) and everything is re-issued with a larger capacity.
         def run(phase):
             dims.flags = flags | phase
             rc = lib.gsr_forward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
@@ -100,18 +103,27 @@ class _Rasterize(torch.autograd.Function):
             dims.flags = flags
             _lib.check(rc, "gsr_forward")
 
+        host = _STATUS_HOST.get(dev.index)
+        if host is None:
+            host = _STATUS_HOST[dev.index] = (torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, pin_memory=True),
+                                              torch.cuda.Event())
+        st, ev = host
         while True:
             L = _lib.workspace_layout(dims, cap)
             ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
             run(_lib.GSR_FLAG_PHASE_BIN)
-            st = status.cpu()
+            st.copy_(status, non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            run(_lib.GSR_FLAG_PHASE_RENDER)
+            while not ev.query():
+                pass
             R = (int(st[3]) << 32) | (int(st[0]) & 0xFFFFFFFF)
             if int(st[1]) == 0:
                 break
             if R > 0xFFFFFFFF:
                 raise RuntimeError(f"gsr_forward: {R} (tile, Gaussian) pairs exceed the 2^32 list limit")
             cap = int(R * 1.25) + 1024
-        run(_lib.GSR_FLAG_PHASE_RENDER)
+        st = st.clone()
         _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
         ctx.dims, ctx.cap, ctx.ws_bytes = dims, cap, L.total
         ctx.want_tau = theta is not None or rho is not None
