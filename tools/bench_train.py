@@ -20,9 +20,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
-ap.add_argument("--config", choices=["c3", "c4"], default="c3",
+ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                 help="c3: NVS-pretrain, 2 ctx / 4 tgt views, MSE, everything trains.  c4: style stage, 4 ctx / 6 tgt views, "
-                     "VGG style loss + identity pass (two encoder/decoder passes), backbone frozen (random-init VGG: no weights here)")
+                     "VGG style loss + identity pass (two encoder/decoder passes), backbone frozen (random-init VGG: no weights here).  "
+                     "c5: stress shapes, 4 ctx views 512x512 -> 1 048 576 Gaussians/scene, sh_degree 4, 4 tgt views 512x512, MSE, all train")
 args = ap.parse_args()
 if args.torch_linear:
     from styl3r_amd import vit as _vit
@@ -33,8 +34,12 @@ dist = dist_utils.init_distributed("nccl", dev)
 torch.manual_seed(0)
 tiny = dict(enc_depth=2, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
             pos_embed="RoPE100", img_size=(512, 512)) if args.tiny else None
-c4 = args.config == "c4"
-enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=c4), trunk_params=tiny).to(dev)
+c4, c5 = args.config == "c4", args.config == "c5"
+from styl3r_amd.encoder import GaussianAdapterCfg
+cfg = EncoderNoPoSplatTokenStyleCfg(stylized=c4)
+if c5:
+    cfg.gaussian_adapter = GaussianAdapterCfg(cfg.gaussian_adapter.gaussian_scale_min, cfg.gaussian_adapter.gaussian_scale_max, 4)
+enc = EncoderNoPoSplatMultiTokenStyle(cfg, trunk_params=tiny).to(dev)
 # the reference's xavier init gives scales ~1e-3 softplus(0): keep default torch init (random weights, data=synthetic)
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
 if c4:
@@ -43,7 +48,7 @@ if c4:
     step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
 else:
     step = TrainStep(enc, dec, dist=dist)
-b, v_ctx, v_tgt, H = args.scenes, (4 if c4 else 2), (6 if c4 else 4), 256
+b, v_ctx, v_tgt, H = args.scenes, (4 if (c4 or c5) else 2), (6 if c4 else 4), (512 if c5 else 256)
 g = torch.Generator(dev).manual_seed(1234 + rank)
 sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
 K = sc.intrinsics[:1].to(dev)
@@ -59,8 +64,9 @@ for _ in range(args.warmup):
 dt = dist_utils.timed_steps(lambda: step(batch), args.steps, lambda: torch.cuda.synchronize(dev), dist, dev)
 if rank == 0:
     nparam = sum(p.numel() for p in enc.parameters())
-    print(json.dumps({"metric": "256x256 rendered views/sec, full train step (encoder+rasterizer fwd+bwd, AdamW, DP all-reduce)",
+    print(json.dumps({"metric": ("512x512" if c5 else "256x256") + " rendered views/sec, full train step (encoder+rasterizer fwd+bwd, AdamW, DP all-reduce)",
                       "config": args.config + (" style stage: 4 ctx / 6 tgt views, VGG style + identity pass, backbone frozen" if c4 else
+                                               " stress: 4 ctx views 512x512 (1 048 576 Gaussians/scene), sh_degree 4, 4 tgt views 512x512" if c5 else
                                                " NVS-pretrain: 2 ctx / 4 tgt views, MSE, all parameters train"),
                       "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.steps, world, dt), 3), "unit": "views/s",
                       "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "scenes_per_gpu": b, "params": nparam,
