@@ -277,6 +277,57 @@ __device__ inline void bitonic_sort_block(KeyPtr key, uint32_t n, int tid, int n
     }
 }
 
+// Register-blocked bitonic sort for lists of <= 1024 keys (the common case), 256 threads x 4 keys: every pass takes its
+// four keys to registers and applies TWO consecutive strides (j, j/2) before writing back, so N = 1024 needs 29 LDS round
+// trips and barriers instead of 55.  Standard (directional) network on a list padded to N with all-ones keys, which sort
+// to the top and are never stored back.  Keys are unique, so the result equals any other correct sort bit for bit.
+__device__ inline void ce(unsigned long long &a, unsigned long long &b, bool asc)
+{
+    const bool sw = asc ? (a > b) : (a < b);
+    const unsigned long long t = sw ? b : a;
+    b = sw ? a : b; a = t;
+}
+__device__ inline void bitonic_sort_1024(unsigned long long *s, uint32_t n, int tid)
+{
+    uint32_t N = 4;
+    while (N < n) N <<= 1;
+    for (uint32_t i = n + tid; i < N; i += 256) s[i] = ~0ull;
+    __syncthreads();
+    const uint32_t G = N >> 2;                               // four-key groups
+    if ((uint32_t)tid < G) {                                 // merges k = 2 and k = 4 on four consecutive keys
+        const uint32_t i = (uint32_t)tid << 2;
+        unsigned long long e0 = s[i], e1 = s[i + 1], e2 = s[i + 2], e3 = s[i + 3];
+        ce(e0, e1, true); ce(e2, e3, false);
+        const bool asc = (i & 4u) == 0;
+        ce(e0, e2, asc); ce(e1, e3, asc); ce(e0, e1, asc); ce(e2, e3, asc);
+        s[i] = e0; s[i + 1] = e1; s[i + 2] = e2; s[i + 3] = e3;
+    }
+    __syncthreads();
+    for (uint32_t k = 8; k <= N; k <<= 1) {
+        uint32_t j = k >> 1;
+        for (; j >= 2; j >>= 2) {                            // strides j and j/2 in one pass
+            if ((uint32_t)tid < G) {
+                const uint32_t h = j >> 1, g = (uint32_t)tid;
+                const uint32_t i0 = (g / h) * (j << 1) + (g % h);
+                const bool asc = (i0 & k) == 0;
+                unsigned long long e0 = s[i0], e1 = s[i0 + h], e2 = s[i0 + j], e3 = s[i0 + j + h];
+                ce(e0, e2, asc); ce(e1, e3, asc); ce(e0, e1, asc); ce(e2, e3, asc);
+                s[i0] = e0; s[i0 + h] = e1; s[i0 + j] = e2; s[i0 + j + h] = e3;
+            }
+            __syncthreads();
+        }
+        if (j == 1) {                                        // odd number of strides in this merge: the last one alone
+            for (uint32_t p = tid; p < (N >> 1); p += 256) {
+                const uint32_t i = p << 1;
+                unsigned long long a = s[i], b = s[i + 1];
+                ce(a, b, (i & k) == 0);
+                s[i] = a; s[i + 1] = b;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
 
 // gather one record into the tile's queue slot and mark the 8x8 quadrants its footprint can touch
@@ -342,7 +393,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
 #if !(defined(GSR_EXP) && GSR_EXP == 5)
-        if (n > 1) bitonic_sort_block(s_key, n, tid, 256);
+        if (n > 1024) bitonic_sort_block(s_key, n, tid, 256);
+        else if (n > 1) bitonic_sort_1024(s_key, n, tid);
 #endif
         for (uint32_t i = tid; i < n; i += 256) {
             const uint32_t id = (uint32_t)(s_key[i] & 0xffffffffull);
