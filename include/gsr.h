@@ -79,6 +79,11 @@ typedef struct GsrDims {
                                     then returns with ~1 ms of GPU work still queued, which hides the launch latency
                                     of everything it enqueues next (loss, backward).  Neither flag: all stages.     */
 
+#define GSR_FLAG_SORT_KEYS_SHIFT 8   /* bits 8-9: LDS budget of the per-tile depth sort: 0 = 4096 keys (default), 1 = 1024,
+                                       2 = 2048.  Pick the smallest budget >= the longest per-tile list expected
+                                       (status[GSR_ST_MAX_TILE] of an earlier call): more workgroups fit a CU.  Longer lists
+                                       remain correct (sorted in global memory), only slower. */
+
 /* status words written by gsr_forward (device int32[GSR_STATUS_WORDS]) */
 #define GSR_STATUS_WORDS 8
 #define GSR_ST_PAIRS 0       /* R: total (tile, Gaussian) pairs over all views (low 32 bits) */

@@ -328,7 +328,7 @@ __device__ inline void bitonic_sort_1024(unsigned long long *s, uint32_t n, int 
     }
 }
 
-constexpr uint32_t SORT_LDS_KEYS = 4096;  // 32 KiB of LDS per workgroup
+constexpr uint32_t SORT_LDS_KEYS = 4096;  // at most 32 KiB of (dynamic) LDS per workgroup; GSR_FLAG_SORT_KEYS_* ask for less
 
 // gather one record into the tile's queue slot and mark the 8x8 quadrants its footprint can touch
 __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *__restrict__ out, uint32_t id, int ox,
@@ -374,10 +374,10 @@ __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *_
     o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
 }
 
-__global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
+__global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t lds_keys)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
-    __shared__ unsigned long long s_key[SORT_LDS_KEYS];
+    extern __shared__ unsigned long long s_key[];   // lds_keys entries: lists longer than that sort in global memory
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists first (as K5 / K6)
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws)
     const int ox = (tile % gx) * TILE, oy = (tile / gx) * TILE;
     const SplatRec *recs = ws.records + (size_t)v * d.G;
     unsigned long long *gk = ws.pairs + start;
-    if (n <= SORT_LDS_KEYS) {
+    if (n <= lds_keys) {
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
 #if !(defined(GSR_EXP) && GSR_EXP == 5)
@@ -609,7 +609,14 @@ render_phase:
     tm.begin(GSR_STAGE_SCATTER);
     hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
     tm.end(GSR_STAGE_SCATTER); tm.begin(GSR_STAGE_SORT);
-    hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), 0, stream, d, ws);
+    {
+        // LDS budget of the per-tile sort: 1024 / 2048 / 4096 keys (8 / 16 / 32 KiB).  The host passes the longest list it
+        // has seen for this shape (GSR_FLAG_SORT_KEYS_*); a smaller budget doubles the resident workgroups per CU, and a
+        // list that exceeds it is still sorted correctly (in place in global memory, slower).
+        const int sel = (d.flags >> GSR_FLAG_SORT_KEYS_SHIFT) & 3;
+        const uint32_t lds_keys = sel == 1 ? 1024u : (sel == 2 ? 2048u : SORT_LDS_KEYS);
+        hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), lds_keys * 8, stream, d, ws, lds_keys);
+    }
     tm.end(GSR_STAGE_SORT); tm.begin(GSR_STAGE_COMPOSITE_FWD);
     if (ntouch)
         hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity,

@@ -22,6 +22,8 @@ from . import _lib
 
 # grow-only hint for the (tile, Gaussian) pair capacity, keyed by problem shape
 _CAP_HINT: dict = {}
+# longest per-tile list seen per problem shape (x1.25): picks the LDS budget of the per-tile sort
+_MAX_TILE_HINT: dict = {}
 # per device: (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward
 _STATUS_HOST: dict = {}
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
@@ -77,7 +79,12 @@ class _Rasterize(torch.autograd.Function):
         cov9 = cov6.dim() == 4   # full (B,G,3,3) matrices: GSR_FLAG_COV9, no triu gather / scatter kernels
         assert (cov6.shape == (B, G, 3, 3) if cov9 else cov6.shape == (B, G, 6)) and opac.shape[:2] == (B, G)
         M = colors.shape[2] if use_sh else 0
-        flags = (_lib.GSR_FLAG_NTOUCHED if want_ntouched else 0) | (_lib.GSR_FLAG_COV9 if cov9 else 0)
+        key = (B, Vt, G, H, W)
+        # LDS budget of the per-tile sort from the longest list seen for this shape (+25 %): 1024 / 2048 / 4096 keys
+        mt = _MAX_TILE_HINT.get(key, 4096)
+        sort_sel = 1 if mt <= 1024 else (2 if mt <= 2048 else 0)
+        flags = (_lib.GSR_FLAG_NTOUCHED if want_ntouched else 0) | (_lib.GSR_FLAG_COV9 if cov9 else 0) | \
+                (sort_sel << _lib.GSR_FLAG_SORT_KEYS_SHIFT)
         dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags,
                             PROFILE.handle if PROFILE is not None else None)
         dev = means.device
@@ -88,7 +95,6 @@ class _Rasterize(torch.autograd.Function):
         n_touched = torch.zeros((V, G) if want_ntouched else (1, 1), dtype=torch.int32, device=dev)
         status = torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)   # fully written by the tile scan
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        key = (B, Vt, G, H, W)
         cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
         # Two-phase forward: preprocess + tile scan first; the pair count they produce is the only thing the host has
         # to see.  It is copied to pinned host memory right behind the scan and the render phase (scatter / sort /
@@ -125,6 +131,7 @@ class _Rasterize(torch.autograd.Function):
             cap = int(R * 1.25) + 1024
         st = st.clone()
         _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
+        _MAX_TILE_HINT[key] = max(_MAX_TILE_HINT.get(key, 0), int(int(st[2]) * 1.25))
         ctx.dims, ctx.cap, ctx.ws_bytes = dims, cap, L.total
         ctx.want_tau = theta is not None or rho is not None
         ctx.want_m2d = means2D is not None and means2D.requires_grad

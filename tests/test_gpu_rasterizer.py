@@ -110,6 +110,16 @@ def test_forward_oversize_tile_list_uses_global_sort():
     means[100:200, 2] = z[100]
     out, st = _check_forward(means, cov6, rng.uniform(0.01, 0.1, G), cam, colors=rng.uniform(0, 1, (G, 3)))
     assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > 4096
+    # a too-small LDS budget hint (GSR_FLAG_SORT_KEYS_*: 1024 keys) must still give the same lists: every tile between
+    # 1025 and 6000 entries now takes the global-memory path
+    old = rz._MAX_TILE_HINT.copy()
+    try:
+        for k in list(rz._MAX_TILE_HINT):
+            rz._MAX_TILE_HINT[k] = 100
+        rz._MAX_TILE_HINT[(1, 1, G, 32, 32)] = 100
+        _check_forward(means, cov6, rng.uniform(0.01, 0.1, G), cam, colors=rng.uniform(0, 1, (G, 3)))
+    finally:
+        rz._MAX_TILE_HINT.clear(); rz._MAX_TILE_HINT.update(old)
 
 
 def test_capacity_overflow_retry():
