@@ -24,7 +24,7 @@ def _debug_on():
     rz.LAST_DEBUG.clear()
 
 
-def _check_forward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), sh_degree=0):
+def _check_forward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), sh_degree=0, min_ok=0.97):
     out = hip_single_view(means, cov6, opac, cam, shs=shs, colors=colors, bg=bg, sh_degree=sh_degree)
     orc, st, ctx = oracle_single_view("f32", means, cov6, opac, cam, shs=shs, colors=colors, bg=bg, sh_degree=sh_degree)
     H, W = cam["H"], cam["W"]
@@ -47,7 +47,7 @@ def _check_forward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), 
     ok = st.fragile == 0
     nc = ws_view("n_contrib", np.uint32, H * W).reshape(H, W)
     assert np.array_equal(nc[ok], st.n_contrib[ok].astype(np.uint32)), "n_contrib"
-    assert ok.mean() > 0.97
+    assert ok.mean() > min_ok   # the fp-fragile mask must not hide the comparison
     # ---- float outputs: <= 1e-4 rel ----
     assert_close_rel(out["image"].cpu().numpy()[:, ok], st.image[:, ok], 1e-4, "image")
     assert_close_rel(out["depth"].cpu().numpy()[0][ok], st.out_depth[ok], 1e-4, "depth")
@@ -369,3 +369,29 @@ def test_single_call_and_two_phase_forward_are_identical():
     assert lib.gsr_forward(C.byref(dims), views.data_ptr(), means.data_ptr(), cov.data_ptr(), op.data_ptr(), shs.data_ptr(),
                            cap, ws.data_ptr(), L.total, img.data_ptr(), dep.data_ptr(), opa.data_ptr(), radii.data_ptr(),
                            None, status.data_ptr(), stream) == -1
+
+
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_randomized_sweep_forward_backward_parity(seed):
+    """seeded sweep over image shapes (ragged, tiny, wide), Gaussian counts, SH degrees, splat sizes (sub-pixel to
+    screen-filling), opacities (near 1/255 to 0.99), backgrounds, off-centre / rotated cameras, with and without pose
+    gradients: forward integer state + images and every gradient against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.choice([16, 17, 33, 48, 64, 95])), int(rng.choice([16, 31, 40, 64, 80, 130]))
+    G = int(rng.choice([1, 7, 64, 500, 3000]))
+    deg = int(rng.choice([0, 0, 1, 2, 3, 4]))
+    use_sh = bool(rng.integers(0, 2)) or deg > 0
+    scale = [(0.001, 0.01), (0.02, 0.12), (0.1, 0.6), (0.5, 3.0)][int(rng.integers(0, 4))]
+    op_range = [(0.004, 0.02), (0.2, 0.95), (0.9, 1.0)][int(rng.integers(0, 3))]
+    ang = rng.uniform(-0.3, 0.3)
+    c2w = np.eye(4)
+    c2w[:3, :3] = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    c2w[:3, 3] = rng.uniform(-0.3, 0.3, 3)
+    cam = simple_camera(H, W, c2w=c2w)
+    means, cov6, opac, shs = random_scene(G, seed=seed, z_range=(0.1, 7.0), spread=1.5, scale=scale, sh_degree=deg, op_range=op_range)
+    bg = tuple(rng.uniform(0, 1, 3)) if rng.integers(0, 2) else (0, 0, 0)
+    kw = dict(shs=shs, sh_degree=deg) if use_sh else dict(colors=rng.uniform(0, 1, (G, 3)))
+    # (hundreds of screen-filling splats per pixel: more pixels have SOME entry within 1e-4 of a threshold)
+    _check_forward(means, cov6, opac, cam, bg=bg, min_ok=0.8, **kw)
+    _check_backward(means, cov6, opac, cam, bg=bg, pose=bool(rng.integers(0, 2)), seed=seed, f64_rel=1e-2, **kw)   # fp64 check is a sanity bound here:
+    # in these extreme scenes single alpha >= 1/255 decisions differ between fp32 and fp64 arithmetic; the parity bar is the 1e-4 match with the fp32 oracle
