@@ -162,8 +162,11 @@ def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0),
         assert_close_rel(v, res["f32"][k], 1e-4, f"d{k} vs f32 oracle")
         assert_close_rel(v, res["f64"][k], f64_rel, f"d{k} vs f64 oracle")
     if pose:
-        assert_close_rel(rho.grad.cpu().numpy(), res["f64"]["rho"], 2e-4, "d rho")
-        assert_close_rel(theta.grad.cpu().numpy(), res["f64"]["theta"], 2e-4, "d theta")
+        # pose gradients are sums over all Gaussians (order differs: atomics): 5e-4 against the fp32 oracle
+        assert_close_rel(rho.grad.cpu().numpy(), res["f32"]["rho"], 5e-4, "d rho vs f32 oracle")
+        assert_close_rel(theta.grad.cpu().numpy(), res["f32"]["theta"], 5e-4, "d theta vs f32 oracle")
+        assert_close_rel(rho.grad.cpu().numpy(), res["f64"]["rho"], max(2e-4, f64_rel), "d rho")
+        assert_close_rel(theta.grad.cpu().numpy(), res["f64"]["theta"], max(2e-4, f64_rel), "d theta")
 
 
 @pytest.mark.parametrize("sh_degree", [0, 2, 4])
