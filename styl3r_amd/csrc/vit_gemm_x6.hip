@@ -83,7 +83,10 @@ __device__ inline void split8(const float4 &lo, const float4 &hi, uint4 &q0, uin
     split2(hi.z, hi.w, q0.w, q1.w, q2.w);
 }
 
-template <int ACT, int TN>
+// SPLITK: gridDim.y workgroups share one output tile, each contracting its own range of K slabs and adding its partial
+// sums into a pre-zeroed `out` with fp32 atomics (bias / residual enter through split 0; no activation).  Used when the
+// tile count alone cannot fill the chip: the 257..514-row GEMMs of batch-1 inference give 48-160 tiles for 256 CUs.
+template <int ACT, int TN, bool SPLITK>
 __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                       const float *__restrict__ bias, const float *__restrict__ residual,
                                                       float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
@@ -193,7 +196,15 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
             }
     };
 
-    const int nk = K / BK;
+    int nk = K / BK;
+    if (SPLITK) {   // this workgroup's slab range [k_lo, k_lo + nk)
+        const int S = gridDim.y, s_ = blockIdx.y, base = nk / S, rem = nk % S;
+        const int k_lo = s_ * base + min(s_, rem);
+        nk = base + (s_ < rem ? 1 : 0);
+        xa += (int64_t)k_lo * BK;
+        wb += (int64_t)k_lo * (BK >> 3) * 3;
+        K -= k_lo * BK;                  // the clamp in X6_GLOAD is relative to the shifted pointers
+    }
     X6_GLOAD(st0, 0);
     X6_GLOAD(st1, BK);
     X6_LSTORE(0, st0);
@@ -224,7 +235,8 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (32 * TN) + 32 * j + col;
         if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const bool first = !SPLITK || blockIdx.y == 0;
+        const float bv = (bias && first) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -233,6 +245,11 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
                 float t = acc[i][j][r] + bv;
+                if (SPLITK) {
+                    if (residual && first) t += residual[o];
+                    atomicAdd(out + o, t);
+                    continue;
+                }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
@@ -305,10 +322,22 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
-#define VIT_LAUNCH_X6(ACT, TN) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
-    if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
-    else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
+    // split-K when the tiles cannot fill the 256 CUs x 3 resident workgroups: S = 2 / 4 / 8 ranges of >= 8 slabs each
+    int S = 1;
+    if (act == 0 && !pre && tiles <= 200) {   // (240 tiles unsplit beat 2 x 240 with the memset + atomics: measured)
+        const int nk = K / x6::BK;
+        while (S < 8 && tiles * S * 2 <= 768 && nk / (S * 2) >= 8) S *= 2;
+    }
+    if (S > 1) {
+        if (hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        if (narrow) hipLaunchKernelGGL((x6::k_linear_x6<0, 1, true>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);
+        else hipLaunchKernelGGL((x6::k_linear_x6<0, 2, true>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);
+    } else {
+#define VIT_LAUNCH_X6(ACT, TN) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
+        if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
+        else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
 #undef VIT_LAUNCH_X6
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
