@@ -98,3 +98,26 @@ def test_noposplat_variant_matches_reference():
     ((gs.means * T("w0")).sum() + 1e4 * (gs.covariances * T("w1")).sum() + (gs.harmonics * T("w2")).sum() +
      (gs.opacities * T("w3")).sum()).backward()
     assert_close_rel(img.grad.cpu().numpy(), G["np_gimage"], 2e-3, "d image")
+
+
+@pytest.mark.gpu
+def test_hipgraph_replay_of_the_encoder_matches_eager():
+    """styl3r_amd.graphs.GraphedEncoder: the HIP kernels are captured into a hipGraph like torch's own; replay with new
+    inputs equals the eager forward"""
+    from styl3r_amd.graphs import GraphedEncoder
+    dev = "cuda:0"
+    m = deterministic_init_(_build(0)).to(dev)
+    T = lambda k: torch.tensor(G[f"sh0_{k}"], device=dev)
+    ctx, style = dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style"))
+    genc = GraphedEncoder(m, ctx, style)
+    ctx2 = dict(image=(ctx["image"] * 0.7 + 0.1).contiguous(), intrinsics=ctx["intrinsics"])
+    got = genc(ctx2, style)
+    with torch.no_grad():
+        want = m(ctx2, style, 0)
+    from tests.gpu_utils import assert_close_rel
+    with torch.no_grad():
+        old = m(ctx, style, 0)
+    for name in ("means", "covariances", "harmonics", "opacities"):
+        a, b = getattr(got, name).cpu().numpy(), getattr(want, name).cpu().numpy()
+        assert_close_rel(a, b, 2e-5, name)                      # (library convolutions may pick another algorithm: fp32 noise)
+        assert abs(a - getattr(old, name).cpu().numpy()).max() > 1e-2 * abs(b).max()   # and it really used the new inputs
