@@ -84,3 +84,34 @@ def test_style_stage_step_two_passes_on_gpu():
     assert not torch.equal(enc.token_stylizer.dec_blocks[0].mlp.fc1.weight, train_before)
     assert enc.backbone.enc_blocks[0].attn.qkv.weight.grad is None
     assert step.global_step == 2
+
+
+@pytest.mark.gpu
+def test_nvs_training_reduces_the_loss_end_to_end():
+    """encoder -> batched rasterizer -> MSE -> backward -> clip -> AdamW on a fixed batch: the loss goes down (gradients
+    of every stage are consistent enough to optimise through)"""
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.scenes import make_scene
+    from styl3r_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tiny = dict(enc_depth=1, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
+                pos_embed="RoPE100", img_size=(512, 512))
+    enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=False), trunk_params=tiny).to(dev).eval()   # eval: no head dropout
+    with torch.no_grad():      # a random-init point head puts every Gaussian behind / beside the cameras: start them in view
+        for h in (enc.downstream_head1, enc.downstream_head2):
+            h.dpt.head[4].bias.copy_(torch.tensor([0.0, 0.0, 1.2], device=dev))
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    step = TrainStep(enc, dec, lr=5e-4, clip=0.5)
+    b, v, vt, H = 2, 2, 2, 64
+    sc = make_scene(n_ctx=2, grid_hw=(8, 8), n_views=vt, image_hw=(H, H), seed=3)
+    ex = lambda t: t.to(dev)[None].expand(b, *t.shape).contiguous()
+    g = torch.Generator(dev).manual_seed(1)
+    batch = dict(context=dict(image=torch.rand(b, v, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=ex(sc.intrinsics[:1].expand(v, 3, 3))),
+                 target=dict(image=torch.rand(b, vt, 3, 8, 8, device=dev, generator=g).repeat_interleave(8, -1).repeat_interleave(8, -2) * 0.5 + 0.25,
+                             extrinsics=ex(sc.extrinsics), intrinsics=ex(sc.intrinsics), near=ex(sc.near), far=ex(sc.far)))
+    losses = [float(step(batch)) for _ in range(40)]
+    assert all(torch.isfinite(torch.tensor(losses)))
+    first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
+    assert last < 0.8 * first, (first, last, losses[::5])
