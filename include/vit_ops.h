@@ -97,6 +97,14 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
 int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                       int M, int N, int K, int act, void *stream);
 
+/*
+ * Weight and bias gradient of the same Linear in bf16x6 arithmetic:
+ *   dw (N,K) = dy^T (M,N)^T . x (M,K),     dbias (N) = column sums of dy   (dbias may be NULL)
+ * dy, x row-major fp32 (autograd's grad_output and the saved input); both outputs are overwritten (the call zeroes
+ * them itself when it splits M across workgroups and accumulates with fp32 atomics).
+ */
+int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

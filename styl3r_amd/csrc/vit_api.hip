@@ -14,6 +14,7 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
 int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                int K, int act, hipStream_t stream);
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
+int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
 }  // namespace vit
@@ -60,6 +61,11 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
                                  float *pre, int M, int N, int K, int act, void *stream)
 {
     return vit::linear_x6_fwd(x, w_packed, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream)
+{
+    return vit::linear_x6_wgrad(dy, x, dw, dbias, M, N, K, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

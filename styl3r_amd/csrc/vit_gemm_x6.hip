@@ -259,6 +259,137 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     }
 }
 
+
+// Weight gradient dW (N,K) = dY^T (N,M) . X (M,K) [+ bias gradient db (N) = column sums of dY] on the same bf16x6 core.
+// Both operands are activations whose contraction index m is the SLOW dimension in memory, so the loader reads them as
+// coalesced rows (lane = output row n / column k, eight 4-byte loads walk m) and the transposition happens for free in
+// the register -> LDS step: a thread's eight m-values of one column are exactly one 8-wide k group of the operand.  The
+// output is small (N x K) and the contraction long (M = 4 000..5 000), so gridDim.y workgroups split M and add their
+// partial tiles with fp32 atomics into the zeroed dW; workgroups of the first K-tile also accumulate db.
+__global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ x,
+                                                     float *__restrict__ dw, float *__restrict__ dbias, int M, int N, int K)
+{
+    constexpr int TN = 2, BN = 128;
+    __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = (K + BN - 1) / BN, tiles_n = (N + BM - 1) / BM;
+    int tn_, tk_;
+    tile_of_block(blockIdx.x, tiles_n, tiles_k, tn_, tk_);
+    const int n0 = tn_ * BM, k0 = tk_ * BN;
+
+    // slab range of this split
+    const int nslab = (M + BK - 1) / BK, S = gridDim.y, sp = blockIdx.y;
+    const int base = nslab / S, rem = nslab % S;
+    const int s_lo = sp * base + min(sp, rem), nk = base + (sp < rem ? 1 : 0);
+
+    const int c = tid & 127, g = tid >> 7;                      // column of the tile, 8-row group of the slab
+    const float *pa = dy + min(n0 + c, N - 1);                  // + m * N
+    const float *pb = x + min(k0 + c, K - 1);                   // + m * K
+    struct Stage { float a[8], b[8]; };
+    Stage st0, st1;
+    float bsum = 0.f;
+#define W6_GLOAD(S_, slab)                                                                                            \
+    do {                                                                                                              \
+        const int m_ = (s_lo + min((slab), nk - 1)) * BK + g * 8;                                                     \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                               \
+            const int mr = min(m_ + r, M - 1);                                                                        \
+            S_.a[r] = pa[(int64_t)mr * N]; S_.b[r] = pb[(int64_t)mr * K];                                             \
+        }                                                                                                             \
+    } while (0)
+#define W6_LSTORE(buf, S_, slab)                                                                                      \
+    do {                                                                                                              \
+        const int m_ = (s_lo + (slab)) * BK + g * 8;                                                                  \
+        float va[8], vb[8];                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                               \
+            const bool ok = (slab) < nk && m_ + r < M;   /* rows past M / past this split: zero (loads were clamped) */ \
+            va[r] = ok ? S_.a[r] : 0.f; vb[r] = ok ? S_.b[r] : 0.f;                                                   \
+            bsum += va[r];                                                                                            \
+        }                                                                                                             \
+        uint4 q0_, q1_, q2_;                                                                                          \
+        split8(make_float4(va[0], va[1], va[2], va[3]), make_float4(va[4], va[5], va[6], va[7]), q0_, q1_, q2_);      \
+        uint4 *p_ = sA[buf] + c * ROWQ;                                                                               \
+        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; p_[swz(c, g * 3 + 2)] = q2_;                        \
+        split8(make_float4(vb[0], vb[1], vb[2], vb[3]), make_float4(vb[4], vb[5], vb[6], vb[7]), q0_, q1_, q2_);      \
+        p_ = sB[buf] + c * ROWQ;                                                                                      \
+        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; p_[swz(c, g * 3 + 2)] = q2_;                        \
+    } while (0)
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
+    auto compute = [&](int buf) {
+        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ;
+        const uint4 *b = sB[buf] + (wn * 64 + col) * ROWQ;
+        bf16x8 fa[2][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[j * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 cc = acc[i][j];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                acc[i][j] = cc;
+            }
+    };
+
+    if (nk > 0) {
+        W6_GLOAD(st0, 0);
+        W6_GLOAD(st1, 1);
+        W6_LSTORE(0, st0, 0);
+        W6_GLOAD(st0, 2);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            compute(0);
+            W6_LSTORE(1, st1, kt + 1);
+            W6_GLOAD(st1, kt + 3);
+            __syncthreads();
+            compute(1);
+            W6_LSTORE(0, st0, kt + 2);   // (past the last slab: rows >= M of this split are masked or never read)
+            W6_GLOAD(st0, kt + 4);
+            __syncthreads();
+        }
+        if (kt < nk) compute(0);
+    }
+#undef W6_GLOAD
+#undef W6_LSTORE
+
+    // acc[i][j]: lane column = k0 + wn*64 + 32 j + col ; register r = row n0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = k0 + wn * 64 + 32 * j + col;
+        if (k >= K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n >= N) continue;
+                float *o = dw + (int64_t)n * K + k;
+                if (single) *o = acc[i][j][r]; else atomicAdd(o, acc[i][j][r]);
+            }
+        }
+    }
+    if (dbias && tk_ == 0 && n0 + c < N) atomicAdd(dbias + n0 + c, bsum);
+}
+
 // w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
 // transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
 // reads and the writes stay coalesced).
@@ -338,6 +469,22 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
         else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
 #undef VIT_LAUNCH_X6
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream)
+{
+    if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) return VIT_EINVAL;
+    const int tiles = ((N + x6::BM - 1) / x6::BM) * ((K + 127) / 128);
+    const int nslab = (M + x6::BK - 1) / x6::BK;
+    int S = 1;                                                  // split M until ~3 workgroups per CU, >= 16 slabs each
+    while (tiles * S * 2 <= 768 && nslab / (S * 2) >= 16) S *= 2;
+    (void)hipGetLastError();
+    if (S > 1 && hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

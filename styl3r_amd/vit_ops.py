@@ -24,7 +24,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -78,6 +78,8 @@ def load() -> C.CDLL:
     lib.vit_split_weight.restype = C.c_int
     lib.vit_linear_x6_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_fwd.restype = C.c_int
+    lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_x6_wgrad.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -281,9 +283,9 @@ def invalidate_split_cache() -> None:
 
 
 class _FusedLinear(torch.autograd.Function):
-    """forward on the hand-written MFMA kernels (f32 or bf16x6); backward: dX on the bf16x6 kernel with the pre-split
-    transposed weight when that mode is on, otherwise (and always for dW = dY^T X) plain library GEMMs through torch /
-    hipBLASLt."""
+    """forward on the hand-written MFMA kernels (f32 or bf16x6); backward in bf16x6 mode: dX with the pre-split transposed
+    weight, dW = dY^T X and db in one split-M pass (vit_linear_x6_wgrad); in f32 mode the backward GEMMs are plain library
+    GEMMs through torch / hipBLASLt."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act):
@@ -331,8 +333,19 @@ class _FusedLinear(torch.autograd.Function):
                 dx = dx.reshape(shp)
             else:
                 dx = (g2 @ w).reshape(shp)
-        dw = g2.t() @ x2 if need_w else None              # frozen layers (style stage) skip the weight GEMM
-        db = g2.sum(0) if (has_bias and need_b) else None
+        dw = db = None
+        if need_w and ctx.weight_ref is not None:         # dW (+ db in the same pass) on the bf16x6 kernel
+            g2c = g2.contiguous().float()
+            N, K = w.shape
+            dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
+            want_b = has_bias and need_b
+            db = torch.empty((N,), dtype=torch.float32, device=g.device) if want_b else None
+            _check(load().vit_linear_x6_wgrad(g2c.data_ptr(), x2.data_ptr(), dw.data_ptr(), db.data_ptr() if want_b else None,
+                                              g2c.shape[0], N, K, _stream(g.device)), "vit_linear_x6_wgrad")
+        else:
+            dw = g2.t() @ x2 if need_w else None          # frozen layers (style stage) skip the weight GEMM
+        if db is None and has_bias and need_b:
+            db = g2.sum(0)
         return dx, dw, db, g_res, None
 
 

@@ -43,6 +43,14 @@ for name, (M, N, K, gelu) in dict(enc_qkv=(5140, 3072, 1024, False), enc_fc1=(51
     vit_ops.LINEAR_MODE = "f32"
     ref = (lambda: torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b))) if gelu else (lambda: torch.nn.functional.linear(x, w, b))
     ms_t = timeit(ref)
+    # weight (+ bias) gradient: bf16x6 split-M kernel vs the library GEMM dY^T X plus the column-sum kernel
+    gy = torch.randn(M, N, device=dev); dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
+    import ctypes as C
+    st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms_w6 = timeit(lambda: vit_ops.load().vit_linear_x6_wgrad(gy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K, st_))
+    ms_wt = timeit(lambda: (gy.t() @ x, gy.sum(0)))
+    res["wgrad_" + name] = dict(bf16x6_ms=round(ms_w6, 4), bf16x6_TF=round(2 * M * N * K / ms_w6 / 1e9, 1), torch_ms=round(ms_wt, 4),
+                                torch_TF=round(2 * M * N * K / ms_wt / 1e9, 1))
     res["linear_" + name] = dict(ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1), bf16x6_ms=round(ms6, 4),
                                  bf16x6_TF=round(2 * M * N * K / ms6 / 1e9, 1), torch_ms=round(ms_t, 4),
                                  torch_TF=round(2 * M * N * K / ms_t / 1e9, 1))
