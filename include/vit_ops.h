@@ -105,6 +105,16 @@ int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, c
  */
 int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream);
 
+/*
+ * Convolution of the DPT heads (dpt_block.py:79-218,350-419; 3x3 pad 1 stride 1, or 1x1) as a bf16x6 implicit GEMM on NCHW
+ * fp32 tensors:  out (B,Co,H,W) = [residual +] bias + conv(f(in (B,Ci,H,W)), w),  f = ReLU if relu_in else identity
+ * (ResidualConvUnit applies its activation BEFORE each convolution, dpt_block.py:  out = conv2(act(conv1(act(x)))) + x).
+ * w_packed = vit_split_weight of the weight rearranged to (Co, ksize*ksize*Ci) with k = tap * Ci + ci, tap = ky * ksize + kx.
+ * The same entry computes the input gradient from the spatially flipped, channel-transposed weight.  Ci % 16 == 0.
+ */
+int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, const float *residual, float *out, int B, int Ci,
+                    int Co, int H, int W, int ksize, int relu_in, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

@@ -14,6 +14,8 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
 int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                int K, int act, hipStream_t stream);
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
+int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float *residual, float *out, int B, int Ci, int Co,
+                int H, int W, int ksize, int relu_in, hipStream_t stream);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
@@ -66,6 +68,12 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
 VIT_EXPORT int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream)
 {
     return vit::linear_x6_wgrad(dy, x, dw, dbias, M, N, K, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, const float *residual, float *out,
+                               int B, int Ci, int Co, int H, int W, int ksize, int relu_in, void *stream)
+{
+    return vit::conv_x6_fwd(in, w_packed, bias, residual, out, B, Ci, Co, H, W, ksize, relu_in, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

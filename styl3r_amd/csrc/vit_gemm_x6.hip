@@ -390,6 +390,146 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
     if (dbias && tk_ == 0 && n0 + c < N) atomicAdd(dbias + n0 + c, bsum);
 }
 
+// 3x3 (pad 1, stride 1) and 1x1 convolution of the DPT heads (E9) as an implicit GEMM on the same bf16x6 core:
+//     out[b][co][y][x] = bias[co] + sum_{tap, ci} w[co][tap][ci] * f(in[b][ci][y + ky - 1][x + kx - 1]),   f = id or ReLU
+// GEMM view: A rows = output channels (the pre-split weight, k = tap * Ci + ci, loaded like the Linear's weight),
+// B rows = output pixels, K = taps * Ci.  NCHW activations need no im2col and no layout change: the B loader is the
+// transposing loader of the weight-gradient kernel (lane = pixel, eight 4-byte loads walk the channels of one tap, lanes
+// are consecutive pixels = consecutive addresses), borders are clamped addresses + a zero mask.  D[co][pixel] has the
+// pixel on the lane, so every accumulator register stores a coalesced run of one output channel.
+template <int KS, bool RELU_IN>
+__global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in, const uint4 *__restrict__ wp,
+                                                    const float *__restrict__ bias, const float *__restrict__ residual,
+                                                    float *__restrict__ out, int B, int Ci, int Co, int H, int W)
+{
+    constexpr int TN = 2, BN = 128, TAPS = KS * KS;
+    __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HW = H * W;
+    const int64_t NP = (int64_t)B * HW;
+    const int tiles_m = (Co + BM - 1) / BM, tiles_n = (int)((NP + BN - 1) / BN);
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int co0 = tm * BM;
+    const int64_t p0 = (int64_t)tn * BN;
+    const int K = TAPS * Ci, KG = K >> 3, nk = K / BK;
+
+    // A loader (weights): thread -> (row, k group), three 16-byte pieces
+    const int lrow = tid >> 1, kg = tid & 1;
+    const uint4 *wa = wp + ((int64_t)min(co0 + lrow, Co - 1) * KG + kg) * 3;
+    // B loader (activations): thread -> (pixel of the tile, 8-channel group)
+    const int c = tid & 127, g = tid >> 7;
+    const int64_t pc = min(p0 + c, NP - 1);
+    const int pb = (int)(pc / HW), pr = (int)(pc - (int64_t)pb * HW), py = pr / W, px = pr - py * W;
+    const float *inb = in + (int64_t)pb * Ci * HW;
+
+    // two register stages, written out as scalars (a struct with mixed members ended up in scratch memory)
+    uint4 a0_0, a1_0, a2_0, a0_1, a1_1, a2_1;
+    float b0_0, b1_0, b2_0, b3_0, b4_0, b5_0, b6_0, b7_0, b0_1, b1_1, b2_1, b3_1, b4_1, b5_1, b6_1, b7_1, m_0, m_1;
+    const int64_t HW64 = HW;
+    const int spt = Ci / BK;                                           // slabs per tap
+    const float *in_g = inb + (int64_t)(g * 8) * HW;
+#define C6_GLOAD(T, slab)                                                                                             \
+    do {                                                                                                              \
+        const int sl_ = min((slab), nk - 1);                                                                          \
+        const uint4 *q_ = wa + sl_ * 6; a0_##T = q_[0]; a1_##T = q_[1]; a2_##T = q_[2];                               \
+        const int tap = sl_ / spt, ci = (sl_ - tap * spt) * BK;                                                       \
+        const int ky_ = KS == 3 ? (tap * 11) >> 5 : 0, kx_ = KS == 3 ? tap - 3 * ky_ : 0;                             \
+        const int ys = py + (KS == 3 ? ky_ - 1 : 0), xs = px + (KS == 3 ? kx_ - 1 : 0);                               \
+        m_##T = (ys >= 0 && ys < H && xs >= 0 && xs < W) ? 1.f : 0.f;                                                 \
+        const float *s_ = in_g + (int64_t)ci * HW64 + (min(max(ys, 0), H - 1) * W + min(max(xs, 0), W - 1));         \
+        b0_##T = s_[0]; b1_##T = s_[HW64]; b2_##T = s_[2 * HW64]; b3_##T = s_[3 * HW64];                              \
+        b4_##T = s_[4 * HW64]; b5_##T = s_[5 * HW64]; b6_##T = s_[6 * HW64]; b7_##T = s_[7 * HW64];                   \
+    } while (0)
+#define C6_LSTORE(buf, T)                                                                                             \
+    do {                                                                                                              \
+        uint4 *pa_ = sA[buf] + lrow * ROWQ;                                                                           \
+        pa_[swz(lrow, kg * 3 + 0)] = a0_##T; pa_[swz(lrow, kg * 3 + 1)] = a1_##T; pa_[swz(lrow, kg * 3 + 2)] = a2_##T; \
+        const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = m_##T;   /* border taps contribute zero (clamped loads) */    \
+        uint4 q0_, q1_, q2_;                                                                                          \
+        split8(make_float4(fmaxf(b0_##T, lo_) * mm_, fmaxf(b1_##T, lo_) * mm_, fmaxf(b2_##T, lo_) * mm_, fmaxf(b3_##T, lo_) * mm_), \
+               make_float4(fmaxf(b4_##T, lo_) * mm_, fmaxf(b5_##T, lo_) * mm_, fmaxf(b6_##T, lo_) * mm_, fmaxf(b7_##T, lo_) * mm_), \
+               q0_, q1_, q2_);                                                                                        \
+        uint4 *pb_ = sB[buf] + c * ROWQ;                                                                              \
+        pb_[swz(c, g * 3 + 0)] = q0_; pb_[swz(c, g * 3 + 1)] = q1_; pb_[swz(c, g * 3 + 2)] = q2_;                     \
+    } while (0)
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
+    auto compute = [&](int buf) {
+        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ;
+        const uint4 *b = sB[buf] + (wn * 64 + col) * ROWQ;
+        bf16x8 fa[2][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[j * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 cc = acc[i][j];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                acc[i][j] = cc;
+            }
+    };
+
+    C6_GLOAD(0, 0);
+    C6_GLOAD(1, 1);
+    C6_LSTORE(0, 0);
+    C6_GLOAD(0, 2);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        compute(0);
+        C6_LSTORE(1, 1);
+        C6_GLOAD(1, kt + 3);
+        __syncthreads();
+        compute(1);
+        C6_LSTORE(0, 0);
+        C6_GLOAD(0, kt + 4);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+#undef C6_GLOAD
+#undef C6_LSTORE
+
+    // acc[i][j]: lane = pixel p0 + wn*64 + 32 j + col ; register r = channel co0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t p = p0 + wn * 64 + 32 * j + col;
+        if (p >= NP) continue;
+        const int b_ = (int)(p / HW);
+        const int64_t obase = (int64_t)b_ * Co * HW + (p - (int64_t)b_ * HW);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co >= Co) continue;
+                const int64_t o = obase + (int64_t)co * HW;
+                float t = acc[i][j][r] + (bias ? bias[co] : 0.f);
+                if (residual) t += residual[o];
+                out[o] = t;
+            }
+        }
+    }
+}
+
 // w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
 // transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
 // reads and the writes stay coalesced).
@@ -485,6 +625,24 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     if (S > 1 && hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float *residual, float *out, int B, int Ci, int Co,
+                int H, int W, int ksize, int relu_in, hipStream_t stream)
+{
+    if (!in || !wp || !out || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return VIT_EINVAL;
+    if ((ksize != 1 && ksize != 3) || (Ci % x6::BK) != 0) return VIT_EINVAL;
+    const int64_t NP = (int64_t)B * H * W;
+    const int64_t tiles = (int64_t)((Co + x6::BM - 1) / x6::BM) * ((NP + 127) / 128);
+    if (tiles > 0x7fffffff) return VIT_EINVAL;
+    const uint4 *w4 = static_cast<const uint4 *>(wp);
+    (void)hipGetLastError();
+#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W)
+    if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
+    else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
+#undef VIT_LAUNCH_C6
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

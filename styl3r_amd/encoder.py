@@ -26,6 +26,7 @@ from torch import Tensor, nn
 
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
+from .vit_ops import Conv2dX6
 
 inf = float("inf")
 
@@ -240,8 +241,8 @@ class TokenStylizer(CrocoTrunk):
 class _ResidualConvUnit(nn.Module):
     def __init__(self, features):
         super().__init__()
-        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
-        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv1 = Conv2dX6(features, features, 3, 1, 1, bias=True)
+        self.conv2 = Conv2dX6(features, features, 3, 1, 1, bias=True)
 
     def forward(self, x):
         out = self.conv1(F.relu(x))
@@ -252,7 +253,7 @@ class _ResidualConvUnit(nn.Module):
 class _FusionBlock(nn.Module):
     def __init__(self, features):
         super().__init__()
-        self.out_conv = nn.Conv2d(features, features, 1, bias=True)
+        self.out_conv = Conv2dX6(features, features, 1, bias=True)
         self.resConfUnit1 = _ResidualConvUnit(features)
         self.resConfUnit2 = _ResidualConvUnit(features)
 
@@ -277,30 +278,30 @@ class DPTAdapter(nn.Module):
         super().__init__()
         self.hooks, self.kind = list(hooks), kind
         sc = nn.Module()
-        sc.layer1_rn = nn.Conv2d(layer_dims[0], feature_dim, 3, 1, 1, bias=False)
-        sc.layer2_rn = nn.Conv2d(layer_dims[1], feature_dim, 3, 1, 1, bias=False)
-        sc.layer3_rn = nn.Conv2d(layer_dims[2], feature_dim, 3, 1, 1, bias=False)
-        sc.layer4_rn = nn.Conv2d(layer_dims[3], feature_dim, 3, 1, 1, bias=False)
+        sc.layer1_rn = Conv2dX6(layer_dims[0], feature_dim, 3, 1, 1, bias=False)
+        sc.layer2_rn = Conv2dX6(layer_dims[1], feature_dim, 3, 1, 1, bias=False)
+        sc.layer3_rn = Conv2dX6(layer_dims[2], feature_dim, 3, 1, 1, bias=False)
+        sc.layer4_rn = Conv2dX6(layer_dims[3], feature_dim, 3, 1, 1, bias=False)
         sc.layer_rn = nn.ModuleList([sc.layer1_rn, sc.layer2_rn, sc.layer3_rn, sc.layer4_rn])   # same tensors, both key sets
         sc.refinenet1, sc.refinenet2 = _FusionBlock(feature_dim), _FusionBlock(feature_dim)
         sc.refinenet3, sc.refinenet4 = _FusionBlock(feature_dim), _FusionBlock(feature_dim)
         self.scratch = sc
         if kind == "pts3d":     # 'regression' head (dpt_block.py:313-321)
-            self.head = nn.Sequential(nn.Conv2d(feature_dim, feature_dim // 2, 3, 1, 1), _Up2(),
-                                      nn.Conv2d(feature_dim // 2, last_dim, 3, 1, 1), nn.ReLU(True),
-                                      nn.Conv2d(last_dim, num_channels, 1))
+            self.head = nn.Sequential(Conv2dX6(feature_dim, feature_dim // 2, 3, 1, 1), _Up2(),
+                                      Conv2dX6(feature_dim // 2, last_dim, 3, 1, 1), nn.ReLU(True),
+                                      Conv2dX6(last_dim, num_channels, 1))
         else:                   # 'gs_params' head (:332-340)
-            self.head = nn.Sequential(nn.Conv2d(feature_dim, feature_dim, 3, padding=1, bias=False), nn.Identity(),
-                                      nn.ReLU(True), nn.Dropout(0.1, False), nn.Conv2d(feature_dim, num_channels, 1))
+            self.head = nn.Sequential(Conv2dX6(feature_dim, feature_dim, 3, padding=1, bias=False), nn.Identity(),
+                                      nn.ReLU(True), nn.Dropout(0.1, False), Conv2dX6(feature_dim, num_channels, 1))
         d = list(dim_tokens)
         self.act_postprocess = nn.ModuleList([
-            nn.Sequential(nn.Conv2d(d[0], layer_dims[0], 1), nn.ConvTranspose2d(layer_dims[0], layer_dims[0], 4, 4)),
-            nn.Sequential(nn.Conv2d(d[1], layer_dims[1], 1), nn.ConvTranspose2d(layer_dims[1], layer_dims[1], 2, 2)),
-            nn.Sequential(nn.Conv2d(d[2], layer_dims[2], 1)),
-            nn.Sequential(nn.Conv2d(d[3], layer_dims[3], 1), nn.Conv2d(layer_dims[3], layer_dims[3], 3, 2, 1)),
+            nn.Sequential(Conv2dX6(d[0], layer_dims[0], 1), nn.ConvTranspose2d(layer_dims[0], layer_dims[0], 4, 4)),
+            nn.Sequential(Conv2dX6(d[1], layer_dims[1], 1), nn.ConvTranspose2d(layer_dims[1], layer_dims[1], 2, 2)),
+            nn.Sequential(Conv2dX6(d[2], layer_dims[2], 1)),
+            nn.Sequential(Conv2dX6(d[3], layer_dims[3], 1), Conv2dX6(layer_dims[3], layer_dims[3], 3, 2, 1)),
         ])
         if kind == "gs":
-            self.input_merger = nn.Sequential(nn.Conv2d(3, 256, 7, 1, 3), nn.ReLU())
+            self.input_merger = nn.Sequential(Conv2dX6(3, 256, 7, 1, 3), nn.ReLU())
 
     def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None) -> Tensor:
         H, W = image_size

@@ -24,7 +24,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -80,6 +80,8 @@ def load() -> C.CDLL:
     lib.vit_linear_x6_fwd.restype = C.c_int
     lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_wgrad.restype = C.c_int
+    lib.vit_conv_x6_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_conv_x6_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -276,6 +278,97 @@ def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
             del _SPLIT_CACHE[k]
     _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
     return packed
+
+
+def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
+    """bf16x3 split of a conv weight (Co,Ci,k,k) rearranged for vit_conv_x6_fwd: (Co, k*k*Ci) with k index = tap*Ci + ci;
+    `for_input_grad`: the spatially flipped, channel-transposed weight (Ci, k*k*Co) whose convolution with dY is dX.
+    Cached like `split_weight` (weak reference + version counter of the ORIGINAL parameter)."""
+    key = (id(weight), "conv_dx" if for_input_grad else "conv")
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    lib = load()
+    w = weight.detach().float()
+    Co, Ci, kh, kw = w.shape
+    if for_input_grad:
+        w2 = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
+    else:
+        w2 = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
+    R, Kc = w2.shape
+    packed = torch.empty(lib.vit_split_weight_bytes(R, Kc), dtype=torch.uint8, device=weight.device)
+    _check(lib.vit_split_weight(w2.data_ptr(), packed.data_ptr(), R, Kc, 0, _stream(weight.device)), "vit_split_weight")
+    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
+    return packed
+
+
+def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+                    relu_in: bool = False, packed: Optional[Tensor] = None) -> Tensor:
+    """out = [residual +] bias + conv2d(relu?(x), weight, padding=k//2) on vit_conv_x6_fwd (no autograd)."""
+    B, Ci, H, W = x.shape
+    Co, _, k, _ = weight.shape
+    x = x.contiguous().float()
+    out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
+    wp = packed if packed is not None else split_conv_weight(weight)
+    res = residual.contiguous().float() if residual is not None else None
+    _check(load().vit_conv_x6_fwd(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                  res.data_ptr() if res is not None else None, out.data_ptr(), B, Ci, Co, H, W, k,
+                                  1 if relu_in else 0, _stream(x.device)), "vit_conv_x6_fwd")
+    return out
+
+
+class _ConvX6(torch.autograd.Function):
+    """conv2d (3x3 pad 1 / 1x1, stride 1) on the bf16x6 implicit-GEMM kernel: forward and input gradient hand-written
+    (dX = the same kernel on the flipped, channel-transposed weight); the weight / bias gradients go through the library
+    (aten::convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, "conv2d")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return conv_x6_forward(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous().float()
+        k = weight.shape[2]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = None
+        if need_x:
+            if weight.shape[0] % 16 == 0 and weight.shape[1] >= 64:
+                B, Co, H, W = g.shape
+                Ci = weight.shape[1]
+                dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
+                _check(load().vit_conv_x6_fwd(g.data_ptr(), split_conv_weight(weight, True).data_ptr(), None, None, dx.data_ptr(),
+                                              B, Co, Ci, H, W, k, 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
+            else:
+                dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                                         [True, False, False])[0]
+        dw = db = None
+        if need_w or need_b:
+            _, dw, db = torch.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
+                                                            [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
+        return dx, dw, db
+
+
+class Conv2dX6(nn.Conv2d):
+    """nn.Conv2d whose forward / input gradient run on vit_conv_x6_fwd when the layer qualifies (k in {1, 3}, stride 1,
+    padding k // 2, no dilation / groups, Ci % 16 == 0, Co >= 64) and the input is a device fp32 tensor in bf16x6 mode;
+    otherwise the stock MIOpen path.  Same parameters / state_dict keys as nn.Conv2d."""
+
+    def _x6_ok(self, x: Tensor) -> bool:
+        k = self.kernel_size[0]
+        return (LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.padding == (k // 2, k // 2)
+                and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
+                and self.in_channels % 16 == 0 and self.out_channels >= 64)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self._x6_ok(x):
+            return _ConvX6.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 def invalidate_split_cache() -> None:

@@ -237,3 +237,27 @@ def test_split_cache_never_serves_a_dead_tensors_entry():
         p0 = _unpack_split(split_weight(w), 32, 64)[0]
         assert float(p0[0, 0]) == float(i + 1)
         del w, p0
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,k,bias", [(2, 32, 64, 9, 13, 3, True), (1, 16, 130, 17, 5, 3, False), (3, 48, 128, 8, 8, 1, True),
+                                                 (2, 256, 256, 32, 32, 3, True), (1, 96, 256, 16, 24, 3, False)])
+def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias):
+    """Conv2dX6 (bf16x6 implicit GEMM: forward + input gradient; library weight gradient) vs an fp64 convolution"""
+    from styl3r_amd.vit_ops import Conv2dX6
+    torch.manual_seed(B * 100 + Ci)
+    m = Conv2dX6(Ci, Co, k, 1, k // 2, bias=bias).to(DEV)
+    assert m._x6_ok(torch.empty(1, Ci, 4, 4, device=DEV))
+    x = torch.randn(B, Ci, H, W, device=DEV, requires_grad=True)
+    y = m(x)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd = m.weight.detach().double().requires_grad_(True)
+    bd = m.bias.detach().double().requires_grad_(True) if bias else None
+    ref = torch.nn.functional.conv2d(xd, wd, bd, padding=k // 2)
+    (ref * gy.double()).sum().backward()
+    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 3e-6, "conv fwd")
+    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 3e-6, "conv dx")
+    assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 2e-5, "conv dw")
+    if bias:
+        assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 2e-5, "conv db")
