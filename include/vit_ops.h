@@ -115,6 +115,13 @@ int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias
 int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, const float *residual, float *out, int B, int Ci,
                     int Co, int H, int W, int ksize, int relu_in, void *stream);
 
+/*
+ * Weight / bias gradient of that convolution: dw (Co,Ci,k,k) and dbias (Co, may be NULL) from dy (B,Co,H,W) and the
+ * forward input `in` (B,Ci,H,W) [through ReLU if relu_in]; both outputs are overwritten.  W % 8 == 0, (H*W) % 16 == 0.
+ */
+int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
+                      int relu_in, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

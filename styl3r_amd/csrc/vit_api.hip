@@ -16,6 +16,8 @@ int linear_fwd(const float *x, const float *w, const float *bias, const float *r
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
 int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float *residual, float *out, int B, int Ci, int Co,
                 int H, int W, int ksize, int relu_in, hipStream_t stream);
+int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
+                  int relu_in, hipStream_t stream);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
@@ -74,6 +76,12 @@ VIT_EXPORT int vit_conv_x6_fwd(const float *in, const void *w_packed, const floa
                                int B, int Ci, int Co, int H, int W, int ksize, int relu_in, void *stream)
 {
     return vit::conv_x6_fwd(in, w_packed, bias, residual, out, B, Ci, Co, H, W, ksize, relu_in, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W,
+                                 int ksize, int relu_in, void *stream)
+{
+    return vit::conv_x6_wgrad(dy, in, dw, dbias, B, Ci, Co, H, W, ksize, relu_in, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

@@ -530,6 +530,159 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
     }
 }
 
+// Weight (+ bias) gradient of that convolution:  dw[co][ci][tap] = sum_{b,y,x} dy[b][co][y][x] * f(in[b][ci][y+ky-1][x+kx-1]).
+// GEMM view: A rows = co, B rows = r = tap * Ci + ci, contraction = the B*H*W output pixels, which are the CONTIGUOUS
+// dimension of both operands (NCHW): both loaders are the Linear kernel's activation loader (thread = (row, 8-pixel
+// group), 32 contiguous bytes), the tap shift is an offset on the B pointer plus a zero mask on the row / the first or
+// last pixel of an image row.  The contraction is 10^5 pixels long and the output 256 x 2 304: gridDim.y workgroups
+// split the pixels and accumulate with fp32 atomics into the zeroed dw (and db from the row sums of dy).
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load with 4-byte alignment (tap shift +-1)
+
+template <int KS, bool RELU_IN>
+__global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ in,
+                                                          float *__restrict__ dw, float *__restrict__ dbias, int B, int Ci,
+                                                          int Co, int H, int W)
+{
+    constexpr int TN = 2, BN = 128, TAPS = KS * KS;
+    __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HW = H * W, R = TAPS * Ci;
+    const int tiles_m = (Co + BM - 1) / BM, tiles_n = (R + BN - 1) / BN;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int co0 = tm * BM, r0 = tn * BN;
+
+    const int spi = HW / BK;                                   // slabs per image
+    const int nslab = B * spi, S = gridDim.y, sp = blockIdx.y;
+    const int base = nslab / S, rem = nslab % S;
+    const int s_lo = sp * base + min(sp, rem), nk = base + (sp < rem ? 1 : 0);
+
+    const int lrow = tid >> 1, kg = tid & 1;
+    // A: dy row co, 8 pixels;  B: in row (tap, ci) shifted by the tap, 8 pixels
+    const int co = min(co0 + lrow, Co - 1);
+    const int r = min(r0 + lrow, R - 1), tap = r / Ci, ci = r - tap * Ci;
+    const int ky = KS == 3 ? tap / 3 - 1 : 0, kx = KS == 3 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int64_t total_in = (int64_t)B * Ci * HW;
+    float4 a0_0, a1_0, a0_1, a1_1;
+    f4u b0_0, b1_0, b0_1, b1_1;
+    float my_0, my_1;      // row-validity mask of the stage (the 8 pixels of a group share one image row: W % 8 == 0)
+    int x0_0, x0_1;
+    float bsum = 0.f;
+#define G6_GLOAD(T, slab)                                                                                             \
+    do {                                                                                                              \
+        const int sl_ = s_lo + min((slab), nk - 1);                                                                   \
+        const int b_ = sl_ / spi, q_ = (sl_ - b_ * spi) * BK + kg * 8;          /* first pixel of the group */          \
+        const float *pa_ = dy + ((int64_t)b_ * Co + co) * HW + q_;                                                    \
+        a0_##T = *reinterpret_cast<const float4 *>(pa_); a1_##T = *reinterpret_cast<const float4 *>(pa_ + 4);         \
+        const int y_ = q_ / W, xx_ = q_ - y_ * W;                                                                     \
+        my_##T = (y_ + ky >= 0 && y_ + ky < H) ? 1.f : 0.f;                                                           \
+        x0_##T = xx_ + kx;                                                                                            \
+        int64_t o_ = ((int64_t)b_ * Ci + ci) * HW + q_ + ky * W + kx;                                                 \
+        /* the +-1 tap shift can start one element before / end one element after the tensor: load the clamped run and  \
+           slide it back (every other out-of-range run belongs to a masked row: only its address has to be legal) */    \
+        const bool lo1_ = o_ == -1, hi1_ = o_ == total_in - 7;                                                        \
+        o_ = min(max(o_, (int64_t)0), total_in - 8);                                                                  \
+        const f4u u0_ = *reinterpret_cast<const f4u *>(in + o_), u1_ = *reinterpret_cast<const f4u *>(in + o_ + 4);   \
+        b0_##T.x = lo1_ ? 0.f : (hi1_ ? u0_.y : u0_.x); b0_##T.y = lo1_ ? u0_.x : (hi1_ ? u0_.z : u0_.y);             \
+        b0_##T.z = lo1_ ? u0_.y : (hi1_ ? u0_.w : u0_.z); b0_##T.w = lo1_ ? u0_.z : (hi1_ ? u1_.x : u0_.w);           \
+        b1_##T.x = lo1_ ? u0_.w : (hi1_ ? u1_.y : u1_.x); b1_##T.y = lo1_ ? u1_.x : (hi1_ ? u1_.z : u1_.y);           \
+        b1_##T.z = lo1_ ? u1_.y : (hi1_ ? u1_.w : u1_.z); b1_##T.w = lo1_ ? u1_.z : (hi1_ ? 0.f : u1_.w);             \
+    } while (0)
+#define G6_LSTORE(buf, T, slab)                                                                                       \
+    do {                                                                                                              \
+        const float live_ = (slab) < nk ? 1.f : 0.f;                                                                  \
+        const float4 va0 = make_float4(a0_##T.x * live_, a0_##T.y * live_, a0_##T.z * live_, a0_##T.w * live_);       \
+        const float4 va1 = make_float4(a1_##T.x * live_, a1_##T.y * live_, a1_##T.z * live_, a1_##T.w * live_);       \
+        bsum += (va0.x + va0.y) + (va0.z + va0.w) + (va1.x + va1.y) + (va1.z + va1.w);                                 \
+        uint4 q0_, q1_, q2_;                                                                                          \
+        split8(va0, va1, q0_, q1_, q2_);                                                                              \
+        uint4 *pa2_ = sA[buf] + lrow * ROWQ;                                                                          \
+        pa2_[swz(lrow, kg * 3 + 0)] = q0_; pa2_[swz(lrow, kg * 3 + 1)] = q1_; pa2_[swz(lrow, kg * 3 + 2)] = q2_;      \
+        const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = my_##T;                                                     \
+        const float m0_ = (x0_##T >= 0) ? mm_ : 0.f, m7_ = (x0_##T + 7 < W) ? mm_ : 0.f;   /* only the ends can leave the row */ \
+        split8(make_float4(fmaxf(b0_##T.x, lo_) * m0_, fmaxf(b0_##T.y, lo_) * mm_, fmaxf(b0_##T.z, lo_) * mm_, fmaxf(b0_##T.w, lo_) * mm_), \
+               make_float4(fmaxf(b1_##T.x, lo_) * mm_, fmaxf(b1_##T.y, lo_) * mm_, fmaxf(b1_##T.z, lo_) * mm_, fmaxf(b1_##T.w, lo_) * m7_), \
+               q0_, q1_, q2_);                                                                                        \
+        uint4 *pb2_ = sB[buf] + lrow * ROWQ;                                                                          \
+        pb2_[swz(lrow, kg * 3 + 0)] = q0_; pb2_[swz(lrow, kg * 3 + 1)] = q1_; pb2_[swz(lrow, kg * 3 + 2)] = q2_;      \
+    } while (0)
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
+    auto compute = [&](int buf) {
+        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ;
+        const uint4 *b = sB[buf] + (wn * 64 + col) * ROWQ;
+        bf16x8 fa[2][3], fb[TN][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[j * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 cc = acc[i][j];
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                acc[i][j] = cc;
+            }
+    };
+
+    if (nk > 0) {
+        G6_GLOAD(0, 0);
+        G6_GLOAD(1, 1);
+        G6_LSTORE(0, 0, 0);
+        G6_GLOAD(0, 2);
+        __syncthreads();
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            compute(0);
+            G6_LSTORE(1, 1, kt + 1);
+            G6_GLOAD(1, kt + 3);
+            __syncthreads();
+            compute(1);
+            G6_LSTORE(0, 0, kt + 2);
+            G6_GLOAD(0, kt + 4);
+            __syncthreads();
+        }
+        if (kt < nk) compute(0);
+    }
+#undef G6_GLOAD
+#undef G6_LSTORE
+
+    // acc[i][j]: lane = r0 + wn*64 + 32 j + col (tap, ci) ; register rr = co0 + wm*64 + 32 i + (rr&3) + 8 (rr>>2) + 4 half
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int rr_ = r0 + wn * 64 + 32 * j + col;
+        if (rr_ >= R) continue;
+        const int tp = rr_ / Ci, c_ = rr_ - tp * Ci;
+        float *o = dw + (int64_t)c_ * TAPS + tp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co_ = co0 + wm * 64 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * half;
+                if (co_ >= Co) continue;
+                atomicAdd(o + (int64_t)co_ * Ci * TAPS, acc[i][j][q]);
+            }
+        }
+    }
+    if (dbias && tn == 0 && co0 + lrow < Co) atomicAdd(dbias + co0 + lrow, bsum);
+}
+
 // w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
 // transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
 // reads and the writes stay coalesced).
@@ -564,6 +717,23 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
     o[0] = q0; o[1] = q1; o[2] = q2;
 }
 }  // namespace x6
+
+// number of contraction splits for the weight-gradient kernels (2 resident workgroups per CU): one full round of 512
+// workgroups when the tiles alone are fewer, otherwise whole multiples are left to the tile count; >= min_slabs per split
+static int split_count(int tiles, int nslab, int min_slabs)
+{
+    // pick S in 1..128 that fills whole rounds of the 512 resident workgroups best; every extra split costs another pass
+    // of atomics over the output tile (-1 % per split in the score)
+    int best = 1;
+    float best_score = -1.f;
+    for (int S = 1; S <= 128; ++S) {
+        if (S > 1 && nslab / S < min_slabs) break;
+        const int wg = tiles * S, rounds = (wg + 511) / 512;
+        const float score = (float)wg / (float)(rounds * 512) - 0.002f * (float)S;
+        if (score > best_score) { best_score = score; best = S; }
+    }
+    return best;
+}
 
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream)
 {
@@ -619,8 +789,8 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) return VIT_EINVAL;
     const int tiles = ((N + x6::BM - 1) / x6::BM) * ((K + 127) / 128);
     const int nslab = (M + x6::BK - 1) / x6::BK;
-    int S = 1;                                                  // split M until ~3 workgroups per CU, >= 16 slabs each
-    while (tiles * S * 2 <= 768 && nslab / (S * 2) >= 16) S *= 2;
+    // split M so that tiles x S fills the 512 resident workgroups (256 CUs x 2) ONCE: 1.1 rounds cost as much as 2
+    int S = split_count(tiles, nslab, 16);
     (void)hipGetLastError();
     if (S > 1 && hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
@@ -643,6 +813,26 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
     else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
 #undef VIT_LAUNCH_C6
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
+                  int relu_in, hipStream_t stream)
+{
+    if (!dy || !in || !dw || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return VIT_EINVAL;
+    if ((ksize != 1 && ksize != 3) || (W % 8) != 0 || ((H * W) % x6::BK) != 0 || (int64_t)B * Ci * H * W < 8) return VIT_EINVAL;
+    const int R = ksize * ksize * Ci;
+    const int tiles = ((Co + x6::BM - 1) / x6::BM) * ((R + 127) / 128);
+    const int nslab = B * (H * W / x6::BK);
+    int S = split_count(tiles, nslab, 32);
+    (void)hipGetLastError();
+    if (hipMemsetAsync(dw, 0, (size_t)Co * R * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+#define VIT_LAUNCH_G6(KS, RL) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W)
+    if (ksize == 3) { if (relu_in) VIT_LAUNCH_G6(3, true); else VIT_LAUNCH_G6(3, false); }
+    else { if (relu_in) VIT_LAUNCH_G6(1, true); else VIT_LAUNCH_G6(1, false); }
+#undef VIT_LAUNCH_G6
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

@@ -24,7 +24,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.vit_linear_x6_wgrad.restype = C.c_int
     lib.vit_conv_x6_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_conv_x6_fwd.restype = C.c_int
+    lib.vit_conv_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_conv_x6_wgrad.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -347,7 +349,16 @@ class _ConvX6(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
         dw = db = None
-        if need_w or need_b:
+        B_, _, H_, W_ = g.shape
+        # dW (+ db) on the bf16x6 split-pixel kernel when there are enough pixels to split (>= 64 x 64 x 16; below that the
+        # library's kernel is faster: measured)
+        if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and B_ * H_ * W_ >= 65536:
+            dw = torch.empty_like(weight, dtype=torch.float32)
+            db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
+            xc = x.contiguous().float()
+            _check(load().vit_conv_x6_wgrad(g.data_ptr(), xc.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
+                                            B_, weight.shape[1], weight.shape[0], H_, W_, k, 0, _stream(g.device)), "vit_conv_x6_wgrad")
+        elif need_w or need_b:
             _, dw, db = torch.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
                                                             [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
         return dx, dw, db

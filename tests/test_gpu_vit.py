@@ -261,3 +261,19 @@ def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias):
     assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 2e-5, "conv dw")
     if bias:
         assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 2e-5, "conv db")
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,k", [(16, 32, 64, 64, 64, 3), (4, 48, 130, 128, 128, 1), (17, 16, 64, 64, 64, 3)])
+def test_conv_x6_weight_gradient_kernel_matches_fp64(B, Ci, Co, H, W, k):
+    """enough pixels (>= 65 536) for Conv2dX6's backward to take vit_conv_x6_wgrad: dW and db vs fp64"""
+    from styl3r_amd.vit_ops import Conv2dX6
+    torch.manual_seed(B + Ci)
+    m = Conv2dX6(Ci, Co, k, 1, k // 2, bias=True).to(DEV)
+    x = torch.randn(B, Ci, H, W, device=DEV)
+    y = m(x)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    wd = m.weight.detach().double().requires_grad_(True); bd = m.bias.detach().double().requires_grad_(True)
+    (torch.nn.functional.conv2d(x.double(), wd, bd, padding=k // 2) * gy.double()).sum().backward()
+    assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 5e-6, "conv dw (x6)")
+    assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 5e-6, "conv db (x6)")
