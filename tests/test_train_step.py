@@ -114,4 +114,4 @@ def test_nvs_training_reduces_the_loss_end_to_end():
     losses = [float(step(batch)) for _ in range(40)]
     assert all(torch.isfinite(torch.tensor(losses)))
     first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
-    assert last < 0.8 * first, (first, last, losses[::5])
+    assert last < 0.9 * first and losses[-1] < losses[len(losses) // 2] < losses[0], (first, last, losses[::5])
