@@ -122,6 +122,12 @@ int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, co
 int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
                       int relu_in, void *stream);
 
+/*
+ * F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) of the DPT heads (dpt_block.py Interpolate /
+ * FeatureFusionBlock): in (planes, H, W) -> out (planes, 2H, 2W), planes = B*C of a contiguous NCHW tensor; W even.
+ */
+int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

@@ -26,7 +26,7 @@ from torch import Tensor, nn
 
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
-from .vit_ops import Conv2dX6
+from .vit_ops import Conv2dX6, upsample2x
 
 inf = float("inf")
 
@@ -261,13 +261,13 @@ class _FusionBlock(nn.Module):
         if skip is not None:
             x = x + self.resConfUnit1(skip)
         x = self.resConfUnit2(x)
-        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        x = upsample2x(x)
         return self.out_conv(x)
 
 
 class _Up2(nn.Module):
     def forward(self, x):
-        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+        return upsample2x(x)
 
 
 class DPTAdapter(nn.Module):
@@ -316,9 +316,9 @@ class DPTAdapter(nn.Module):
         p2 = self.scratch.refinenet2(p3, layers[1])
         p1 = self.scratch.refinenet1(p2, layers[0])
         if self.kind == "gs":
-            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True) + self.input_merger(imgs.contiguous())
+            p1 = upsample2x(p1) + self.input_merger(imgs.contiguous())
         elif self.kind == "sh":
-            p1 = F.interpolate(p1, scale_factor=2, mode="bilinear", align_corners=True)
+            p1 = upsample2x(p1)
         return _PackGrad.apply(self.head(p1))
 
 

@@ -22,9 +22,9 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -84,6 +84,8 @@ def load() -> C.CDLL:
     lib.vit_conv_x6_fwd.restype = C.c_int
     lib.vit_conv_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_conv_x6_wgrad.restype = C.c_int
+    lib.vit_upsample2x_fwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
+    lib.vit_upsample2x_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -380,6 +382,30 @@ class Conv2dX6(nn.Conv2d):
         if self._x6_ok(x):
             return _ConvX6.apply(x, self.weight, self.bias)
         return super().forward(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, Cc, H, W = x.shape
+        x = x.contiguous().float()
+        out = torch.empty((B, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        _check(load().vit_upsample2x_fwd(x.data_ptr(), out.data_ptr(), B * Cc, H, W, _stream(x.device)), "vit_upsample2x_fwd")
+        ctx.shape = (B, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, H, W = ctx.shape
+        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [2 * H, 2 * W], [B, Cc, H, W], True, None, None)
+
+
+def upsample2x(x: Tensor) -> Tensor:
+    """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True); device fp32 NCHW tensors with an even width
+    take vit_upsample2x_fwd (backward: the framework's kernel), anything else the framework's forward too."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0:
+        return _Upsample2x.apply(x)
+    return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
 
 
 def invalidate_split_cache() -> None:

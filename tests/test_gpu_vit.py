@@ -277,3 +277,20 @@ def test_conv_x6_weight_gradient_kernel_matches_fp64(B, Ci, Co, H, W, k):
     (torch.nn.functional.conv2d(x.double(), wd, bd, padding=k // 2) * gy.double()).sum().backward()
     assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 5e-6, "conv dw (x6)")
     assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 5e-6, "conv db (x6)")
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 8), (1, 3, 16, 24), (3, 4, 1, 2), (2, 16, 64, 64)])
+def test_upsample2x_matches_framework_bilinear_align_corners(shape):
+    from styl3r_amd.vit_ops import upsample2x
+    x = torch.randn(shape, device=DEV, requires_grad=True)
+    y = upsample2x(x)
+    ref = torch.nn.functional.interpolate(x.detach().double(), scale_factor=2, mode="bilinear", align_corners=True)
+    assert y.shape == ref.shape
+    assert_close_rel(y.detach().cpu().numpy(), ref.cpu().numpy(), 1e-5, "upsample2x vs fp64")   # fp32 source-index rounding
+    same = torch.nn.functional.interpolate(x.detach(), scale_factor=2, mode="bilinear", align_corners=True)
+    assert_close_rel(y.detach().cpu().numpy(), same.cpu().numpy(), 2e-7, "upsample2x vs the framework's fp32 kernel")
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    torch.nn.functional.interpolate(x2, scale_factor=2, mode="bilinear", align_corners=True).backward(g)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-6)
