@@ -321,6 +321,16 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
     return out
 
 
+# the implicit-GEMM convolution walks its K = taps * Ci slabs sequentially (~0.12 ms floor at Ci = 256): it beats the library
+# (1.2-1.7x) once the 128 x 128 output tiles fill the chip, and loses (0.3-0.7x) below ~128 tiles (measured,
+# tools/probes/conv_small.py); smaller problems stay on the library path
+_CONV_X6_MIN_TILES = 200
+
+
+def _conv_tiles(out_channels: int, x: Tensor) -> int:
+    return ((out_channels + 127) // 128) * ((x.shape[0] * x.shape[2] * x.shape[3] + 127) // 128)
+
+
 class _ConvX6(torch.autograd.Function):
     """conv2d (3x3 pad 1 / 1x1, stride 1) on the bf16x6 implicit-GEMM kernel: forward and input gradient hand-written
     (dX = the same kernel on the flipped, channel-transposed weight); the weight / bias gradients go through the library
@@ -341,7 +351,7 @@ class _ConvX6(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = None
         if need_x:
-            if weight.shape[0] % 16 == 0 and weight.shape[1] >= 64:
+            if weight.shape[0] % 16 == 0 and weight.shape[1] >= 64 and _conv_tiles(weight.shape[1], g) >= _CONV_X6_MIN_TILES:
                 B, Co, H, W = g.shape
                 Ci = weight.shape[1]
                 dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
@@ -376,7 +386,8 @@ class Conv2dX6(nn.Conv2d):
         return (LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.padding == (k // 2, k // 2)
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
-                and self.in_channels % 16 == 0 and self.out_channels >= 64)
+                and self.in_channels % 16 == 0 and self.out_channels >= 64
+                and _conv_tiles(self.out_channels, x) >= _CONV_X6_MIN_TILES)
 
     def forward(self, x: Tensor) -> Tensor:
         if self._x6_ok(x):

@@ -241,10 +241,12 @@ def test_split_cache_never_serves_a_dead_tensors_entry():
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,k,bias", [(2, 32, 64, 9, 13, 3, True), (1, 16, 130, 17, 5, 3, False), (3, 48, 128, 8, 8, 1, True),
                                                  (2, 256, 256, 32, 32, 3, True), (1, 96, 256, 16, 24, 3, False)])
-def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias):
+def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias, monkeypatch):
     """Conv2dX6 (bf16x6 implicit GEMM: forward + input gradient; library weight gradient) vs an fp64 convolution"""
     from styl3r_amd.vit_ops import Conv2dX6
     torch.manual_seed(B * 100 + Ci)
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "_CONV_X6_MIN_TILES", 0)          # force the bf16x6 kernels at these small test sizes
     m = Conv2dX6(Ci, Co, k, 1, k // 2, bias=bias).to(DEV)
     assert m._x6_ok(torch.empty(1, Ci, 4, 4, device=DEV))
     x = torch.randn(B, Ci, H, W, device=DEV, requires_grad=True)
