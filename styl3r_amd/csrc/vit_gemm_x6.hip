@@ -792,8 +792,10 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     // split M so that tiles x S fills the 512 resident workgroups (256 CUs x 2) ONCE: 1.1 rounds cost as much as 2
     int S = split_count(tiles, nslab, 16);
     (void)hipGetLastError();
-    if (S > 1 && hipMemsetAsync(dw, 0, (size_t)N * K * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-    if (dbias && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    // one memset when the caller laid db out right behind dw (vit_ops.py does)
+    const bool joined = dbias == dw + (size_t)N * K;
+    if (S > 1 && hipMemsetAsync(dw, 0, ((size_t)N * K + (joined ? N : 0)) * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    if (dbias && !(S > 1 && joined) && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }

@@ -478,9 +478,10 @@ class _FusedLinear(torch.autograd.Function):
         if need_w and ctx.weight_ref is not None:         # dW (+ db in the same pass) on the bf16x6 kernel
             g2c = g2.contiguous().float()
             N, K = w.shape
-            dw = torch.empty((N, K), dtype=torch.float32, device=g.device)
             want_b = has_bias and need_b
-            db = torch.empty((N,), dtype=torch.float32, device=g.device) if want_b else None
+            buf = torch.empty(N * K + (N if want_b else 0), dtype=torch.float32, device=g.device)   # db right behind dw: one memset
+            dw = buf[:N * K].view(N, K)
+            db = buf[N * K:] if want_b else None
             _check(load().vit_linear_x6_wgrad(g2c.data_ptr(), x2.data_ptr(), dw.data_ptr(), db.data_ptr() if want_b else None,
                                               g2c.shape[0], N, K, _stream(g.device)), "vit_linear_x6_wgrad")
         else:
