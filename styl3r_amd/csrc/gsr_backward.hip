@@ -121,17 +121,18 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 s[GR_DEPTH] += w * gd[k];
                 const float dL_dG = b.y * dL_dalpha;
                 const float gdx = Gv * dx, gdy = Gv * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                s[GR_MX] += dL_dG * dG_ddelx;      // x 0.5 W after the loop
-                s[GR_MY] += dL_dG * dG_ddely;      // x 0.5 H
+                // dL/dmean2D = sum dL_dG * (-G dx A - G dy B, -G dy C - G dx B) * (W/2, H/2) is linear in the two sums
+                // hx = sum(-dL_dG/2 * G dx), hy = sum(-dL_dG/2 * G dy), which the conic gradients need anyway: accumulate
+                // those (two adds per evaluation instead of six multiply-adds) and apply A, B, C once per Gaussian in K7
                 const float hg = -0.5f * dL_dG;
-                s[GR_CA] += hg * gdx * dx;
-                s[GR_CB] += hg * gdx * dy;
-                s[GR_CC] += hg * gdy * dy;
+                const float hx = hg * gdx, hy = hg * gdy;
+                s[GR_MX] += hx;
+                s[GR_MY] += hy;
+                s[GR_CA] += hx * dx;
+                s[GR_CB] += hx * dy;
+                s[GR_CC] += hy * dy;
                 s[GR_OP] += Gv * dL_dalpha;
             }
-            s[GR_MX] *= ddelx_dx; s[GR_MY] *= ddely_dy;
             if (__ballot(any) == 0ull) continue;  // wave-uniform
 #if defined(GSR_EXP) && GSR_EXP == 2
             { float z = 0.f; for (int i = 0; i < 10; ++i) z += s[i]; asm volatile("" ::"v"(z)); continue; }
@@ -305,7 +306,12 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
             const float hw = m[0] * Pm[3] + m[1] * Pm[7] + m[2] * Pm[11] + Pm[15];
             const float mw = 1.0f / (hw + 0.0000001f);
             const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
-            g2x = gr[GR_MX]; g2y = gr[GR_MY];
+            {   // K6 accumulated hx = sum(-dL_dG/2 G dx), hy likewise: mean2D gradient = (A hx + B hy) W, (C hy + B hx) H
+                const float4 q1 = reinterpret_cast<const float4 *>(ws.records + vg)[1];
+                const float sx = gr[GR_MX], sy = gr[GR_MY];
+                g2x = (q1.x * sx + q1.y * sy) * (float)d.W;
+                g2y = (q1.z * sy + q1.y * sx) * (float)d.H;
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 dm[k] += (Pm[4 * k + 0] * mw - Pm[4 * k + 3] * mul1) * g2x + (Pm[4 * k + 1] * mw - Pm[4 * k + 3] * mul2) * g2y;
