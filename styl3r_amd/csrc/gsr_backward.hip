@@ -20,6 +20,8 @@ enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_
 // A lane first adds the partial gradients of its own pixels in registers, then ONE
 // ten-value wave reduction per splat (wave_reduce10) and ten lanes issue the tile's single
 // atomic per component.  No LDS atomics, no workgroup barriers.
+// DEPTH = false: no dL/ddepth was passed (Styl3R trains on colour only): the depth terms drop out of the evaluation
+template <bool DEPTH>
 __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      const float *__restrict__ dL_dimage,
                                                      const float *__restrict__ dL_ddepth)
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         g0[k] = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
         g1[k] = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
         g2[k] = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
-        gd[k] = (inside && dL_ddepth) ? dL_ddepth[v * P + pix] : 0.f;
+        gd[k] = (DEPTH && inside) ? dL_ddepth[v * P + pix] : 0.f;
         bgT[k] = -Tf * (vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k]);
         Tr[k] = Tf;
         accu[k] = last_alpha[k] = last_u[k] = 0.f;
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             const float4 c = s_q[j * 3 + 2];                // r, g, b, quad
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
             if (quad == 0) continue;   // footprint misses the tile: nothing to evaluate, nothing to reduce
+            const float kop = -0.5f * b.y;
             float s[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) s[i] = 0.f;
@@ -112,26 +115,26 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp) for both 1/(1-alpha) uses
                 Tr[k] *= inv;
                 const float w = alpha * Tr[k];
-                const float u = c.x * g0[k] + c.y * g1[k] + c.z * g2[k] + b.z * gd[k];
+                float u = c.x * g0[k] + c.y * g1[k] + c.z * g2[k];
+                if (DEPTH) u += b.z * gd[k];
                 accu[k] = last_alpha[k] * last_u[k] + (1.f - last_alpha[k]) * accu[k];
                 last_u[k] = u;
                 last_alpha[k] = alpha;
                 const float dL_dalpha = (u - accu[k]) * Tr[k] + bgT[k] * inv;
                 s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
-                s[GR_DEPTH] += w * gd[k];
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = Gv * dx, gdy = Gv * dy;
+                if (DEPTH) s[GR_DEPTH] += w * gd[k];
                 // dL/dmean2D = sum dL_dG * (-G dx A - G dy B, -G dy C - G dx B) * (W/2, H/2) is linear in the two sums
                 // hx = sum(-dL_dG/2 * G dx), hy = sum(-dL_dG/2 * G dy), which the conic gradients need anyway: accumulate
                 // those (two adds per evaluation instead of six multiply-adds) and apply A, B, C once per Gaussian in K7
-                const float hg = -0.5f * dL_dG;
-                const float hx = hg * gdx, hy = hg * gdy;
+                const float t = Gv * dL_dalpha;            // dL/dopacity term; dL_dG * G = opacity * t
+                s[GR_OP] += t;
+                const float hgG = kop * t;                  // -1/2 dL_dG G, kop = -opacity / 2 (per entry)
+                const float hx = hgG * dx, hy = hgG * dy;
                 s[GR_MX] += hx;
                 s[GR_MY] += hy;
                 s[GR_CA] += hx * dx;
                 s[GR_CB] += hx * dy;
                 s[GR_CC] += hy * dy;
-                s[GR_OP] += Gv * dL_dalpha;
             }
             if (__ballot(any) == 0ull) continue;  // wave-uniform
 #if defined(GSR_EXP) && GSR_EXP == 2
@@ -416,7 +419,8 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
     if (!hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
     if (dL_dtau && !hip_ok(hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream))) return GSR_ELAUNCH;
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
-    hipLaunchKernelGGL(k_composite_bwd, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
+    if (dL_ddepth) hipLaunchKernelGGL(k_composite_bwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
+    else hipLaunchKernelGGL(k_composite_bwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
     tm.end(GSR_STAGE_COMPOSITE_BWD); tm.begin(GSR_STAGE_PREPROCESS_BWD);
     const dim3 gG((d.G + 255) / 256, d.B);
 #define GSR_LAUNCH_K7(DEG) hipLaunchKernelGGL(k_preprocess_bwd<DEG>, gG, dim3(256), 0, stream, d, views, means, cov6, shs, ws, \
