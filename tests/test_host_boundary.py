@@ -34,7 +34,11 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.GsrDims) == 40          # 8 x int32 + pointer
-    assert C.sizeof(_lib.GsrLayout) == 12 * C.sizeof(C.c_size_t)
+    header = (ROOT / "include/gsr.h").read_text()
+    body = header[header.index("typedef struct GsrLayout {"):header.index("} GsrLayout;")]
+    fields = re.findall(r"^\s*size_t\s+(\w+);", body, flags=re.M)
+    assert fields == [n for n, _ in _lib.GsrLayout._fields_]          # same names, same order as include/gsr.h
+    assert C.sizeof(_lib.GsrLayout) == len(fields) * C.sizeof(C.c_size_t)
     assert _lib.GSR_VIEW_FLOATS * 4 == 256
 
 
