@@ -174,3 +174,86 @@ def compute_psnr(ground_truth: Tensor, predicted: Tensor) -> Tensor:
     """src/evaluation/metrics.py:11-20 (per image, inputs in [0,1])."""
     mse = ((ground_truth.clip(0, 1) - predicted.clip(0, 1)) ** 2).flatten(1).mean(dim=1)
     return -10 * mse.log10()
+
+
+# ---------------------------------------------------------------------------
+# LPIPS (src/loss/loss_lpips.py:27-54 uses `lpips.LPIPS(net="vgg")`, a third-party package that is not installed here and
+# whose weights cannot be fetched).  This is the published LPIPS-VGG architecture with the package's parameter names, so
+# its `state_dict` (vgg16 features + the five 1x1 "lin" layers) loads unchanged; without weights it is random-init.
+# ---------------------------------------------------------------------------
+class _LpipsLin(nn.Module):
+    def __init__(self, c_in: int):
+        super().__init__()
+        self.model = nn.Sequential(nn.Dropout(), nn.Conv2d(c_in, 1, 1, bias=False))      # keys: linK.model.1.weight
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _LpipsVgg16(nn.Module):
+    """torchvision vgg16().features split at relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 (keys: net.sliceK.<idx>.weight)"""
+    _CFG = ((64, 64), (128, 128), (256, 256, 256), (512, 512, 512), (512, 512, 512))
+
+    def __init__(self):
+        super().__init__()
+        idx, c_in = 0, 3
+        for s, widths in enumerate(self._CFG, start=1):
+            block = nn.Sequential()
+            if s > 1:
+                block.add_module(str(idx), nn.MaxPool2d(2, 2)); idx += 1
+            for w in widths:
+                block.add_module(str(idx), nn.Conv2d(c_in, w, 3, padding=1)); idx += 1
+                block.add_module(str(idx), nn.ReLU(inplace=False)); idx += 1
+                c_in = w
+            setattr(self, f"slice{s}", block)
+
+    def forward(self, x):
+        feats = []
+        for s in range(1, 6):
+            x = getattr(self, f"slice{s}")(x)
+            feats.append(x)
+        return feats
+
+
+class LPIPS(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = _LpipsVgg16()
+        for k, c in enumerate((64, 128, 256, 512, 512)):
+            setattr(self, f"lin{k}", _LpipsLin(c))
+        self.register_buffer("shift", torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("scale", torch.tensor([.458, .448, .450]).view(1, 3, 1, 1), persistent=False)
+
+    def forward(self, a: Tensor, b: Tensor, normalize: bool = False) -> Tensor:
+        if normalize:                                                       # [0,1] -> [-1,1]
+            a, b = 2 * a - 1, 2 * b - 1
+        fa, fb = self.net((a - self.shift) / self.scale), self.net((b - self.shift) / self.scale)
+        total = 0
+        for k, (x, y) in enumerate(zip(fa, fb)):
+            x = x / (x.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            y = y / (y.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+            total = total + getattr(self, f"lin{k}")((x - y) ** 2).mean(dim=(2, 3), keepdim=True)
+        return total                                                        # (N,1,1,1)
+
+
+@dataclass
+class LossLpipsCfg:
+    weight: float = 0.05
+    apply_after_step: int = 0
+
+
+class LossLpips(nn.Module):
+    def __init__(self, cfg: LossLpipsCfg = LossLpipsCfg(), lpips: LPIPS | None = None):
+        super().__init__()
+        self.cfg = cfg
+        self.lpips = (lpips or LPIPS()).eval()
+        for p in self.lpips.parameters():                                   # convert_to_buffer(..., persistent=False)
+            p.requires_grad_(False)
+
+    def forward(self, prediction, batch, gaussians=None, global_step: int = 0) -> Tensor:
+        image = batch["target"]["image"]
+        if global_step < self.cfg.apply_after_step:
+            return torch.tensor(0, dtype=torch.float32, device=image.device)
+        b, v = image.shape[:2]
+        loss = self.lpips(prediction.color.reshape(b * v, *image.shape[2:]), image.reshape(b * v, *image.shape[2:]), normalize=True)
+        return self.cfg.weight * loss.mean()

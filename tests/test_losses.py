@@ -56,3 +56,26 @@ def test_style_and_identity_losses_match_numpy_restatement():
     np.testing.assert_allclose(float(IdentityLoss(70, 1, vgg)(pred, batch)), ident, rtol=2e-5)
     m, s = calc_mean_std(torch.tensor(fp[0], dtype=torch.float32))
     assert m.shape == (6, 64, 1) and s.shape == (6, 64, 1)
+
+
+def test_lpips_structure_and_gating():
+    """LPIPS-VGG layout with the lpips package's parameter names; LossLpips gating and zero at identity"""
+    import torch
+    from types import SimpleNamespace
+    from styl3r_amd.losses import LPIPS, LossLpips, LossLpipsCfg
+    torch.manual_seed(0)
+    m = LPIPS()
+    keys = set(m.state_dict().keys())
+    assert {"net.slice1.0.weight", "net.slice1.2.bias", "net.slice2.5.weight", "net.slice3.10.weight", "net.slice4.17.weight",
+            "net.slice5.24.weight", "lin0.model.1.weight", "lin4.model.1.weight"} <= keys
+    assert m.lin2.model[1].weight.shape == (1, 256, 1, 1) and sum(p.numel() for p in m.net.parameters()) == 14_714_688
+    loss = LossLpips(LossLpipsCfg(weight=0.05, apply_after_step=10), m)
+    img = torch.rand(1, 2, 3, 32, 32)
+    pred = SimpleNamespace(color=img.clone().requires_grad_(True))
+    batch = {"target": {"image": img}}
+    assert float(loss(pred, batch, None, 5)) == 0.0                          # before apply_after_step
+    assert abs(float(loss(pred, batch, None, 10))) < 1e-12                   # identical images
+    other = SimpleNamespace(color=(img * 0.5).requires_grad_(True))
+    l = loss(other, batch, None, 10)
+    l.backward()
+    assert torch.isfinite(l) and other.color.grad.abs().sum() > 0
