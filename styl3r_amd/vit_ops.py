@@ -325,6 +325,7 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # (1.2-1.7x) once the 128 x 128 output tiles fill the chip, and loses (0.3-0.7x) below ~128 tiles (measured,
 # tools/probes/conv_small.py); smaller problems stay on the library path
 _CONV_X6_MIN_TILES = 200
+CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0}   # how often each bf16x6 convolution kernel was taken (tests)
 
 
 def _conv_tiles(out_channels: int, x: Tensor) -> int:
@@ -341,6 +342,7 @@ class _ConvX6(torch.autograd.Function):
         _need_gpu(x, "conv2d")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        CALLS["conv_x6_fwd"] += 1
         return conv_x6_forward(x, weight, bias)
 
     @staticmethod
@@ -355,6 +357,7 @@ class _ConvX6(torch.autograd.Function):
                 B, Co, H, W = g.shape
                 Ci = weight.shape[1]
                 dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
+                CALLS["conv_x6_dx"] += 1
                 _check(load().vit_conv_x6_fwd(g.data_ptr(), split_conv_weight(weight, True).data_ptr(), None, None, dx.data_ptr(),
                                               B, Co, Ci, H, W, k, 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
             else:
@@ -368,6 +371,7 @@ class _ConvX6(torch.autograd.Function):
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
             xc = x.contiguous().float()
+            CALLS["conv_x6_wgrad"] += 1
             _check(load().vit_conv_x6_wgrad(g.data_ptr(), xc.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
                                             B_, weight.shape[1], weight.shape[0], H_, W_, k, 0, _stream(g.device)), "vit_conv_x6_wgrad")
         elif need_w or need_b:

@@ -121,3 +121,36 @@ def test_hipgraph_replay_of_the_encoder_matches_eager():
         a, b = getattr(got, name).cpu().numpy(), getattr(want, name).cpu().numpy()
         assert_close_rel(a, b, 2e-5, name)                      # (library convolutions may pick another algorithm: fp32 noise)
         assert abs(a - getattr(old, name).cpu().numpy()).max() > 1e-2 * abs(b).max()   # and it really used the new inputs
+
+
+@pytest.mark.gpu
+def test_bf16x6_and_f32_paths_agree_through_the_whole_encoder():
+    """Large enough images for the bf16x6 convolution kernels (Conv2dX6, >= 200 output tiles) and split-K Linear paths to
+    run inside the real graph: Gaussians and input gradients must match the exact-f32 MFMA Linear + MIOpen convolution
+    path (VIT_LINEAR_MODE=f32) to fp32 round-off"""
+    from styl3r_amd import vit_ops
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(_build(0)).to(dev)
+    g = torch.Generator(dev).manual_seed(5)
+    H, W = 128, 160
+    img = (torch.rand(1, 2, 3, H, W, device=dev, generator=g) * 2 - 1)
+    K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]], device=dev).expand(1, 2, 3, 3).contiguous()
+    style = torch.rand(1, 3, H, W, device=dev, generator=g) * 2 - 1
+    res = {}
+    old = vit_ops.LINEAR_MODE
+    try:
+        for mode in ("f32", "bf16x6"):
+            vit_ops.LINEAR_MODE = mode
+            x = img.clone().requires_grad_(True)
+            gs = m(dict(image=x, intrinsics=K), dict(image=style), global_step=0)
+            loss = (gs.means * 0.01).sum() + gs.covariances.sum() * 1e3 + gs.harmonics.sum() * 0.1 + gs.opacities.sum() * 0.1
+            loss.backward()
+            res[mode] = [t.detach().cpu().numpy() for t in (gs.means, gs.covariances, gs.harmonics, gs.opacities, x.grad)]
+            if mode == "f32":
+                before = dict(vit_ops.CALLS)
+    finally:
+        vit_ops.LINEAR_MODE = old
+    assert vit_ops.CALLS["conv_x6_fwd"] > before["conv_x6_fwd"] and vit_ops.CALLS["conv_x6_dx"] > before["conv_x6_dx"]   # really taken
+    for name, a, b in zip(("means", "covariances", "harmonics", "opacities", "d image"), res["bf16x6"], res["f32"]):
+        assert_close_rel(a, b, 2e-3 if name == "d image" else 1e-4, name)
