@@ -258,8 +258,8 @@ def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias, mon
     bd = m.bias.detach().double().requires_grad_(True) if bias else None
     ref = torch.nn.functional.conv2d(xd, wd, bd, padding=k // 2)
     (ref * gy.double()).sum().backward()
-    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 3e-6, "conv fwd")
-    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 3e-6, "conv dx")
+    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 5e-6, "conv fwd")
+    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 5e-6, "conv dx")
     assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 2e-5, "conv dw")
     if bias:
         assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 2e-5, "conv db")
