@@ -141,22 +141,34 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
 
 // ------------------------------------------------------------------ K2
 // One workgroup of 1024 threads scans n = V*T counters (n is at most a few 10^4).
+// Fast path (n <= 16 384 counters, e.g. 40 views x 256 tiles): the counters go through LDS once (coalesced loads), every
+// thread then owns PER consecutive counters in registers: serial scan of its own, one wave scan + one cross-wave fix-up
+// of the thread totals -- 6 barriers instead of 3 per 1 024 counters.
+constexpr int SCAN_PER_MAX = 16;
+
 __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, Ptrs ws, int32_t *__restrict__ status)
 {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
     __shared__ uint32_t s_max[16];
     __shared__ uint32_t s_bin[256], s_shift;
+    __shared__ uint32_t s_cnt[1024 * SCAN_PER_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) s_carry = 0;
     uint32_t mx = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + tid;
-        uint32_t c = (i < n) ? ws.tile_count[i] : 0u;
-        mx = max(mx, c);
-        // inclusive scan inside the wave (64 lanes) with shuffles
-        unsigned long long x = c;
+    const int per = (n + 1023) / 1024;
+    const bool fast = per <= SCAN_PER_MAX;
+    uint32_t c[SCAN_PER_MAX];
+    if (fast) {
+        for (int i = tid; i < per * 1024; i += 1024) s_cnt[i] = (i < n) ? ws.tile_count[i] : 0u;
+        __syncthreads();
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_PER_MAX; ++e) {
+            c[e] = (e < per) ? s_cnt[tid * per + e] : 0u;
+            mx = max(mx, c[e]);
+            tot += c[e];
+        }
+        unsigned long long x = tot;                       // inclusive scan of the thread totals inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             unsigned long long y = __shfl_up(x, o, 64);
@@ -164,22 +176,51 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
         }
         if (lane == 63) s_wave[wid] = x;
         __syncthreads();
-        unsigned long long wave_off = 0;
-        for (int w = 0; w < wid; ++w) wave_off += s_wave[w];
-        unsigned long long carry = s_carry;
-        unsigned long long excl = carry + wave_off + x - c;
-        if (i < n) {
-            ws.tile_offset[i] = (uint32_t)min(excl, (unsigned long long)0xffffffffu);
-            ws.tile_cursor[i] = 0u;
+        unsigned long long off = x - tot;
+        for (int w = 0; w < wid; ++w) off += s_wave[w];
+        if (tid == 1023) s_carry = off + tot;
+#pragma unroll
+        for (int e = 0; e < SCAN_PER_MAX; ++e) {
+            const int i = tid * per + e;
+            if (e < per && i < n) {
+                ws.tile_offset[i] = (uint32_t)min(off, (unsigned long long)0xffffffffu);
+                ws.tile_cursor[i] = 0u;
+            }
+            off += c[e];
         }
+    } else {
+        if (tid == 0) s_carry = 0;
         __syncthreads();
-        if (tid == 1023) s_carry = carry + wave_off + x;
-        __syncthreads();
+        for (int base = 0; base < n; base += 1024) {
+            int i = base + tid;
+            uint32_t cc = (i < n) ? ws.tile_count[i] : 0u;
+            mx = max(mx, cc);
+            unsigned long long x = cc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned long long y = __shfl_up(x, o, 64);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) s_wave[wid] = x;
+            __syncthreads();
+            unsigned long long wave_off = 0;
+            for (int w = 0; w < wid; ++w) wave_off += s_wave[w];
+            unsigned long long carry = s_carry;
+            unsigned long long excl = carry + wave_off + x - cc;
+            if (i < n) {
+                ws.tile_offset[i] = (uint32_t)min(excl, (unsigned long long)0xffffffffu);
+                ws.tile_cursor[i] = 0u;
+            }
+            __syncthreads();
+            if (tid == 1023) s_carry = carry + wave_off + x;
+            __syncthreads();
+        }
     }
     // block max of the tile lengths
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     if (lane == 0) s_max[wid] = mx;
+    if (tid < 256) s_bin[tid] = 0u;
     __syncthreads();
     if (tid == 0) {
         uint32_t m = 0;
@@ -193,21 +234,41 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
         while ((m >> sh) > 255u) ++sh;
         s_shift = sh;
     }
+    __syncthreads();
     // Launch order of the composite kernels: longest lists first (counting sort into 256 length classes), so the
     // workgroups that take longest start first and the tail of K5 / K6 is made of short tiles (LPT scheduling).
-    if (tid < 256) s_bin[tid] = 0u;
-    __syncthreads();
     const uint32_t sh = s_shift;
-    for (int i = tid; i < n; i += 1024) atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
-    __syncthreads();
-    if (tid == 0) {                            // exclusive scan of 256 bins: trivial next to the launch latency
-        uint32_t acc = 0;
-        for (int b = 0; b < 256; ++b) { const uint32_t c = s_bin[b]; s_bin[b] = acc; acc += c; }
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < SCAN_PER_MAX; ++e)
+            if (e < per && tid * per + e < n) atomicAdd(&s_bin[255u - min(c[e] >> sh, 255u)], 1u);
+    } else {
+        for (int i = tid; i < n; i += 1024) atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const uint32_t pos = atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
-        ws.tile_order[pos] = (uint32_t)i;
+    if (tid < 64) {                            // exclusive scan of the 256 bins by one wavefront (4 bins per lane)
+        uint32_t b0 = s_bin[tid * 4], b1 = s_bin[tid * 4 + 1], b2 = s_bin[tid * 4 + 2], b3 = s_bin[tid * 4 + 3];
+        uint32_t t4 = b0 + b1 + b2 + b3, x = t4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
+            if (lane >= o) x += y;
+        }
+        uint32_t off = x - t4;
+        s_bin[tid * 4] = off; s_bin[tid * 4 + 1] = off + b0; s_bin[tid * 4 + 2] = off + b0 + b1; s_bin[tid * 4 + 3] = off + b0 + b1 + b2;
+    }
+    __syncthreads();
+    if (fast) {
+#pragma unroll
+        for (int e = 0; e < SCAN_PER_MAX; ++e) {
+            const int i = tid * per + e;
+            if (e < per && i < n) ws.tile_order[atomicAdd(&s_bin[255u - min(c[e] >> sh, 255u)], 1u)] = (uint32_t)i;
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            const uint32_t pos = atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
+            ws.tile_order[pos] = (uint32_t)i;
+        }
     }
 }
 

@@ -21,7 +21,7 @@ def _scene(n_ctx, res, n_views, sh_degree=0, seed=0):
     return sc, g, dec, args
 
 
-@pytest.mark.parametrize("n_ctx,res,views", [(4, 256, 6), (4, 512, 2)])   # C4: 262 144 Gaussians; C5: 1 048 576 at 512^2
+@pytest.mark.parametrize("n_ctx,res,views", [(4, 256, 6), (4, 512, 2), (1, 512, 18)])   # C4: 262 144 Gaussians; C5: 1 048 576 at 512^2; 18 x 1024 tiles: the tile scan's looped path (> 16 384 counters)
 def test_tile_lists_sorted_and_consistent_at_full_size(n_ctx, res, views):
     sc, g, dec, args = _scene(n_ctx, res, views, seed=3)
     rz.KEEP_DEBUG = True
