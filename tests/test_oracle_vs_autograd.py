@@ -22,10 +22,22 @@ def _sh_color(deg, shs, dirs):
     return res
 
 
-def torch_render(means, cov6, opac, colors_or_shs, cam, bg, sh_degree, use_sh):
+def torch_render(means, cov6, opac, colors_or_shs, cam, bg, sh_degree, use_sh, tau=None):
     H, W = cam["H"], cam["W"]
     T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
     view, proj, campos = T(cam["view"]), T(cam["proj"]), T(cam["campos"])
+    if tau is not None:
+        # left se(3) perturbation of the world-to-camera transform, T_cw' = exp(tau^) T_cw with tau = (rho, theta)
+        # (src/misc/cam_utils.py:118-137); matrices are stored row-vector / transposed (cuda_splatting.py:86-88)
+        rho, th = tau[:3], tau[3:]
+        z = torch.zeros((), dtype=torch.float64)
+        xi = torch.stack([torch.stack([z, -th[2], th[1], rho[0]]), torch.stack([th[2], z, -th[0], rho[1]]),
+                          torch.stack([-th[1], th[0], z, rho[2]]), torch.stack([z, z, z, z])])
+        Tcw = torch.matrix_exp(xi) @ view.T
+        view = Tcw.T
+        proj = view @ T(cam["proj_raw"])
+        # `campos` is a separate, non-differentiated setting of the rasterizer (cuda_splatting.py:112): the pose gradient
+        # holds it fixed, i.e. the SH view direction does not move with tau (oracle/gsr_oracle.c: "campos held fixed")
     G = means.shape[0]
     hom = torch.cat([means, torch.ones(G, 1, dtype=torch.float64)], 1)
     pv = hom @ view                      # row-vector convention (cuda_splatting.py:86-88)
@@ -93,6 +105,9 @@ def torch_render(means, cov6, opac, colors_or_shs, cam, bg, sh_degree, use_sh):
 @pytest.mark.parametrize("use_sh,sh_degree,seed", [(False, 0, 3), (True, 1, 4), (True, 0, 5)])
 def test_oracle_forward_and_analytic_gradients_match_autograd(use_sh, sh_degree, seed):
     cam = simple_camera(32, 48, c2w=np.array([[0.995, 0, 0.0998, 0.1], [0, 1, 0, -0.05], [-0.0998, 0, 0.995, 0.2], [0, 0, 0, 1]]))
+    # full projection and camera centre recomputed in fp64 from (view, proj_raw), so that the tau = 0 perturbed camera of the
+    # autograd path is bit-identical to the oracle's inputs (the helper's matrices are fp32 products)
+    cam = dict(cam, proj=cam["view"] @ cam["proj_raw"], campos=np.linalg.inv(cam["view"].T)[:3, 3])
     G = 40
     means, cov6, opac, shs = random_scene(G, seed=seed, sh_degree=sh_degree, scale=(0.05, 0.25))
     rng = np.random.default_rng(seed)
@@ -103,10 +118,11 @@ def test_oracle_forward_and_analytic_gradients_match_autograd(use_sh, sh_degree,
     st, ctx = orc.forward(means, cov6, opac, shs=shs if use_sh else None, colors=None if use_sh else colors, H=cam["H"], W=cam["W"],
                           tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg, view=cam["view"], proj=cam["proj"],
                           proj_raw=cam["proj_raw"], campos=cam["campos"], sh_degree=sh_degree)
-    g = orc.backward(st, ctx, wI, wD)
+    g = orc.backward(st, ctx, wI, wD, want_tau=True)
     tm, tc, to = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (means, cov6, opac))
     tcol = torch.tensor(shs if use_sh else colors, dtype=torch.float64, requires_grad=True)
-    img, dep, radii, ncontrib = torch_render(tm, tc, to, tcol, cam, bg, sh_degree, use_sh)
+    tau = torch.zeros(6, dtype=torch.float64, requires_grad=True)
+    img, dep, radii, ncontrib = torch_render(tm, tc, to, tcol, cam, bg, sh_degree, use_sh, tau=tau)
     # forward: images, depth, radii, n_contrib
     np.testing.assert_allclose(st.image, img.detach().numpy(), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(st.out_depth, dep.detach().numpy(), rtol=1e-9, atol=1e-11)
@@ -118,3 +134,7 @@ def test_oracle_forward_and_analytic_gradients_match_autograd(use_sh, sh_degree,
         ref = ref.numpy().reshape(np.asarray(ours).shape)
         scale = max(np.abs(ref).max(), 1e-12)
         assert np.abs(np.asarray(ours) - ref).max() <= 1e-7 * scale, (name, np.abs(np.asarray(ours) - ref).max(), scale)
+    # pose gradient (MonoGS "-w-pose" extension): tau = (rho, theta)
+    got_tau = np.concatenate([np.asarray(g["rho"]).reshape(3), np.asarray(g["theta"]).reshape(3)])
+    ref_tau = tau.grad.numpy()
+    assert np.abs(got_tau - ref_tau).max() <= 1e-7 * np.abs(ref_tau).max(), (got_tau, ref_tau)
