@@ -16,8 +16,11 @@
  * (upstream cuda_rasterizer/{forward,backward,
  * rasterizer_impl}.cu) and is anchored on the reference's own call site
  * src/model/decoder/cuda_splatting.py:101-129 (argument layouts, the 5-tuple
- * return).  It pins itself with analytic known-answer cases and fp64
- * finite-difference gradient checks (tests/test_oracle_*.py).
+ * return).  It pins itself with analytic known-answer cases, fp64
+ * finite-difference gradient checks (tests/test_oracle_*.py) and an independent
+ * dense PyTorch fp64 restatement whose gradients come from autograd
+ * (tests/test_oracle_vs_autograd.py: images / depth / radii / n_contrib equal,
+ * every analytic gradient incl. the pose tau within 1e-7).
  *
  * The file is compiled twice: -DGSO_REAL=float (libgsr_oracle_f32.so, mirrors
  * the fp32 arithmetic of the GPU path operation-for-operation; build with
