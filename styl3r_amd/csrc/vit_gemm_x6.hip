@@ -414,7 +414,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
     tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int co0 = tm * BM;
     const int64_t p0 = (int64_t)tn * BN;
-    const int K = TAPS * Ci, KG = K >> 3, nk = K / BK;
+    const int K = TAPS * Ci, KG = K >> 3;
+    // gridDim.y > 1: the K = taps * Ci slabs are split across workgroups that add their partial tiles into the zeroed
+    // output with fp32 atomics (small images: too few output tiles to fill the chip, and 144 slabs in a row are a
+    // 0.12 ms floor); bias / residual enter through split 0
+    const int nslab = K / BK, S_ = gridDim.y, sp_ = blockIdx.y;
+    const int s_lo = sp_ * (nslab / S_) + min(sp_, nslab % S_), nk = nslab / S_ + (sp_ < nslab % S_ ? 1 : 0);
 
     // A loader (weights): thread -> (row, k group), three 16-byte pieces
     const int lrow = tid >> 1, kg = tid & 1;
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
     const float *in_g = inb + (int64_t)(g * 8) * HW;
 #define C6_GLOAD(T, slab)                                                                                             \
     do {                                                                                                              \
-        const int sl_ = min((slab), nk - 1);                                                                          \
+        const int sl_ = s_lo + min((slab), nk - 1);                                                                   \
         const uint4 *q_ = wa + sl_ * 6; a0_##T = q_[0]; a1_##T = q_[1]; a2_##T = q_[2];                               \
         const int tap = sl_ / spt, ci = (sl_ - tap * spt) * BK;                                                       \
         const int ky_ = KS == 3 ? (tap * 11) >> 5 : 0, kx_ = KS == 3 ? tap - 3 * ky_ : 0;                             \
@@ -522,9 +527,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
                 const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co >= Co) continue;
                 const int64_t o = obase + (int64_t)co * HW;
-                float t = acc[i][j][r] + (bias ? bias[co] : 0.f);
-                if (residual) t += residual[o];
-                out[o] = t;
+                const bool first = blockIdx.y == 0;
+                float t = acc[i][j][r] + ((bias && first) ? bias[co] : 0.f);
+                if (residual && first) t += residual[o];
+                if (gridDim.y == 1) out[o] = t; else atomicAdd(out + o, t);
             }
         }
     }
@@ -811,7 +817,12 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     if (tiles > 0x7fffffff) return VIT_EINVAL;
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
-#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W)
+    // few output tiles: split the K slabs so that tiles x S fills the 512 resident workgroups, >= 8 slabs per split
+    int S = 1;
+    const int nslab = ksize * ksize * Ci / x6::BK;
+    if (tiles < 256) { S = (int)(512 / tiles); while (S > 1 && nslab / S < 8) --S; if (S < 1) S = 1; if (S > 16) S = 16; }
+    if (S > 1 && hipMemsetAsync(out, 0, (size_t)NP * Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
     else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
 #undef VIT_LAUNCH_C6

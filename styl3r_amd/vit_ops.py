@@ -322,9 +322,9 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 
 
 # the implicit-GEMM convolution walks its K = taps * Ci slabs sequentially (~0.12 ms floor at Ci = 256): it beats the library
-# (1.2-1.7x) once the 128 x 128 output tiles fill the chip, and loses (0.3-0.7x) below ~128 tiles (measured,
+# (1.2-1.7x) once the 128 x 128 output tiles fill the chip; with fewer tiles it splits K across workgroups (atomics) and is on par down to ~100 tiles, slower below (measured,
 # tools/probes/conv_small.py); smaller problems stay on the library path
-_CONV_X6_MIN_TILES = 200
+_CONV_X6_MIN_TILES = 100
 CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0}   # how often each bf16x6 convolution kernel was taken (tests)
 
 
