@@ -127,6 +127,8 @@ int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias,
  * FeatureFusionBlock): in (planes, H, W) -> out (planes, 2H, 2W), planes = B*C of a contiguous NCHW tensor; W even.
  */
 int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream);
+/* its input gradient: dout (planes, 2H, 2W) -> din (planes, H, W), a gather (no atomics), overwritten */
+int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream);
 
 const char *vit_version(void);
 const char *vit_last_error(void);

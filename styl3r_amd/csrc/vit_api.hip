@@ -19,6 +19,7 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
 int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
                   int relu_in, hipStream_t stream);
 int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hipStream_t stream);
+int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
@@ -88,6 +89,11 @@ VIT_EXPORT int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, fl
 VIT_EXPORT int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream)
 {
     return vit::upsample2x_fwd(in, out, planes, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream)
+{
+    return vit::upsample2x_bwd(dout, din, planes, H, W, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

@@ -24,7 +24,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     lib.vit_conv_x6_wgrad.restype = C.c_int
     lib.vit_upsample2x_fwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
     lib.vit_upsample2x_fwd.restype = C.c_int
+    lib.vit_upsample2x_bwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
+    lib.vit_upsample2x_bwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -412,12 +414,15 @@ class _Upsample2x(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         B, Cc, H, W = ctx.shape
-        return torch.ops.aten.upsample_bilinear2d_backward(g.contiguous(), [2 * H, 2 * W], [B, Cc, H, W], True, None, None)
+        g = g.contiguous().float()
+        din = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
+        _check(load().vit_upsample2x_bwd(g.data_ptr(), din.data_ptr(), B * Cc, H, W, _stream(g.device)), "vit_upsample2x_bwd")
+        return din
 
 
 def upsample2x(x: Tensor) -> Tensor:
     """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True); device fp32 NCHW tensors with an even width
-    take vit_upsample2x_fwd (backward: the framework's kernel), anything else the framework's forward too."""
+    take vit_upsample2x_fwd / vit_upsample2x_bwd, anything else the framework's kernels."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0:
         return _Upsample2x.apply(x)
     return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
