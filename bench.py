@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes", type=int, default=10, help="scenes per GPU per step (C3 batch)")
     ap.add_argument("--views", type=int, default=4, help="target views per scene")
-    ap.add_argument("--ctx", type=int, default=1, help="context views per scene (65 536 Gaussians each)")
+    ap.add_argument("--ctx", type=int, default=1, help="context views per scene (grid x grid Gaussians each)")
+    ap.add_argument("--grid", type=int, default=256, help="Gaussians per context view = grid^2 (256 -> 65 536; sweep: 128, 512)")
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,7 +53,7 @@ def build_batch(args, rank, dev):
     from styl3r_amd.decoder import Gaussians
     from styl3r_amd.scenes import make_scene
     from styl3r_amd.dist_utils import scene_seeds
-    scenes = [make_scene(n_ctx=args.ctx, grid_hw=(256, 256), n_views=args.views, image_hw=(args.res, args.res),
+    scenes = [make_scene(n_ctx=args.ctx, grid_hw=(args.grid, args.grid), n_views=args.views, image_hw=(args.res, args.res),
                          sh_degree=args.sh_degree, seed=sd) for sd in scene_seeds(rank, args.scenes)]
     st = lambda name: torch.stack([getattr(s, name) for s in scenes]).to(dev)
     g = Gaussians(st("means"), st("covariances"), st("harmonics"), st("opacities"))
@@ -168,7 +169,7 @@ def main():
     # MI355X guide prescribes for gfx950).  null when the file does not cover the kernel.
     traffic, valu_busy = None, None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists() and (B, Vt, args.ctx, args.res, args.sh_degree) == (10, 4, 1, 256, 0):
+    if pmc.exists() and (B, Vt, args.ctx, args.grid, args.res, args.sh_degree) == (10, 4, 1, 256, 256, 0):
         try:
             rec = json.loads(pmc.read_text()).get(dominant, {})
             traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac")
@@ -186,7 +187,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
-                                   f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x 256x256), sh_degree="
+                                   f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x {args.grid}x{args.grid}), sh_degree="
                                    f"{args.sh_degree}, make_scale_invariant, all views in one batched launch",
                        "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
             "roofline": roofline,
