@@ -104,6 +104,10 @@ int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, c
  * them itself when it splits M across workgroups and accumulates with fp32 atomics).
  */
 int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream);
+/* same, ADDING to the values dw / dbias already hold (no zeroing): lets the host point them at the zeroed slices of a
+ * gradient all-reduce bucket, so the gradient is produced in place (no memset per layer, no pack copy) and a weight used
+ * twice in one backward accumulates correctly */
+int vit_linear_x6_wgrad_acc(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream);
 
 /*
  * Convolution of the DPT heads (dpt_block.py:79-218,350-419; 3x3 pad 1 stride 1, or 1x1) as a bf16x6 implicit GEMM on NCHW

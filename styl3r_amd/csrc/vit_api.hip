@@ -20,7 +20,8 @@ int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int
                   int relu_in, hipStream_t stream);
 int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hipStream_t stream);
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
-int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream);
+int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
+                    hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
 }  // namespace vit
@@ -71,7 +72,12 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
 
 VIT_EXPORT int vit_linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream)
 {
-    return vit::linear_x6_wgrad(dy, x, dw, dbias, M, N, K, static_cast<hipStream_t>(stream));
+    return vit::linear_x6_wgrad(dy, x, dw, dbias, M, N, K, 0, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_linear_x6_wgrad_acc(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, void *stream)
+{
+    return vit::linear_x6_wgrad(dy, x, dw, dbias, M, N, K, 1, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, const float *residual, float *out,

@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
 // output is small (N x K) and the contraction long (M = 4 000..5 000), so gridDim.y workgroups split M and add their
 // partial tiles with fp32 atomics into the zeroed dW; workgroups of the first K-tile also accumulate db.
 __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ x,
-                                                     float *__restrict__ dw, float *__restrict__ dbias, int M, int N, int K)
+                                                     float *__restrict__ dw, float *__restrict__ dbias, int M, int N, int K,
+                                                     int accumulate)
 {
     constexpr int TN = 2, BN = 128;
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
@@ -383,7 +384,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
                 const int n = n0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (n >= N) continue;
                 float *o = dw + (int64_t)n * K + k;
-                if (single) *o = acc[i][j][r]; else atomicAdd(o, acc[i][j][r]);
+                if (!single) atomicAdd(o, acc[i][j][r]);
+                else if (accumulate) *o += acc[i][j][r];     // one workgroup owns the tile: plain read-add-write
+                else *o = acc[i][j][r];
             }
         }
     }
@@ -790,7 +793,8 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     return VIT_OK;
 }
 
-int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, hipStream_t stream)
+int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
+                    hipStream_t stream)
 {
     if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) return VIT_EINVAL;
     const int tiles = ((N + x6::BM - 1) / x6::BM) * ((K + 127) / 128);
@@ -798,11 +802,13 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     // split M so that tiles x S fills the 512 resident workgroups (256 CUs x 2) ONCE: 1.1 rounds cost as much as 2
     int S = split_count(tiles, nslab, 16);
     (void)hipGetLastError();
-    // one memset when the caller laid db out right behind dw (vit_ops.py does)
-    const bool joined = dbias == dw + (size_t)N * K;
-    if (S > 1 && hipMemsetAsync(dw, 0, ((size_t)N * K + (joined ? N : 0)) * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-    if (dbias && !(S > 1 && joined) && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-    hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K);
+    if (!accumulate) {   // accumulate: dw / dbias already hold the running gradient (e.g. a zeroed all-reduce bucket slice)
+        // one memset when the caller laid db out right behind dw (vit_ops.py does)
+        const bool joined = dbias == dw + (size_t)N * K;
+        if (S > 1 && hipMemsetAsync(dw, 0, ((size_t)N * K + (joined ? N : 0)) * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        if (dbias && !(S > 1 && joined) && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    }
+    hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

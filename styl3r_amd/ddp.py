@@ -21,8 +21,9 @@ from torch import nn
 
 
 class BucketedGradReducer:
-    def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20, inplace_grads: bool = True):
         self.dist = dist
+        self.inplace_grads = inplace_grads
         self.world = dist.get_world_size() if dist is not None else 1
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))
@@ -63,7 +64,8 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None]
+        # (gradients the kernels already produced in place -- vit_ops._FusedLinear with `_grad_slot` -- need no copy)
+        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         for p, v in zip(b["params"], b["views"]):
@@ -78,8 +80,11 @@ class BucketedGradReducer:
         torch._foreach_zero_([b["flat"] for b in self.buckets])
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
-            for p in b["params"]:
+            for p, v in zip(b["params"], b["views"]):
                 p.grad = None
+                # in-place gradient slot: layers that can (the bf16x6 Linear) accumulate dW / db straight into this zeroed
+                # slice of the bucket and hand it to autograd as the gradient (no per-layer memset, no pack copy)
+                p._grad_slot = {"view": v, "used": False} if self.inplace_grads else None
 
     def finish(self):
         """call after backward: reduce the buckets whose gradients never all arrived, wait, average."""
@@ -90,6 +95,9 @@ class BucketedGradReducer:
             h.wait()
         self._handles.clear()
         self._armed = False
+        for b in self.buckets:
+            for p in b["params"]:
+                p._grad_slot = None            # a backward outside prepare()/finish() must not write into the buckets
         if self.world > 1:
             torch._foreach_mul_([b["flat"] for b in self.buckets], 1.0 / self.world)
 

@@ -24,7 +24,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -80,6 +80,8 @@ def load() -> C.CDLL:
     lib.vit_linear_x6_fwd.restype = C.c_int
     lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_wgrad.restype = C.c_int
+    lib.vit_linear_x6_wgrad_acc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_x6_wgrad_acc.restype = C.c_int
     lib.vit_conv_x6_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_conv_x6_fwd.restype = C.c_int
     lib.vit_conv_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
@@ -459,6 +461,7 @@ class _FusedLinear(torch.autograd.Function):
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
         ctx.save_for_backward(x2, w, pre)
         ctx.weight_ref = weight if x6 else None
+        ctx.bias_ref = bias if x6 else None
         ctx.meta = (shp, bias is not None, residual is not None, act)
         return out.reshape(*shp[:-1], N)
 
@@ -484,6 +487,27 @@ class _FusedLinear(torch.autograd.Function):
             else:
                 dx = (g2 @ w).reshape(shp)
         dw = db = None
+        wslot = getattr(ctx.weight_ref, "_grad_slot", None) if ctx.weight_ref is not None else None
+        if need_w and wslot is not None:
+            # In-place gradients (ddp.BucketedGradReducer.prepare): dW / db are ACCUMULATED straight into the parameter's
+            # zeroed slice of its all-reduce bucket -- no per-layer memset, no pack copy afterwards.  The first use of
+            # a parameter in this backward hands the slice to autograd as its gradient; later uses (two encoder passes
+            # share the weights) have already added into the same memory and return None.
+            g2c = g2.contiguous().float()
+            N, K = w.shape
+            bslot = getattr(ctx.bias_ref, "_grad_slot", None) if (has_bias and need_b and ctx.bias_ref is not None) else None
+            _check(load().vit_linear_x6_wgrad_acc(g2c.data_ptr(), x2.data_ptr(), wslot["view"].data_ptr(),
+                                                  bslot["view"].data_ptr() if bslot is not None else None, g2c.shape[0], N, K,
+                                                  _stream(g.device)), "vit_linear_x6_wgrad_acc")
+            if not wslot["used"]:
+                wslot["used"] = True
+                dw = wslot["view"].detach()          # a fresh alias: autograd can adopt it as .grad without cloning
+            if bslot is not None and not bslot["used"]:
+                bslot["used"] = True
+                db = bslot["view"].detach()
+            if has_bias and need_b and bslot is None:
+                db = g2.sum(0)
+            return dx, dw, db, g_res, None
         if need_w and ctx.weight_ref is not None:         # dW (+ db in the same pass) on the bf16x6 kernel
             g2c = g2.contiguous().float()
             N, K = w.shape

@@ -115,3 +115,49 @@ def test_nvs_training_reduces_the_loss_end_to_end():
     assert all(torch.isfinite(torch.tensor(losses)))
     first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
     assert last < 0.9 * first and losses[-1] < losses[len(losses) // 2] < losses[0], (first, last, losses[::5])
+
+
+@pytest.mark.gpu
+def test_inplace_bucket_gradients_match_the_copy_path():
+    """BucketedGradReducer(inplace_grads=True): the bf16x6 Linear accumulates dW / db straight into the bucket slices (incl.
+    weights used by TWO encoder passes in one backward); every parameter gradient must equal the copy path's"""
+    from styl3r_amd.ddp import BucketedGradReducer
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tiny = dict(enc_depth=1, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
+                pos_embed="RoPE100", img_size=(512, 512))
+    enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=True), trunk_params=tiny).to(dev).eval()
+    g = torch.Generator(dev).manual_seed(2)
+    H = 64
+    ctx = dict(image=torch.rand(1, 2, 3, H, H, device=dev, generator=g) * 2 - 1,
+               intrinsics=torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]], device=dev).expand(1, 2, 3, 3).contiguous())
+    s1 = dict(image=torch.rand(1, 3, H, H, device=dev, generator=g) * 2 - 1)
+    s2 = dict(image=ctx["image"][:, 0])
+
+    def run(inplace):
+        params = [p for p in enc.parameters() if p.requires_grad]
+        red = BucketedGradReducer(params, None, bucket_bytes=8 << 20, inplace_grads=inplace)
+        red.prepare()
+        tot = 0
+        for st in (s1, s2):                                  # two passes through the same weights (style + identity)
+            gs = enc(ctx, st, 0)
+            tot = tot + (gs.means * 0.01).sum() + gs.harmonics.sum() * 0.1 + gs.opacities.sum() * 0.1 + gs.covariances.sum() * 1e3
+        tot.backward()
+        red.finish()
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in enc.named_parameters()}
+        adopted = sum(1 for b in red.buckets for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+        red.close()
+        return grads, adopted
+
+    ref, _ = run(False)
+    ref2, _ = run(False)                                      # run-to-run noise of the copy path itself (atomics, library convs)
+    got, adopted = run(True)
+    assert adopted > 20                                       # the Linear weights really live in the buckets
+    for n in ref:
+        if ref[n] is None:
+            assert got[n] is None or float(got[n].abs().max()) == 0.0, n
+            continue
+        scale = float(ref[n].abs().max())
+        noise = float((ref2[n] - ref[n]).abs().max())
+        assert float((got[n] - ref[n]).abs().max()) <= 1e-4 * scale + 4 * noise + 1e-12, (n, float((got[n] - ref[n]).abs().max()), noise, scale)
