@@ -1,0 +1,19 @@
+#!/bin/bash
+# Reproduces every number quoted in DESIGN.md section 6 / 8 on one MI355X (run from the repo root, ~6 minutes).
+# usage: bash tools/run_all_benchmarks.sh [outdir]      (default: gpurun_out/benchmarks)
+set -u
+OUT=${1:-gpurun_out/benchmarks}; mkdir -p "$OUT"
+run() { echo "== $*"; "$@" 2>&1 | tail -1 | tee -a "$OUT/all.jsonl" | cut -c1-260; }
+run python bench.py                                                              # headline M1 (+ roofline, CPU baseline)
+run python bench.py --grid 128 --no-cpu-baseline                                 # 16 384 Gaussians / scene
+run python bench.py --ctx 2 --no-cpu-baseline                                    # 131 072
+run python bench.py --ctx 4 --no-cpu-baseline                                    # 262 144
+run python bench.py --ctx 4 --res 512 --sh-degree 4 --scenes 3 --no-cpu-baseline # C5 stress shapes
+run python bench.py --grid 512 --ctx 4 --res 512 --scenes 2 --no-cpu-baseline    # 1 048 576
+run python tools/bench_train.py --config c3 --scenes 10 --steps 3 --warmup 2     # M2, C3
+run python tools/bench_train.py --config c3 --scenes 8 --steps 3 --warmup 2
+run python tools/bench_train.py --config c4 --scenes 2 --steps 2 --warmup 1      # style stage
+run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1      # 512^2 / sh 4 stress step
+run python tools/bench_infer.py                                                  # C2 inference
+run python tools/bench_vit.py                                                    # kernel microbenchmarks
+echo "results: $OUT/all.jsonl"
