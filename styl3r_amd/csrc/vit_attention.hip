@@ -213,6 +213,10 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
     }
 }
 
+int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
+int attention_fwd_tail(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, int rows,
+                       hipStream_t stream);
+
 int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse,
                   hipStream_t stream)
 {
@@ -222,12 +226,16 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     if (rope && (!a.sin_tab || !a.qpos || !a.kpos || a.P <= 0)) return VIT_EINVAL;
     // float4 epilogue / V loads need 16-byte aligned rows
     if ((a.o_sn | a.o_sh | a.o_sb | a.v_sn | a.v_sh | a.v_sb) & 3) return VIT_EINVAL;
-    const dim3 grid((a.Nq + QB - 1) / QB, a.H, a.B);
+    // 257 = 2 x 128 + 1 queries: the last 1..4 rows go to the vector kernel (vit_attention_tail.hip) instead of a third,
+    // almost empty workgroup per (batch, head) that would open a second round on the chip
+    const int tail_rows = attention_tail_rows(a.Nq, a.Nk, a.H * a.B);
+    const dim3 grid((a.Nq - tail_rows + QB - 1) / QB, a.H, a.B);
     (void)hipGetLastError();
     if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
     else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    if (tail_rows) return attention_fwd_tail(a, q, k, v, out, lse, tail_rows, stream);
     return VIT_OK;
 }
 }  // namespace vit

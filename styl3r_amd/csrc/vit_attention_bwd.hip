@@ -278,6 +278,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd_q(VitAttnArgs a, const float *
     }
 }
 
+int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
+int attention_bwd_tails(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *lse, const float *dout,
+                        const float *delta, float *dq, float *dk, float *dv, int q_rows, int k_rows, hipStream_t stream);
+
 int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *out, const float *lse,
                   const float *dout, float *dq, float *dk, float *dv, float *delta_ws, hipStream_t stream)
 {
@@ -288,7 +292,10 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     (void)hipGetLastError();
     const long long rows = (long long)a.B * a.Nq * a.H;
     hipLaunchKernelGGL(k_attn_delta, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, stream, out, dout, delta_ws, a.B, a.H, a.Nq);
-    const dim3 gkv((a.Nk + 127) / 128, a.H, a.B), gq((a.Nq + 127) / 128, a.H, a.B);
+    // the last 1..4 rows of a 128 n + r problem (257 tokens) go to the vector kernels of vit_attention_tail.hip: a third,
+    // almost empty workgroup per (batch, head) would open a second round on the chip (+63 % measured)
+    const int q_tail = attention_tail_rows(a.Nq, a.Nk, a.H * a.B), k_tail = attention_tail_rows(a.Nk, a.Nq, a.H * a.B);
+    const dim3 gkv((a.Nk - k_tail + 127) / 128, a.H, a.B), gq((a.Nq - q_tail + 127) / 128, a.H, a.B);
     if (rope) {
         hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
         hipLaunchKernelGGL(k_attn_bwd_q<true>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
@@ -298,6 +305,7 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    if (q_tail || k_tail) return attention_bwd_tails(a, q, k, v, lse, dout, delta_ws, dq, dk, dv, q_tail, k_tail, stream);
     return VIT_OK;
 }
 }  // namespace vit

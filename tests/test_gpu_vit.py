@@ -49,7 +49,7 @@ def test_rope_kernel_matches_reference_golden_and_is_inplace_on_views():
     assert torch.equal(qkv[:, :, 1:], before[:, :, 1:])   # k, v untouched
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1), (11, 16, 257, 257), (11, 16, 260, 129), (1, 1, 1025, 1025)])
 def test_attention_forward_vs_oracle(B, H, Nq, Nk):
     from styl3r_amd.vit_ops import memory_efficient_attention
     g = torch.Generator(DEV).manual_seed(Nq * 7 + Nk)
@@ -76,7 +76,8 @@ def test_attention_forward_fused_rope_on_qkv_views():
     assert_close_rel(out.cpu().numpy(), ref, 1e-5, "attention fwd + fused rope")
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, False), (1, 2, 130, 771, True), (1, 1, 5, 1, False), (2, 2, 33, 160, True)])
+@pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, False), (1, 2, 130, 771, True), (1, 1, 5, 1, False), (2, 2, 33, 160, True),
+                                             (11, 16, 257, 257, True), (11, 16, 259, 514, True), (1, 2, 256, 130, True)])   # 11 x 16 heads: the tail-row kernels kick in (they need > 512 workgroups)
 def test_attention_backward_vs_oracle(B, H, Nq, Nk, rope):
     from styl3r_amd.vit_ops import memory_efficient_attention
     g = torch.Generator(DEV).manual_seed(Nq * 3 + Nk)
