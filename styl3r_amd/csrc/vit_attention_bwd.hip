@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_kv(VitAttnArgs a, const float 
 
 // ------------------------------------------------------------------ dQ
 template <bool ROPE>
-__global__ void __launch_bounds__(256) k_attn_bwd_q(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
+__global__ void __launch_bounds__(256, 3) k_attn_bwd_q(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
                                                     const float *__restrict__ v, const float *__restrict__ g,
                                                     const float *__restrict__ lse, const float *__restrict__ delta,
                                                     float *__restrict__ dq)

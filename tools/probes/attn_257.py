@@ -8,7 +8,7 @@ def timeit(fn, iters=20, warm=5):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / iters
 for N in (256, 257, 288, 320):
-    B, H = 16, 16
+    B, H = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 16
     q = torch.randn(B, N, H, 64, device=dev, requires_grad=True); k = torch.randn(B, N, H, 64, device=dev, requires_grad=True); v = torch.randn(B, N, H, 64, device=dev, requires_grad=True)
     pos = torch.zeros(B, N, 2, dtype=torch.int64, device=dev)
     f = lambda: vit_ops.memory_efficient_attention(q, k, v, 0.125, qpos=pos, kpos=pos, max_pos=64)
