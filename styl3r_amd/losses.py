@@ -20,6 +20,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from .vit_ops import Conv2dX6   # nn.Conv2d on the CPU; bf16x6 implicit-GEMM kernels for eligible layers on the GPU
+
 _VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512]   # features[:21] ends after relu4_1
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
@@ -40,7 +42,7 @@ class VGGEncoder(nn.Module):
             if v == "M":
                 layers.append(nn.MaxPool2d(2, 2))
             else:
-                layers += [nn.Conv2d(c_in, v, 3, padding=1), nn.ReLU(inplace=False)]
+                layers += [Conv2dX6(c_in, v, 3, padding=1), nn.ReLU(inplace=False)]
                 c_in = v
         self.features = nn.Sequential(*layers)
         assert len(self.features) == 21
@@ -202,7 +204,7 @@ class _LpipsVgg16(nn.Module):
             if s > 1:
                 block.add_module(str(idx), nn.MaxPool2d(2, 2)); idx += 1
             for w in widths:
-                block.add_module(str(idx), nn.Conv2d(c_in, w, 3, padding=1)); idx += 1
+                block.add_module(str(idx), Conv2dX6(c_in, w, 3, padding=1)); idx += 1
                 block.add_module(str(idx), nn.ReLU(inplace=False)); idx += 1
                 c_in = w
             setattr(self, f"slice{s}", block)

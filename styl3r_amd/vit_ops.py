@@ -329,6 +329,7 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # (1.2-1.7x) once the 128 x 128 output tiles fill the chip; with fewer tiles it splits K across workgroups (atomics) and is on par down to ~100 tiles, slower below (measured,
 # tools/probes/conv_small.py); smaller problems stay on the library path
 _CONV_X6_MIN_TILES = 100
+_CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0}   # how often each bf16x6 convolution kernel was taken (tests)
 
 
@@ -357,7 +358,7 @@ class _ConvX6(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = None
         if need_x:
-            if weight.shape[0] % 16 == 0 and weight.shape[1] >= 64 and _conv_tiles(weight.shape[1], g) >= _CONV_X6_MIN_TILES:
+            if weight.shape[0] % 16 == 0 and weight.shape[1] >= _CONV_X6_MIN_ROWS and _conv_tiles(weight.shape[1], g) >= _CONV_X6_MIN_TILES:
                 B, Co, H, W = g.shape
                 Ci = weight.shape[1]
                 dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
@@ -386,7 +387,7 @@ class _ConvX6(torch.autograd.Function):
 
 class Conv2dX6(nn.Conv2d):
     """nn.Conv2d whose forward / input gradient run on vit_conv_x6_fwd when the layer qualifies (k in {1, 3}, stride 1,
-    padding k // 2, no dilation / groups, Ci % 16 == 0, Co >= 64) and the input is a device fp32 tensor in bf16x6 mode;
+    padding k // 2, no dilation / groups, Ci % 16 == 0, Co >= 96) and the input is a device fp32 tensor in bf16x6 mode;
     otherwise the stock MIOpen path.  Same parameters / state_dict keys as nn.Conv2d."""
 
     def _x6_ok(self, x: Tensor) -> bool:
@@ -394,7 +395,7 @@ class Conv2dX6(nn.Conv2d):
         return (LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.padding == (k // 2, k // 2)
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
-                and self.in_channels % 16 == 0 and self.out_channels >= 64
+                and self.in_channels % 16 == 0 and self.out_channels >= _CONV_X6_MIN_ROWS
                 and _conv_tiles(self.out_channels, x) >= _CONV_X6_MIN_TILES)
 
     def forward(self, x: Tensor) -> Tensor:

@@ -33,3 +33,35 @@ def test_mse_noncontiguous_and_cpu_dispatch():
     b = torch.rand(8, 6, 4, device=dev)
     assert torch.allclose(mse_loss(a, b), ((a - b) ** 2).mean(), rtol=1e-6)
     assert torch.allclose(mse_loss(a.cpu(), b.cpu()), ((a - b) ** 2).mean().cpu(), rtol=1e-6)   # CPU tensors: torch expression
+
+
+def test_vgg_encoder_runs_on_the_bf16x6_convolutions_and_matches_fp64(monkeypatch):
+    """VGGEncoder (relu1_1 .. relu4_1, src/test/vgg_model.py:79-98 in the reference) on the GPU: the layers with >= 96
+    output channels take vit_conv_x6_fwd (forward and input gradient); features and d(sum of features)/d(image) agree
+    with the same network evaluated in fp64 by the framework's convolution."""
+    from styl3r_amd import vit_ops
+    from styl3r_amd.losses import VGGEncoder
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = VGGEncoder().to(dev)
+    ref = VGGEncoder().double().to(dev)
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x = torch.rand(8, 3, 128, 128, device=dev).requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    before = dict(vit_ops.CALLS)
+    feats = net(x)
+    sum(f.square().mean() for f in feats).backward()
+    assert vit_ops.CALLS["conv_x6_fwd"] - before["conv_x6_fwd"] >= 6      # conv2_1 .. conv4_1 (conv1_x: 64 channels -> MIOpen)
+    assert vit_ops.CALLS["conv_x6_dx"] - before["conv_x6_dx"] >= 4        # those with >= 96 input channels and >= 100 tiles
+    feats64 = ref(x64)                                                       # fp64 tensors never take the x6 path
+    sum(f.square().mean() for f in feats64).backward()
+    for f, f64 in zip(feats, feats64):
+        assert float((f.double() - f64).abs().max() / f64.abs().max()) < 2e-5
+    # the input gradient crosses seven ReLUs: an activation within fp32 round-off of zero flips its mask between fp32
+    # and fp64, so the yardstick is the framework's own fp32 convolution against the same fp64 reference
+    err_x6 = float((x.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f32")                       # Conv2dX6 -> nn.Conv2d (MIOpen)
+    x32 = x.detach().clone().requires_grad_(True)
+    sum(f.square().mean() for f in net(x32)).backward()
+    err_lib = float((x32.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())
+    assert err_x6 < max(1e-4, 3 * err_lib), (err_x6, err_lib)

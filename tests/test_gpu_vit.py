@@ -248,6 +248,7 @@ def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias, mon
     torch.manual_seed(B * 100 + Ci)
     from styl3r_amd import vit_ops
     monkeypatch.setattr(vit_ops, "_CONV_X6_MIN_TILES", 0)          # force the bf16x6 kernels at these small test sizes
+    monkeypatch.setattr(vit_ops, "_CONV_X6_MIN_ROWS", 16)
     m = Conv2dX6(Ci, Co, k, 1, k // 2, bias=bias).to(DEV)
     assert m._x6_ok(torch.empty(1, Ci, 4, 4, device=DEV))
     x = torch.randn(B, Ci, H, W, device=DEV, requires_grad=True)
