@@ -115,7 +115,12 @@ int vit_linear_x6_wgrad_acc(const float *dy, const float *x, float *dw, float *d
  * (ResidualConvUnit applies its activation BEFORE each convolution, dpt_block.py:  out = conv2(act(conv1(act(x)))) + x).
  * w_packed = vit_split_weight of the weight rearranged to (Co, ksize*ksize*Ci) with k = tap * Ci + ci, tap = ky * ksize + kx.
  * The same entry computes the input gradient from the spatially flipped, channel-transposed weight.  Ci % 16 == 0.
+ * `relu_in` is a flag word: bit 0 = ReLU on the input; bit 1 (VIT_CONV_GATE) = `residual` is not added but used as a sign
+ * gate, out = residual > 0 ? conv : 0 -- the input gradient of a ReLU-fused convolution with residual := its forward
+ * input (bias must be NULL).
  */
+#define VIT_CONV_RELU_IN 1
+#define VIT_CONV_GATE 2
 int vit_conv_x6_fwd(const float *in, const void *w_packed, const float *bias, const float *residual, float *out, int B, int Ci,
                     int Co, int H, int W, int ksize, int relu_in, void *stream);
 

@@ -400,10 +400,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
 // transposing loader of the weight-gradient kernel (lane = pixel, eight 4-byte loads walk the channels of one tap, lanes
 // are consecutive pixels = consecutive addresses), borders are clamped addresses + a zero mask.  D[co][pixel] has the
 // pixel on the lane, so every accumulator register stores a coalesced run of one output channel.
+// Epilogue: + bias, + residual (the skip connection of a ResidualConvUnit), or -- `gate` -- the ReLU mask of the
+// backward pass; RELU_IN applies the unit's ReLU while the activations are staged (no separate ReLU pass / tensor).
 template <int KS, bool RELU_IN>
 __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in, const uint4 *__restrict__ wp,
                                                     const float *__restrict__ bias, const float *__restrict__ residual,
-                                                    float *__restrict__ out, int B, int Ci, int Co, int H, int W)
+                                                    float *__restrict__ out, int B, int Ci, int Co, int H, int W, int gate)
 {
     constexpr int TN = 2, BN = 128, TAPS = KS * KS;
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
@@ -532,7 +534,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
                 const int64_t o = obase + (int64_t)co * HW;
                 const bool first = blockIdx.y == 0;
                 float t = acc[i][j][r] + ((bias && first) ? bias[co] : 0.f);
-                if (residual && first) t += residual[o];
+                // gate: `residual` is the forward input of a ReLU-fused convolution and this launch computes its input
+                // gradient: dX = (x > 0) ? conv^T(dY) : 0 (every K split gates its own partial sum)
+                if (residual) { const float rv = residual[o]; if (gate) t = rv > 0.f ? t : 0.f; else if (first) t += rv; }
                 if (gridDim.y == 1) out[o] = t; else atomicAdd(out + o, t);
             }
         }
@@ -814,8 +818,10 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     return VIT_OK;
 }
 int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float *residual, float *out, int B, int Ci, int Co,
-                int H, int W, int ksize, int relu_in, hipStream_t stream)
+                int H, int W, int ksize, int flags, hipStream_t stream)
 {
+    const int relu_in = flags & 1, gate = (flags >> 1) & 1;
+    if (gate && (!residual || bias)) return VIT_EINVAL;
     if (!in || !wp || !out || B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return VIT_EINVAL;
     if ((ksize != 1 && ksize != 3) || (Ci % x6::BK) != 0) return VIT_EINVAL;
     const int64_t NP = (int64_t)B * H * W;
@@ -828,7 +834,7 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     const int nslab = ksize * ksize * Ci / x6::BK;
     if (tiles < 256) { S = (int)(512 / tiles); while (S > 1 && nslab / S < 8) --S; if (S < 1) S = 1; if (S > 16) S = 16; }
     if (S > 1 && hipMemsetAsync(out, 0, (size_t)NP * Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W)
+#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
     else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
 #undef VIT_LAUNCH_C6

@@ -245,9 +245,8 @@ class _ResidualConvUnit(nn.Module):
         self.conv2 = Conv2dX6(features, features, 3, 1, 1, bias=True)
 
     def forward(self, x):
-        out = self.conv1(F.relu(x))
-        out = self.conv2(F.relu(out))
-        return out + x
+        # conv2(relu(conv1(relu(x)))) + x with both ReLUs and the skip add inside the convolution kernels
+        return self.conv2.forward_fused(self.conv1.forward_fused(x), x)
 
 
 class _FusionBlock(nn.Module):

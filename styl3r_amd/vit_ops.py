@@ -338,17 +338,21 @@ def _conv_tiles(out_channels: int, x: Tensor) -> int:
 
 
 class _ConvX6(torch.autograd.Function):
-    """conv2d (3x3 pad 1 / 1x1, stride 1) on the bf16x6 implicit-GEMM kernel: forward and input gradient hand-written
-    (dX = the same kernel on the flipped, channel-transposed weight); the weight / bias gradients go through the library
-    (aten::convolution_backward)."""
+    """out = [residual +] bias + conv2d(f(x), weight) (3x3 pad 1 / 1x1, stride 1; f = ReLU if relu_in) on the bf16x6
+    implicit-GEMM kernels: forward, input gradient (the same kernel on the flipped, channel-transposed weight, with the
+    ReLU mask applied in its epilogue) and weight / bias gradients (vit_conv_x6_wgrad, which applies the ReLU while it
+    stages the input); small problems fall back to aten::convolution_backward per gradient.  With relu_in and residual a
+    ResidualConvUnit (dpt_block.py:79-118: conv2(act(conv1(act(x)))) + x) is two launches forward and no ReLU / add
+    passes or ReLU'd copies of the activations in either direction."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None, relu_in=False):
         _need_gpu(x, "conv2d")
+        x = x.contiguous().float()
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.has_res, ctx.relu_in = bias is not None, residual is not None, bool(relu_in)
         CALLS["conv_x6_fwd"] += 1
-        return conv_x6_forward(x, weight, bias)
+        return conv_x6_forward(x, weight, bias, residual, relu_in)
 
     @staticmethod
     def backward(ctx, g):
@@ -356,6 +360,15 @@ class _ConvX6(torch.autograd.Function):
         g = g.contiguous().float()
         k = weight.shape[2]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        need_r = ctx.has_res and ctx.needs_input_grad[3]
+        xin = None                                          # f(x), materialised only for a library fallback
+
+        def f_x():
+            nonlocal xin
+            if xin is None:
+                xin = torch.relu(x) if ctx.relu_in else x
+            return xin
+
         dx = None
         if need_x:
             if weight.shape[0] % 16 == 0 and weight.shape[1] >= _CONV_X6_MIN_ROWS and _conv_tiles(weight.shape[1], g) >= _CONV_X6_MIN_TILES:
@@ -363,11 +376,14 @@ class _ConvX6(torch.autograd.Function):
                 Ci = weight.shape[1]
                 dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
                 CALLS["conv_x6_dx"] += 1
-                _check(load().vit_conv_x6_fwd(g.data_ptr(), split_conv_weight(weight, True).data_ptr(), None, None, dx.data_ptr(),
-                                              B, Co, Ci, H, W, k, 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
+                _check(load().vit_conv_x6_fwd(g.data_ptr(), split_conv_weight(weight, True).data_ptr(), None,
+                                              x.data_ptr() if ctx.relu_in else None, dx.data_ptr(),
+                                              B, Co, Ci, H, W, k, 2 if ctx.relu_in else 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
             else:
-                dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                dx = torch.ops.aten.convolution_backward(g, f_x(), weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
+                if ctx.relu_in:
+                    dx = dx * (x > 0)
         dw = db = None
         B_, _, H_, W_ = g.shape
         # dW (+ db) on the bf16x6 split-pixel kernel when there are enough pixels to split (>= 64 x 64 x 16; below that the
@@ -375,14 +391,14 @@ class _ConvX6(torch.autograd.Function):
         if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and B_ * H_ * W_ >= 65536:
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
-            xc = x.contiguous().float()
             CALLS["conv_x6_wgrad"] += 1
-            _check(load().vit_conv_x6_wgrad(g.data_ptr(), xc.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
-                                            B_, weight.shape[1], weight.shape[0], H_, W_, k, 0, _stream(g.device)), "vit_conv_x6_wgrad")
+            _check(load().vit_conv_x6_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
+                                            B_, weight.shape[1], weight.shape[0], H_, W_, k, 1 if ctx.relu_in else 0,
+                                            _stream(g.device)), "vit_conv_x6_wgrad")
         elif need_w or need_b:
-            _, dw, db = torch.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
+            _, dw, db = torch.ops.aten.convolution_backward(g, f_x(), weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
                                                             [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
-        return dx, dw, db
+        return dx, dw, db, (g if need_r else None), None
 
 
 class Conv2dX6(nn.Conv2d):
@@ -402,6 +418,13 @@ class Conv2dX6(nn.Conv2d):
         if self._x6_ok(x):
             return _ConvX6.apply(x, self.weight, self.bias)
         return super().forward(x)
+
+    def forward_fused(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        """[residual +] conv(relu(x)): one launch on the bf16x6 kernel when the layer qualifies, the plain sequence otherwise."""
+        if self._x6_ok(x):
+            return _ConvX6.apply(x, self.weight, self.bias, residual, True)
+        out = super().forward(torch.relu(x))
+        return out if residual is None else out + residual
 
 
 class _Upsample2x(torch.autograd.Function):

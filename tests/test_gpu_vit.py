@@ -283,6 +283,44 @@ def test_conv_x6_weight_gradient_kernel_matches_fp64(B, Ci, Co, H, W, k):
     assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 5e-6, "conv db (x6)")
 
 
+@pytest.mark.parametrize("B,C,H,W,force", [(2, 32, 9, 13, True), (1, 144, 17, 8, True), (16, 32, 64, 64, True), (2, 32, 8, 8, False)])
+def test_residual_conv_unit_fused_relu_and_skip_match_fp64(B, C, H, W, force, monkeypatch):
+    """_ResidualConvUnit (dpt_block.py:79-118: conv2(relu(conv1(relu(x)))) + x) with both ReLUs and the skip add inside the
+    convolution kernels (relu_in staging, residual epilogue; backward: sign-gate epilogue of the dX launch, relu_in in the
+    weight-gradient kernel, skip gradient passed through) against the plain sequence in fp64.  Inputs keep a margin from
+    zero so that no ReLU mask depends on fp32 round-off.  force=False: the small-problem fallback (library convolutions)."""
+    from styl3r_amd import vit_ops
+    from styl3r_amd.encoder import _ResidualConvUnit
+    torch.manual_seed(B * 7 + C)
+    if force:
+        monkeypatch.setattr(vit_ops, "_CONV_X6_MIN_TILES", 0)
+        monkeypatch.setattr(vit_ops, "_CONV_X6_MIN_ROWS", 16)
+    m = _ResidualConvUnit(C).to(DEV)
+    x = torch.randn(B, C, H, W, device=DEV)
+    x = (x + 0.05 * torch.sign(x)).requires_grad_(True)
+    before = dict(vit_ops.CALLS)
+    y = m(x)
+    gy = torch.randn_like(y)
+    (y * gy).sum().backward()
+    took = {k: vit_ops.CALLS[k] - before[k] for k in before}
+    assert took["conv_x6_fwd"] == (2 if force else 0) and took["conv_x6_dx"] == (2 if force else 0), took
+    assert took["conv_x6_wgrad"] == (2 if force and B * H * W >= 65536 else 0), took
+    md = _ResidualConvUnit(C).double().to(DEV)
+    md.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    xd = x.detach().double().requires_grad_(True)
+    mid = torch.nn.functional.conv2d(torch.relu(xd), md.conv1.weight, md.conv1.bias, padding=1)
+    ref = torch.nn.functional.conv2d(torch.relu(mid), md.conv2.weight, md.conv2.bias, padding=1) + xd
+    (ref * gy.double()).sum().backward()
+    # (the intermediate activation can sit within round-off of zero: compare where its ReLU mask is unambiguous)
+    safe = bool((mid.detach().abs() > 1e-5).all())
+    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "rcu fwd")
+    tol = 2e-5 if safe else 2e-3
+    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), tol, "rcu dx")
+    for name in ("conv1", "conv2"):
+        assert_close_rel(getattr(m, name).weight.grad.cpu().numpy(), getattr(md, name).weight.grad.cpu().numpy(), max(tol, 3e-5), name + " dw")
+        assert_close_rel(getattr(m, name).bias.grad.cpu().numpy(), getattr(md, name).bias.grad.cpu().numpy(), max(tol, 3e-5), name + " db")
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 8, 8), (1, 3, 16, 24), (3, 4, 1, 2), (2, 16, 64, 64)])
 def test_upsample2x_matches_framework_bilinear_align_corners(shape):
     from styl3r_amd.vit_ops import upsample2x
