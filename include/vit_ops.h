@@ -132,6 +132,21 @@ int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias,
                       int relu_in, void *stream);
 
 /*
+ * LayerNorm over the last dimension of a row-major (M, C) fp32 tensor (croco/blocks.py:144-152,205-222 norm1..3 / norm_y,
+ * the trunks' enc_norm / dec_norm; nn.LayerNorm(C, eps=1e-6) semantics: biased variance, y = (x - mean) * rstd * gamma + beta).
+ * C % 256 == 0, C <= 2048.  The forward also returns the per-row mean / rstd the backward needs.
+ * Backward: dx = LayerNorm input gradient [+ dskip]; `dskip` (nullable) is the gradient that arrived at the residual
+ * branch of a pre-norm block (x + f(LN(x))): adding it here replaces the framework's separate (M, C) add.  dgamma / dbeta
+ * (dbeta nullable) are overwritten, or added to when accumulate != 0.  scratch: vit_layernorm_scratch_bytes(M, C) bytes.
+ */
+size_t vit_layernorm_scratch_bytes(int M, int C);
+int vit_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd, int M, int C,
+                      float eps, void *stream);
+int vit_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma,
+                      const float *dskip, float *dx, float *dgamma, float *dbeta, void *scratch, int M, int C, int accumulate,
+                      void *stream);
+
+/*
  * F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) of the DPT heads (dpt_block.py Interpolate /
  * FeatureFusionBlock): in (planes, H, W) -> out (planes, 2H, 2W), planes = B*C of a contiguous NCHW tensor; W even.
  */

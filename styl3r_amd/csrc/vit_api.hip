@@ -19,6 +19,11 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
 int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
                   int relu_in, hipStream_t stream);
 int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hipStream_t stream);
+size_t layernorm_scratch_bytes(int M, int C);
+int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd, int M, int C,
+                  float eps, hipStream_t stream);
+int layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, const float *dskip,
+                  float *dx, float *dgamma, float *dbeta, float *scratch, int M, int C, int accumulate, hipStream_t stream);
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
                     hipStream_t stream);
@@ -90,6 +95,22 @@ VIT_EXPORT int vit_conv_x6_wgrad(const float *dy, const float *in, float *dw, fl
                                  int ksize, int relu_in, void *stream)
 {
     return vit::conv_x6_wgrad(dy, in, dw, dbias, B, Ci, Co, H, W, ksize, relu_in, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT size_t vit_layernorm_scratch_bytes(int M, int C) { return vit::layernorm_scratch_bytes(M, C); }
+
+VIT_EXPORT int vit_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd, int M,
+                                 int C, float eps, void *stream)
+{
+    return vit::layernorm_fwd(x, gamma, beta, y, mean, rstd, M, C, eps, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma,
+                                 const float *dskip, float *dx, float *dgamma, float *dbeta, void *scratch, int M, int C,
+                                 int accumulate, void *stream)
+{
+    return vit::layernorm_bwd(dy, x, mean, rstd, gamma, dskip, dx, dgamma, dbeta, static_cast<float *>(scratch), M, C, accumulate,
+                              static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream)

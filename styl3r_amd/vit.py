@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from .vit_ops import fused_linear, memory_efficient_attention
+from .vit_ops import LayerNorm, fused_linear, memory_efficient_attention
 
 # Linear layers of the blocks run on the fused fp32-MFMA kernel (bias / exact GELU / residual in the
 # epilogue); set to False to route them through torch.nn.functional.linear (hipBLASLt) instead.
@@ -79,6 +79,14 @@ class Attention(nn.Module):
         return _linear(self.proj, o.reshape(B, N, C), residual=residual)
 
 
+def _norm_skip(norm: nn.Module, x: Tensor):
+    """(norm(x), x): for vit_ops.LayerNorm the pair comes from ONE autograd node, so the gradient of the residual branch and
+    the LayerNorm input gradient are summed inside vit_layernorm_bwd instead of by a separate add over the (B, N, C) tensor."""
+    if isinstance(norm, LayerNorm):
+        return norm.forward_skip(x)
+    return norm(x), x
+
+
 class Block(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm, rope=None):
@@ -90,8 +98,10 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def forward(self, x: Tensor, xpos: Tensor) -> Tensor:
-        x = self.attn(self.norm1(x), xpos, residual=x)        # x + attn(...): residual add in the proj epilogue
-        x = self.mlp(self.norm2(x), residual=x)
+        h, xs = _norm_skip(self.norm1, x)
+        x = self.attn(h, xpos, residual=xs)                   # x + attn(...): residual add in the proj epilogue
+        h, xs = _norm_skip(self.norm2, x)
+        x = self.mlp(h, residual=xs)
         return x
 
 
@@ -137,11 +147,14 @@ class DecoderBlock(nn.Module):
         self.norm_y = norm_layer(dim) if norm_mem else nn.Identity()
 
     def forward(self, x: Tensor, y: Tensor, xpos: Tensor, ypos: Tensor):
-        x = self.attn(self.norm1(x), xpos, residual=x)
+        h, xs = _norm_skip(self.norm1, x)
+        x = self.attn(h, xpos, residual=xs)
         y_ = self.norm_y(y)
-        x = self.cross_attn(self.norm2(x), y_, y_, xpos, ypos, residual=x)
-        x = self.mlp(self.norm3(x), residual=x)
+        h, xs = _norm_skip(self.norm2, x)
+        x = self.cross_attn(h, y_, y_, xpos, ypos, residual=xs)
+        h, xs = _norm_skip(self.norm3, x)
+        x = self.mlp(h, residual=xs)
         return x, y
 
 
-LayerNorm6 = partial(nn.LayerNorm, eps=1e-6)   # croco.py:34 norm_layer=partial(nn.LayerNorm, eps=1e-6)
+LayerNorm6 = partial(LayerNorm, eps=1e-6)   # croco.py:34 norm_layer=partial(nn.LayerNorm, eps=1e-6); vit_ops.LayerNorm: same parameters, HIP kernels

@@ -22,9 +22,10 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_version", "vit_last_error")
+           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -90,6 +91,12 @@ def load() -> C.CDLL:
     lib.vit_upsample2x_fwd.restype = C.c_int
     lib.vit_upsample2x_bwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
     lib.vit_upsample2x_bwd.restype = C.c_int
+    lib.vit_layernorm_scratch_bytes.argtypes = [C.c_int, C.c_int]
+    lib.vit_layernorm_scratch_bytes.restype = C.c_size_t
+    lib.vit_layernorm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]
+    lib.vit_layernorm_fwd.restype = C.c_int
+    lib.vit_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_layernorm_bwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -552,3 +559,67 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
                  gelu: bool = False) -> Tensor:
     """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd)."""
     return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0)
+
+
+# --------------------------------------------------------------------------- LayerNorm (E2, E5, E6: norm1..3, norm_y, enc/dec_norm)
+class _LayerNormHip(torch.autograd.Function):
+    """y = LayerNorm(x) on vit_layernorm_fwd / vit_layernorm_bwd.  with_skip: also returns x itself as a second output for
+    the block's residual branch; the backward then receives the skip gradient together with dy and adds it inside the
+    kernel (dx = dskip + LN'(dy)) instead of leaving an (M, C) add to the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, with_skip):
+        _need_gpu(x, "layer_norm")
+        ctx.set_materialize_grads(False)
+        Cn = x.shape[-1]
+        xc = x.contiguous().float()
+        M = xc.numel() // Cn
+        y = torch.empty_like(xc)
+        stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+        _check(load().vit_layernorm_fwd(xc.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                        stats[0].data_ptr(), stats[1].data_ptr(), M, Cn, float(eps), _stream(x.device)), "vit_layernorm_fwd")
+        ctx.save_for_backward(xc, weight, stats)
+        ctx.has_bias, ctx.with_skip = bias is not None, bool(with_skip)
+        if with_skip:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g, gskip=None):
+        xc, weight, stats = ctx.saved_tensors
+        Cn = xc.shape[-1]
+        M = xc.numel() // Cn
+        dev = xc.device
+        if g is None:                       # only the skip branch received a gradient
+            return gskip, None, None, None, None
+        g = g.contiguous().float()
+        gs = gskip.contiguous().float() if gskip is not None else None
+        dx = torch.empty_like(xc)
+        dwb = torch.empty((2, Cn), dtype=torch.float32, device=dev)
+        scratch = torch.empty(load().vit_layernorm_scratch_bytes(M, Cn), dtype=torch.uint8, device=dev)
+        _check(load().vit_layernorm_bwd(g.data_ptr(), xc.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), weight.data_ptr(),
+                                        gs.data_ptr() if gs is not None else None, dx.data_ptr(), dwb[0].data_ptr(),
+                                        dwb[1].data_ptr(), scratch.data_ptr(), M, Cn, 0, _stream(dev)), "vit_layernorm_bwd")
+        return dx, dwb[0], (dwb[1] if ctx.has_bias else None), None, None
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict keys) whose forward and backward run on the HIP kernels for device fp32
+    inputs with C % 256 == 0, C <= 2048 (the trunks' 1024 / 768); anything else takes the framework path.
+    `forward_skip(x) -> (LN(x), x)`: the second output is x for the residual branch of a pre-norm block, so that the two
+    gradients of x meet inside vit_layernorm_bwd."""
+
+    def _hip_ok(self, x: Tensor) -> bool:
+        Cn = x.shape[-1]
+        return (x.is_cuda and x.dtype == torch.float32 and len(self.normalized_shape) == 1 and self.weight is not None
+                and Cn % 256 == 0 and Cn <= 2048 and x.numel() > 0)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self._hip_ok(x):
+            return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, False)
+        return super().forward(x)
+
+    def forward_skip(self, x: Tensor):
+        if self._hip_ok(x) and torch.is_grad_enabled() and x.requires_grad:
+            return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, True)
+        return self.forward(x), x

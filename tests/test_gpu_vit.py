@@ -336,3 +336,56 @@ def test_upsample2x_matches_framework_bilinear_align_corners(shape):
     x2 = x.detach().clone().requires_grad_(True)
     torch.nn.functional.interpolate(x2, scale_factor=2, mode="bilinear", align_corners=True).backward(g)
     assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,bias", [((4, 257, 1024), True), ((2, 33, 768), True), ((5, 256), True), ((1, 1025, 1024), False),
+                                         ((3000, 512), True)])
+def test_layernorm_kernels_match_fp64_with_and_without_skip(shape, bias):
+    """vit_layernorm_fwd / vit_layernorm_bwd (nn.LayerNorm(C, eps=1e-6) semantics) vs fp64: output, dx, dgamma, dbeta;
+    forward_skip: the residual-branch gradient is added inside the backward kernel (dx = dskip + LN'(dy))."""
+    from styl3r_amd.vit_ops import LayerNorm
+    torch.manual_seed(shape[0])
+    C = shape[-1]
+    m = LayerNorm(C, eps=1e-6, bias=bias).to(DEV)
+    with torch.no_grad():
+        m.weight.copy_(1 + 0.3 * torch.randn(C, device=DEV))
+        if bias:
+            m.bias.copy_(0.2 * torch.randn(C, device=DEV))
+    x = (3 * torch.randn(shape, device=DEV) + 0.7).requires_grad_(True)
+    gy, gs = torch.randn(shape, device=DEV), torch.randn(shape, device=DEV)
+    xd = x.detach().double().requires_grad_(True)
+    wd = m.weight.detach().double().requires_grad_(True)
+    bd = m.bias.detach().double().requires_grad_(True) if bias else None
+    for skip in (False, True):
+        x.grad = m.weight.grad = None
+        if bias:
+            m.bias.grad = None
+        xd.grad = wd.grad = None
+        if bias:
+            bd.grad = None
+        ref = torch.nn.functional.layer_norm(xd, (C,), wd, bd, 1e-6)
+        if skip:
+            y, xs = m.forward_skip(x)
+            assert xs.data_ptr() == x.data_ptr()
+            ((y * gy).sum() + (xs * gs).sum()).backward()
+            ((ref * gy.double()).sum() + (xd * gs.double()).sum()).backward()
+        else:
+            y = m(x)
+            (y * gy).sum().backward()
+            (ref * gy.double()).sum().backward()
+        assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6, "ln fwd")
+        assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 5e-6, f"ln dx skip={skip}")
+        assert_close_rel(m.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "ln dgamma")
+        if bias:
+            assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "ln dbeta")
+    # only the skip output used: the gradient passes through untouched
+    x.grad = None
+    y, xs = m.forward_skip(x)
+    (xs * gs).sum().backward()
+    assert torch.equal(x.grad, gs)
+    # bitwise run-to-run determinism of the parameter gradients (fixed-order partial sums, no atomics)
+    def grads():
+        m.weight.grad = None
+        (m(x.detach()) * gy).sum().backward()
+        return m.weight.grad.clone()
+    assert torch.equal(grads(), grads())
