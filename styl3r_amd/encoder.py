@@ -454,22 +454,34 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
 
         with torch.autocast("cuda", enabled=False):
-            pts, params, appearance = [], [], []
-            for i in range(v):
-                head = self.downstream_head1 if i == 0 else self.downstream_head2
-                pts.append(landscape_mean_head(head, [t[:, i].float() for t in dec_feat], h, w))
-            for i in range(v):
-                head = self.gaussian_param_head if i == 0 else self.gaussian_param_head2
-                out = head([t[:, i].float() for t in dec_feat], (h, w), images[:, i, :3])
-                params.append(out.flatten(2).transpose(1, 2))
-            for i in range(v):
-                out = self.gaussian_appearance_head([t[:, i].float() for t in sty_feat], (h, w))
-                appearance.append(out.flatten(2).transpose(1, 2))
+            # The reference calls a head once per view (encoder_noposplat_multi_token_style.py:152-177: head1 for view 0,
+            # head2 for every other view, the appearance head for each view).  The heads act on every sample independently,
+            # so the views that share a head go through it as ONE batch of b * (#views) samples: same results, a third of
+            # the launches at v = 4, and small-resolution layers that fill more of the chip.
+            def rest(t):                                   # (b, v, ...) -> (b * (v - 1), ...), views 1..v-1
+                return t[:, 1:].reshape(b * (v - 1), *t.shape[2:])
 
-        pts_all = torch.stack(pts, dim=1).reshape(b, v, h * w, 1, 3)              # (b v r srf xyz)
+            def per_view(first, others):                   # -> (b, v, ...)
+                if others is None:
+                    return first.unsqueeze(1)
+                return torch.cat((first.unsqueeze(1), others.reshape(b, v - 1, *others.shape[1:])), dim=1)
+
+            pts_r = par_r = None
+            pts_0 = landscape_mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat], h, w)
+            par_0 = self.gaussian_param_head([t[:, 0].float() for t in dec_feat], (h, w), images[:, 0, :3])
+            if v > 1:
+                pts_r = landscape_mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat], h, w)
+                par_r = self.gaussian_param_head2([rest(t).float() for t in dec_feat], (h, w), rest(images)[:, :3])
+                par_r = par_r.flatten(2).transpose(1, 2)
+            pts = per_view(pts_0, pts_r)
+            params = per_view(par_0.flatten(2).transpose(1, 2), par_r)
+            app = self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))
+            appearance = app.flatten(2).transpose(1, 2).reshape(b, v, h * w, -1)
+
+        pts_all = pts.reshape(b, v, h * w, 1, 3)                                  # (b v r srf xyz)
         depths = pts_all[..., -1].unsqueeze(-1)
         d_sh3 = 3 * self.gaussian_adapter.d_sh
-        raw = torch.cat((torch.stack(params, dim=1)[..., :self.raw_gs_dim - d_sh3], torch.stack(appearance, dim=1)), dim=-1)
+        raw = torch.cat((params[..., :self.raw_gs_dim - d_sh3], appearance), dim=-1)
         raw = raw.reshape(b, v, h * w, 1, -1)                                     # (b v r srf c)
         densities = raw[..., 0].sigmoid().unsqueeze(-1)
         g = self.gaussian_adapter(pts_all.unsqueeze(-2), depths, self.map_pdf_to_opacity(densities, global_step),
