@@ -145,14 +145,16 @@ class LossStyle(nn.Module):
         target = _imagenet_normalize(flat(batch["target"]["image"]))
         pred = _imagenet_normalize(flat(prediction.color))
         style = _imagenet_normalize(batch["style"]["image"])
-        style = style[:, None].expand(b, v, *style.shape[1:]).reshape(b * v, *style.shape[1:])
+        # loss_style.py:53-60 repeats the style image v times and runs the VGG on the b*v copies; the feature statistics of
+        # identical images are identical, so the VGG sees each style image ONCE and its (mean, std) are repeated instead
         fp, ft, fs = self.vgg(pred), self.vgg(target), self.vgg(style)
         content = F.mse_loss(fp[-2], ft[-2]) + F.mse_loss(fp[-1], ft[-1])
         style_loss = 0
+        rep = lambda t: t[:, None].expand(b, v, *t.shape[1:]).reshape(b * v, *t.shape[1:])
         for a, s in zip(fp, fs):
             am, astd = calc_mean_std(a)
             sm, sstd = calc_mean_std(s)
-            style_loss = style_loss + F.mse_loss(am, sm) + F.mse_loss(astd, sstd)
+            style_loss = style_loss + F.mse_loss(am, rep(sm)) + F.mse_loss(astd, rep(sstd))
         return content + self.cfg.style_weight * style_loss
 
 

@@ -13,7 +13,7 @@ run python bench.py --grid 512 --ctx 4 --res 512 --scenes 2 --no-cpu-baseline   
 run python tools/bench_train.py --config c3 --scenes 10 --steps 3 --warmup 2     # M2, C3
 run python tools/bench_train.py --config c3 --scenes 8 --steps 3 --warmup 2
 run python tools/bench_train.py --config c4 --scenes 2 --steps 2 --warmup 1      # style stage
-run python tools/bench_train.py --config c4 --scenes 6 --steps 2 --warmup 1      # style stage at the reference's batch
+run python tools/bench_train.py --config c4 --scenes 6 --steps 3 --warmup 2      # style stage at the reference's batch
 run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1      # 512^2 / sh 4 stress step
 run python tools/bench_infer.py                                                  # C2 inference
 run python tools/bench_vit.py                                                    # kernel microbenchmarks
