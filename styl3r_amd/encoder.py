@@ -221,11 +221,15 @@ class TokenStylizer(CrocoTrunk):
     def __init__(self, cfg: TokenStylizerCfg, params: Optional[dict] = None):
         super().__init__(**(params or CROCO_PARAMS[cfg.model]))
 
-    def forward(self, style: dict, content_feat: Tensor, content_pos: Tensor):
+    def encode_style(self, style: dict):
+        """style image -> (style tokens in decoder width, positions); independent of the content views"""
         x, spos = self.patch_embed(style["image"])
         for blk in self.enc_blocks:
             x = blk(x, spos)
-        style_feat = self.decoder_embed(self.enc_norm(x))
+        return self.decoder_embed(self.enc_norm(x)), spos
+
+    def forward(self, style: dict, content_feat: Tensor, content_pos: Tensor, encoded=None):
+        style_feat, spos = encoded if encoded is not None else self.encode_style(style)
         b, v, l, c = content_feat.shape
         outs = [content_feat]
         cf = self.decoder_embed(content_feat.reshape(b, v * l, c))
@@ -441,6 +445,28 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         self.token_stylizer = TokenStylizer(cfg.token_stylizer, trunk_params)
         self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
 
+    head_streams = False     # inference option: run the five independent head calls on their own HIP streams
+
+    def _run_heads(self, jobs, like: Tensor):
+        """The head calls only depend on the trunk outputs.  At serving batch sizes (one scene) none of their kernels fills
+        256 CUs, so with `head_streams` (no-grad, device tensors) each call is issued on its own stream between two
+        fork / join waits on the caller's stream; otherwise they run in order on the current stream."""
+        if not (self.head_streams and like.is_cuda and not torch.is_grad_enabled()):
+            return [fn() for fn in jobs]
+        cur = torch.cuda.current_stream(like.device)
+        pool = self.__dict__.setdefault("_head_stream_pool", [])
+        while len(pool) < len(jobs):
+            pool.append(torch.cuda.Stream(like.device))
+        outs = []
+        for fn, st in zip(jobs, pool):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(fn())
+        for o, st in zip(outs, pool):
+            cur.wait_stream(st)
+            o.record_stream(cur)         # allocated on the side stream, consumed on the caller's
+        return outs
+
     def map_pdf_to_opacity(self, pdf: Tensor, global_step: int) -> Tensor:
         cfg = self.cfg.opacity_mapping
         x = cfg.initial + min(global_step / cfg.warm_up, 1) * (cfg.final - cfg.initial)
@@ -466,16 +492,17 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
                     return first.unsqueeze(1)
                 return torch.cat((first.unsqueeze(1), others.reshape(b, v - 1, *others.shape[1:])), dim=1)
 
-            pts_r = par_r = None
-            pts_0 = landscape_mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat], h, w)
-            par_0 = self.gaussian_param_head([t[:, 0].float() for t in dec_feat], (h, w), images[:, 0, :3])
+            jobs = [lambda: landscape_mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat], h, w),
+                    lambda: self.gaussian_param_head([t[:, 0].float() for t in dec_feat], (h, w), images[:, 0, :3]),
+                    lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
             if v > 1:
-                pts_r = landscape_mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat], h, w)
-                par_r = self.gaussian_param_head2([rest(t).float() for t in dec_feat], (h, w), rest(images)[:, :3])
-                par_r = par_r.flatten(2).transpose(1, 2)
+                jobs += [lambda: landscape_mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat], h, w),
+                         lambda: self.gaussian_param_head2([rest(t).float() for t in dec_feat], (h, w), rest(images)[:, :3])]
+            res = self._run_heads(jobs, images)
+            pts_0, par_0, app = res[:3]
+            pts_r, par_r = (res[3], res[4].flatten(2).transpose(1, 2)) if v > 1 else (None, None)
             pts = per_view(pts_0, pts_r)
             params = per_view(par_0.flatten(2).transpose(1, 2), par_r)
-            app = self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))
             appearance = app.flatten(2).transpose(1, 2).reshape(b, v, h * w, -1)
 
         pts_all = pts.reshape(b, v, h * w, 1, 3)                                  # (b v r srf xyz)

@@ -154,3 +154,26 @@ def test_bf16x6_and_f32_paths_agree_through_the_whole_encoder():
     assert vit_ops.CALLS["conv_x6_fwd"] > before["conv_x6_fwd"] and vit_ops.CALLS["conv_x6_dx"] > before["conv_x6_dx"]   # really taken
     for name, a, b in zip(("means", "covariances", "harmonics", "opacities", "d image"), res["bf16x6"], res["f32"]):
         assert_close_rel(a, b, 2e-3 if name == "d image" else 1e-4, name)
+
+
+@pytest.mark.gpu
+def test_head_streams_option_gives_the_same_gaussians():
+    """serving option `head_streams`: the five head calls on their own HIP streams (fork / join on the caller's stream)
+    return the same Gaussians as the in-order launch, repeatedly (no allocator hazards across streams)"""
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(_build(0)).to(dev)
+    T = lambda k: torch.tensor(G[f"sh0_{k}"], device=dev)
+    ctx, style = dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style"))
+    with torch.no_grad():
+        ref = m(ctx, style, 0)
+        m.head_streams = True
+        for _ in range(3):
+            got = m(ctx, style, 0)
+            torch.cuda.synchronize()
+            # (max-norm: the small convolutions go through split-K atomics / the library, whose summation order is not fixed)
+            for name, a, b in (("means", got.means, ref.means), ("cov", got.covariances, ref.covariances),
+                               ("sh", got.harmonics, ref.harmonics), ("opacity", got.opacities, ref.opacities)):
+                assert_close_rel(a.cpu().numpy(), b.cpu().numpy(), 1e-4, name)
+        assert len(m._head_stream_pool) == 5
+    m.head_streams = False

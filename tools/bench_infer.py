@@ -14,6 +14,7 @@ from styl3r_amd.scenes import make_scene
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--tiny", action="store_true")
+ap.add_argument("--streams", action="store_true", help="run the five head calls on their own streams (encoder.head_streams)")
 ap.add_argument("--graph", action="store_true", help="replay the encoder forward as one hipGraph (styl3r_amd.graphs.GraphedEncoder)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -21,6 +22,7 @@ torch.manual_seed(0)
 tiny = dict(enc_depth=2, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=128, enc_num_heads=16, dec_num_heads=2,
             pos_embed="RoPE100", img_size=(512, 512)) if args.tiny else None
 enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(), trunk_params=tiny).to(dev).eval()
+enc.head_streams = args.streams
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
 H, v_ctx, v_tgt = 256, 2, 3
 sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234)
@@ -55,4 +57,4 @@ print(json.dumps({"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, 
                   "rasterizer_ms": round(t_ras / n, 3), "total_ms": round((t_enc + t_ras) / n, 3),
                   "views_per_s": round(v_tgt * 1e3 * n / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1]),
                   "encoder_fwd_TFLOPs_per_s": round(1.3146 / (t_enc / n) * 1e3 / 1e0, 1) if not args.tiny else None,
-                  "encoder_launch": "hipGraph replay" if args.graph else "eager", "dtype": "f32", "data": "synthetic, random-init weights"}))
+                  "encoder_launch": "hipGraph replay" if args.graph else ("eager, heads on 5 streams" if args.streams else "eager"), "dtype": "f32", "data": "synthetic, random-init weights"}))
