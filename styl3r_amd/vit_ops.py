@@ -109,7 +109,10 @@ def _check(rc: int, what: str):
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    # (the raw-stream query is ~10x cheaper than torch.cuda.current_stream(dev).cuda_stream: at batch-1 inference the
+    # host issues ~900 of these launches per forward and is the limit, tools/probes/infer_host_time.py)
+    idx = dev.index
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch.cuda.current_device()))
 
 
 def _need_gpu(t: Tensor, what: str):
@@ -558,6 +561,24 @@ class _FusedLinear(torch.autograd.Function):
 def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
                  gelu: bool = False) -> Tensor:
     """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd)."""
+    if not torch.is_grad_enabled() and LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32:
+        # serving path: no autograd node, no saved tensors, straight to the kernel
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(-1, N)
+            if not res2.is_contiguous() or res2.dtype != torch.float32:
+                res2 = res2.contiguous().float()
+        _check(load().vit_linear_x6_fwd(x2.data_ptr(), split_weight(weight).data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
+                                        1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
+        return out.reshape(*shp[:-1], N)
     return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0)
 
 
@@ -616,6 +637,17 @@ class LayerNorm(nn.LayerNorm):
 
     def forward(self, x: Tensor) -> Tensor:
         if self._hip_ok(x):
+            if not torch.is_grad_enabled():          # serving path: no autograd node
+                xc = x if x.is_contiguous() else x.contiguous()
+                Cn = xc.shape[-1]
+                M = xc.numel() // Cn
+                y = torch.empty_like(xc)
+                stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+                _check(load().vit_layernorm_fwd(xc.data_ptr(), self.weight.data_ptr(),
+                                                self.bias.data_ptr() if self.bias is not None else None, y.data_ptr(),
+                                                stats.data_ptr(), stats.data_ptr() + 4 * M, M, Cn, float(self.eps),
+                                                _stream(x.device)), "vit_layernorm_fwd")
+                return y
             return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, False)
         return super().forward(x)
 

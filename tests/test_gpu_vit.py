@@ -389,3 +389,20 @@ def test_layernorm_kernels_match_fp64_with_and_without_skip(shape, bias):
         (m(x.detach()) * gy).sum().backward()
         return m.weight.grad.clone()
     assert torch.equal(grads(), grads())
+
+
+def test_no_grad_fast_paths_equal_the_autograd_paths():
+    """serving: under no_grad fused_linear and LayerNorm skip the autograd node and go straight to the kernels; the
+    results are the same bits as the autograd path's forward (same kernels, same arguments)"""
+    from styl3r_amd.vit_ops import LayerNorm, fused_linear
+    torch.manual_seed(11)
+    x = torch.randn(3, 257, 1024, device=DEV)
+    w = torch.randn(768, 1024, device=DEV) / 32; b = torch.randn(768, device=DEV); r = torch.randn(3, 257, 768, device=DEV)
+    ln = LayerNorm(1024, eps=1e-6).to(DEV)
+    xg = x.clone().requires_grad_(True)
+    want_lin, want_ln = fused_linear(xg, w, b, r, gelu=True), ln(xg)
+    with torch.no_grad():
+        got_lin, got_ln = fused_linear(x, w, b, r, gelu=True), ln(x)
+        got_t = fused_linear(x.transpose(0, 1), w, b)              # non-contiguous input
+    assert torch.equal(got_lin, want_lin.detach()) and torch.equal(got_ln, want_ln.detach())
+    assert torch.equal(got_t, fused_linear(xg.transpose(0, 1), w, b).detach())
