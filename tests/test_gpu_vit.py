@@ -405,4 +405,5 @@ def test_no_grad_fast_paths_equal_the_autograd_paths():
         got_lin, got_ln = fused_linear(x, w, b, r, gelu=True), ln(x)
         got_t = fused_linear(x.transpose(0, 1), w, b)              # non-contiguous input
     assert torch.equal(got_lin, want_lin.detach()) and torch.equal(got_ln, want_ln.detach())
-    assert torch.equal(got_t, fused_linear(xg.transpose(0, 1), w, b).detach())
+    # (this small GEMM splits K across workgroups with fp32 atomics: equal up to the summation order)
+    assert torch.allclose(got_t, fused_linear(xg.transpose(0, 1), w, b).detach(), rtol=1e-5, atol=1e-5)
