@@ -79,6 +79,10 @@ typedef struct GsrDims {
                                     then returns with ~1 ms of GPU work still queued, which hides the launch latency
                                     of everything it enqueues next (loss, backward).  Neither flag: all stages.     */
 
+#define GSR_FLAG_PREZERO_GRADS 16 /* gsr_forward: the composite kernel also zeroes the workspace's per-(view, Gaussian) gradient
+                                    accumulators (126 MB at the headline size; that kernel is VALU-bound, HBM is idle under it).
+                                    gsr_backward with the same flag then skips its own memset.  Valid for the FIRST backward
+                                    after the forward only: the backward leaves the accumulators dirty. */
 #define GSR_FLAG_SORT_KEYS_SHIFT 8   /* bits 8-9: LDS budget of the per-tile depth sort: 0 = 4096 keys (default), 1 = 1024,
                                        2 = 2048.  Pick the smallest budget >= the longest per-tile list expected
                                        (status[GSR_ST_MAX_TILE] of an earlier call): more workgroups fit a CU.  Longer lists

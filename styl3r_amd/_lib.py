@@ -68,6 +68,7 @@ GSR_FLAG_NTOUCHED = 1
 GSR_FLAG_COV9 = 2
 GSR_FLAG_PHASE_BIN = 4
 GSR_FLAG_PHASE_RENDER = 8
+GSR_FLAG_PREZERO_GRADS = 16
 GSR_FLAG_SORT_KEYS_SHIFT = 8
 GSR_STATUS_WORDS = 8
 GSR_VIEW_FLOATS = 64

@@ -13,7 +13,7 @@
 namespace gsr {
 
 // grad_rec layout, 12 floats per (view, Gaussian)
-enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_CC = 8, GR_OP = 9, GR_STRIDE = 12 };
+enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_CC = 8, GR_OP = 9 };   // GR_STRIDE: gsr_common.h
 
 // ------------------------------------------------------------------ K6
 // One wavefront per tile, 4 pixels per lane (same pixel <-> lane map as the forward).
@@ -416,7 +416,9 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
     const int V = d.B * d.Vt, T = tiles_x(d.W) * tiles_y(d.H);
     (void)hipGetLastError();
     StageTimer tm(d.profile, false, stream);
-    if (!hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
+    // (GSR_FLAG_PREZERO_GRADS: the forward's composite kernel already zeroed the accumulators)
+    if (!(d.flags & GSR_FLAG_PREZERO_GRADS) &&
+        !hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
     if (dL_dtau && !hip_ok(hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream))) return GSR_ELAUNCH;
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
     if (dL_ddepth) hipLaunchKernelGGL(k_composite_bwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);

@@ -32,6 +32,8 @@ struct alignas(16) QueueRec {
 };
 static_assert(sizeof(QueueRec) == 48, "QueueRec must be 48 bytes");
 
+constexpr int GR_STRIDE = 12;   // floats per (view, Gaussian) gradient accumulator record (layout: gsr_backward.hip)
+
 struct Ptrs {             // carved workspace
     SplatRec *records;
     uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;

@@ -495,6 +495,16 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     const int lane = threadIdx.x;
     const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
 
+    if (d.flags & GSR_FLAG_PREZERO_GRADS) {
+        // side job: this wavefront's slice of the backward's gradient accumulators (stores only; the kernel's own work is
+        // VALU-bound, so the 48 B per (view, Gaussian) ride on otherwise idle HBM bandwidth instead of a separate memset)
+        const size_t n4 = (size_t)d.B * d.Vt * d.G * (GR_STRIDE / 4);
+        const size_t nwg = (size_t)gridDim.x * gridDim.y, wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t per = (n4 + nwg - 1) / nwg, lo = wg * per, hi = lo + per < n4 ? lo + per : n4;
+        float4 *gz = reinterpret_cast<float4 *>(ws.grad_rec);
+        for (size_t i = lo + lane; i < hi; i += 64) gz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
     const int n = (int)(ws.tile_offset[t + 1] - start);

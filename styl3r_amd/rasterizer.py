@@ -83,8 +83,10 @@ class _Rasterize(torch.autograd.Function):
         # LDS budget of the per-tile sort from the longest list seen for this shape (+25 %): 1024 / 2048 / 4096 keys
         mt = _MAX_TILE_HINT.get(key, 4096)
         sort_sel = 1 if mt <= 1024 else (2 if mt <= 2048 else 0)
+        # a backward will follow: the composite kernel zeroes the gradient accumulators on the side (GSR_FLAG_PREZERO_GRADS)
+        prezero = any(ctx.needs_input_grad)
         flags = (_lib.GSR_FLAG_NTOUCHED if want_ntouched else 0) | (_lib.GSR_FLAG_COV9 if cov9 else 0) | \
-                (sort_sel << _lib.GSR_FLAG_SORT_KEYS_SHIFT)
+                (sort_sel << _lib.GSR_FLAG_SORT_KEYS_SHIFT) | (_lib.GSR_FLAG_PREZERO_GRADS if prezero else 0)
         dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags,
                             PROFILE.handle if PROFILE is not None else None)
         dev = means.device
@@ -163,6 +165,7 @@ class _Rasterize(torch.autograd.Function):
                               ctx.ws_bytes, _ptr(g_image), _ptr(g_depth), _ptr(d_means), _ptr(d_cov6), _ptr(d_opac),
                               _ptr(d_colors), _ptr(d_m2d), _ptr(d_tau), stream)
         _lib.check(rc, "gsr_backward")
+        dims.flags &= ~_lib.GSR_FLAG_PREZERO_GRADS     # the accumulators are dirty now: a second backward (retain_graph) zeroes them itself
         has_theta, has_rho, has_m2d = ctx.has
         g_theta = d_tau[:, 3:6] if (ctx.want_tau and has_theta) else None
         g_rho = d_tau[:, 0:3] if (ctx.want_tau and has_rho) else None

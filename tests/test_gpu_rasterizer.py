@@ -398,3 +398,42 @@ def test_randomized_sweep_forward_backward_parity(seed):
     _check_forward(means, cov6, opac, cam, bg=bg, min_ok=0.8, **kw)
     _check_backward(means, cov6, opac, cam, bg=bg, pose=bool(rng.integers(0, 2)), seed=seed, f64_rel=1e-2, **kw)   # fp64 check is a sanity bound here:
     # in these extreme scenes single alpha >= 1/255 decisions differ between fp32 and fp64 arithmetic; the parity bar is the 1e-4 match with the fp32 oracle
+
+
+def test_prezeroed_gradient_accumulators_equal_the_memset_path_and_survive_a_second_backward(monkeypatch):
+    """GSR_FLAG_PREZERO_GRADS (include/gsr.h): the composite-forward kernel zeroes the backward's per-(view, Gaussian)
+    accumulators as a side job and gsr_backward skips its memset.  Same gradients as the memset path; a second backward
+    through the same graph (retain_graph) finds dirty accumulators, zeroes them itself and returns the same gradients."""
+    from styl3r_amd import _lib
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder
+    from styl3r_amd.scenes import make_scene
+    dev = torch.device("cuda:0")
+    scs = [make_scene(n_ctx=1, grid_hw=(64, 64), n_views=2, image_hw=(80, 96), sh_degree=1, seed=300 + i) for i in range(2)]
+    st = lambda n: torch.stack([getattr(s, n) for s in scs]).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.1, 0.2, 0.3], True)).to(dev)
+    w = torch.rand(2, 2, 3, 80, 96, device=dev, generator=torch.Generator(dev).manual_seed(2))
+
+    def grads(twice):
+        g = Gaussians(*(st(n).requires_grad_(True) for n in ("means", "covariances", "harmonics", "opacities")))
+        out = dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (80, 96))
+        loss = (out.color * w).sum()
+        leaves = (g.means, g.covariances, g.harmonics, g.opacities)
+        first = torch.autograd.grad(loss, leaves, retain_graph=twice)
+        return first, (torch.autograd.grad(loss, leaves) if twice else None)
+
+    seen = []
+    real = _lib.load().gsr_backward
+    import ctypes as C
+    class Spy:                                       # records the flag word every gsr_backward call receives
+        def __call__(self, dims, *a):
+            seen.append(C.cast(dims, C.POINTER(_lib.GsrDims)).contents.flags & _lib.GSR_FLAG_PREZERO_GRADS)
+            return real(dims, *a)
+    monkeypatch.setattr(_lib.load(), "gsr_backward", Spy(), raising=False)
+    a, a2 = grads(True)
+    assert seen == [_lib.GSR_FLAG_PREZERO_GRADS, 0], seen      # first backward trusts the forward, the second one zeroes
+    monkeypatch.setattr(_lib, "GSR_FLAG_PREZERO_GRADS", 0)     # memset path
+    b, _ = grads(False)
+    assert seen[-1] == 0
+    for x, y, z, name in zip(a, a2, b, ("means", "cov", "sh", "opac")):
+        assert_close_rel(x.cpu().numpy(), z.cpu().numpy(), 2e-5, f"prezero vs memset d{name}")
+        assert_close_rel(y.cpu().numpy(), z.cpu().numpy(), 2e-5, f"second backward d{name}")
