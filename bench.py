@@ -5,20 +5,30 @@ Metric (BASELINE.json): 256x256 stylized views/sec, forward + backward, at a
 fixed ~65k Gaussians per scene.  One "step" = one pass of the decoder hot path
 (DecoderSplattingHIP.forward -> MSE -> backward) over one batch of synthetic
 scenes: B scenes x Vt target views of 256x256, G = 65 536 Gaussians per scene,
-inputs resident in HBM before the timed region.  Multi-GPU: one process per GPU,
-scenes sharded on the batch axis (weak scaling, no data-path collective -- the
-raster path has no exchange step).
+inputs resident in HBM before the timed region.
+
+Multi-GPU (`--gpus N`): one process per GPU.  Under `torch.distributed.run` the ranks come from
+RANK / LOCAL_RANK / WORLD_SIZE; a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the
+environment) re-executes itself under `torch.distributed.run` with N ranks on 127.0.0.1, the launch the
+reference gets from Lightning's DDP strategy (src/main_style.py:98-118: devices="auto", per-rank seed).
+The raster leg shards scenes on the batch axis with no data-path collective (weak scaling, SURVEY 8e);
+the `train_step` leg is the C3 optimisation step (full-size encoder fwd+bwd + rasterizer fwd+bwd + MSE +
+bucketed gradient all-reduce over RCCL overlapped with the backward + clip + AdamW) -- the one collective the
+path has, so the 1 -> N curve contains it.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  "roofline":     live hipEvent timing of the dominant kernel vs the HBM peak
-  "cpu_baseline": the CPU oracle (a port of the published algorithm; the
-                  reference has no CPU rasterizer) on a bounded sample.
+  "roofline":     live hipEvent timing of the dominant kernel vs the HBM peak, what actually bounds it
+  "cpu_baseline": the CPU oracle (a port of the published algorithm; the reference has no CPU rasterizer)
+                  on a bounded sample
+  "train_step":   M2: C3 ms/step, rendered views/s, bytes all-reduced, RCCL ranks
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,17 +37,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=10, help="scenes per GPU per step (C3 batch)")
     ap.add_argument("--views", type=int, default=4, help="target views per scene")
     ap.add_argument("--ctx", type=int, default=1, help="context views per scene (grid x grid Gaussians each)")
@@ -46,10 +53,34 @@ def parse():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-views", type=int, default=2, help="views in the CPU-baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
+    ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
+    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-tiny", action="store_true", help="small trunk for the train leg (smoke tests only; flagged in the line)")
+    ap.add_argument("--dry-cpu", action="store_true",
+                    help="launch-path test mode: gloo on CPU, no kernels, no oracle -- checks spawning / sharding / the JSON line")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------ launch
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(args) -> int:
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start N ranks of this script, one per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STYL3R_BENCH_SPAWNED="1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------ raster leg
 def build_batch(args, rank, dev):
+    import torch
     from styl3r_amd.decoder import Gaussians
     from styl3r_amd.scenes import make_scene
     from styl3r_amd.dist_utils import scene_seeds
@@ -62,12 +93,14 @@ def build_batch(args, rank, dev):
 
 
 def algorithmic_bytes(stage, V, B, G, P, n_sh, R, R_eff):
-    """SURVEY.md section 8d per-view figures x the views one launch processes."""
+    """SURVEY.md section 8d per-view figures x the views one launch processes.
+    tile_sort: what this design's K4 moves per (tile, Gaussian) pair -- 8 B key read + 4 B sorted id written (the 12R of
+    the sort proper) + the 48-B record gathered and the 48-B queue entry written (96R)."""
     return {
         "preprocess": B * G * (40 + 12 * n_sh) + V * G * (48 + 4),
         "scan_tiles": 0,
         "scatter": V * G * 16 + 8 * R,
-        "tile_sort": 12 * R,
+        "tile_sort": 12 * R + 96 * R,
         "composite_fwd": 44 * R_eff + 28 * V * P,
         "composite_bwd": 44 * R_eff + 24 * V * P + 44 * V * G,
         "preprocess_bwd": B * G * (40 + 12 * n_sh) + V * G * (48 + 16) + B * G * (40 + 12 * n_sh),
@@ -76,6 +109,8 @@ def algorithmic_bytes(stage, V, B, G, P, n_sh, R, R_eff):
 
 def cpu_baseline(args, scenes):
     """Oracle (kind 'port') on `cpu_views` views of scene 0, fwd + bwd, all host cores in the OpenMP loops."""
+    import numpy as np
+    import torch
     from oracle.gsr_oracle import Oracle
     from styl3r_amd.decoder import prepare_views
     sc = scenes[0]
@@ -99,19 +134,38 @@ def cpu_baseline(args, scenes):
     dt = time.perf_counter() - t0
     return {"value": round(nv / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
             "sample": f"{nv} of the {args.views} views of scene 0 (G={sc.means.shape[0]}, {H}x{W}), fwd+bwd, "
-                      f"oracle/gsr_oracle.c f32, OpenMP over tiles"}
+                      f"oracle/gsr_oracle.c f32, OpenMP over Gaussians (preprocess, key emission, preprocess-backward) "
+                      f"and tiles (per-tile sort, composite forward / backward)"}
 
 
-def main():
-    args = parse()
-    from styl3r_amd import dist_utils
-    rank, local_rank, world = dist_utils.env_world()
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = dist_utils.init_distributed("nccl", dev)   # "nccl" is RCCL on ROCm
+def pmc_record(kernel, headline_workload):
+    """Counter-derived figures of `kernel` from profiles/pmc_latest.json (rocprofv3 --pmc passes of this very command,
+    tools/pmc_run.sh -> tools/pmc_summary.py -> tools/pmc_latest.py).  They are reported only when the file was measured
+    on the SAME BUILD (digest of the kernel sources + flags, stamped into the file and next to libgsr_hip.so) and the run is
+    the headline workload; otherwise null -- never a stale number."""
+    from styl3r_amd import _lib
+    pmc = ROOT / "profiles" / "pmc_latest.json"
+    out = {"traffic": None, "pmc_source": None, "valu": None}
+    if not (pmc.exists() and headline_workload):
+        return out
+    try:
+        doc = json.loads(pmc.read_text())
+    except Exception:
+        return out
+    if doc.get("build_digest") != _lib.built_digest() or not _lib.built_digest():
+        out["pmc_source"] = f"stale: pmc_latest.json was measured on build {doc.get('build_digest')}, this is {_lib.built_digest()}"
+        return out
+    rec = doc.get("kernels", {}).get(kernel, {})
+    out["traffic"] = rec.get("hbm_bytes_per_launch")
+    out["pmc_source"] = doc.get("source")
+    out["valu"] = {k: rec.get(k) for k in ("valu_insts_per_launch", "valu_insts_per_pair", "valu_active_frac", "salu_insts_per_pair",
+                                           "lds_insts_per_pair") if k in rec}
+    return out
 
-    from styl3r_amd import _lib, rasterizer as rz
+
+def raster_leg(args, rank, world, dev, dist):
+    import torch
+    from styl3r_amd import _lib, dist_utils, rasterizer as rz
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
     from styl3r_amd.losses import mse_loss
     _lib.load()  # fail loudly if the HIP library is missing
@@ -164,35 +218,140 @@ def main():
                         "GBps": round(by / (avg * 1e-3) / 1e9, 1) if avg > 0 else None}
     dominant = max(stages, key=lambda k: stages[k]["avg_ms"])
     dk = stages[dominant]
-    # HBM traffic / VALU occupancy of the same kernel from the committed rocprofv3 --pmc passes of this workload
-    # (profiles/pmc_latest.json, produced by tools/pmc_run.sh + tools/pmc_summary.py; FETCH_SIZE doubled as the
-    # MI355X guide prescribes for gfx950).  null when the file does not cover the kernel.
-    traffic, valu_busy = None, None
-    pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists() and (B, Vt, args.ctx, args.grid, args.res, args.sh_degree) == (10, 4, 1, 256, 256, 0):
-        try:
-            rec = json.loads(pmc.read_text()).get(dominant, {})
-            traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_frac")
-        except Exception:
-            pass
+    headline = (B, Vt, args.ctx, args.grid, args.res, args.sh_degree) == (10, 4, 1, 256, 256, 0)
+    pm = pmc_record(dominant, headline)
+    # `bound`: the class SURVEY 8d assigns the stage (the fraction below is against THAT roof, as north_star asks);
+    # `limited_by`: what the counters say limits it on this workload
     roofline = {"kernel": "k_" + dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "valu_busy_frac_pmc": valu_busy,
+                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": pm["traffic"],
+                "limited_by": "valu-issue" if dominant.startswith("composite") else "hbm",
+                "valu": pm["valu"], "pmc_source": pm["pmc_source"],
                 "alg_bytes_per_launch": dk["alg_bytes"], "avg_launch_ms": dk["avg_ms"],
+                "ns_per_pair_per_simd": round(dk["avg_ms"] * 1e6 * 1024 / max(R, 1), 2),
                 "pairs_R": R, "R_eff": R_eff, "stages": stages}
+    res = {
+        "metric": "256x256 stylized views/sec (fwd+bwd) @ ~65k Gaussians",
+        "value": round(dist_utils.aggregate_throughput(V, args.steps, world, dt), 2), "unit": "views/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
+                               f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x {args.grid}x{args.grid}), sh_degree="
+                               f"{args.sh_degree}, make_scale_invariant, all views in one batched launch",
+                   "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
+        "roofline": roofline,
+    }
+    del g, cams, target, dec
+    torch.cuda.empty_cache()
+    return res, scenes
 
+
+# ------------------------------------------------------------------ train leg (M2, C3)
+def train_leg(args, rank, world, dev, dist):
+    """C3 NVS-pretrain step (2 ctx / 4 tgt views, MSE, every parameter trains) on the full-size encoder,
+    random init (checkpoints absent), per-rank data (seed 1234 + rank, main_style.py:118), gradients all-reduced in
+    64 MiB buckets over RCCL while the backward runs (styl3r_amd/ddp.py)."""
+    import torch
+    from styl3r_amd import dist_utils
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.scenes import make_scene
+    from styl3r_amd.train import TrainStep
+    cpu = dev.type == "cpu"
+    torch.manual_seed(0)   # identical replicas on every rank
+    tiny = dict(enc_depth=1, dec_depth=2, enc_embed_dim=64, dec_embed_dim=32, enc_num_heads=2, dec_num_heads=2,
+                pos_embed="RoPE100", img_size=(512, 512)) if args.train_tiny else None
+    enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=False), trunk_params=tiny).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    step = TrainStep(enc, dec, dist=dist)
+    b, v_ctx, v_tgt, H = args.train_scenes, 2, 4, (32 if args.train_tiny else 256)
+    g = torch.Generator(dev).manual_seed(1234 + rank)
+    sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
+    K = sc.intrinsics[:1].to(dev)
+    ex = lambda t, *shape: t.to(dev)[None].expand(b, *shape).contiguous()
+    batch = dict(
+        context=dict(image=torch.rand(b, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=K.expand(b, v_ctx, 3, 3).contiguous()),
+        target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
+                    intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
+    sync = (lambda: None) if cpu else (lambda: torch.cuda.synchronize(dev))
+    for _ in range(args.train_warmup):
+        step(batch)
+    dt = dist_utils.timed_steps(lambda: step(batch), args.train_steps, sync, dist, dev)
+    grad_bytes = sum(step.reducer.bucket_sizes_bytes())
+    from styl3r_amd import vit_ops
+    out = {"metric": "256x256 rendered views/sec, full C3 train step (encoder + rasterizer fwd+bwd, MSE, DP all-reduce, clip, AdamW)",
+           "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.train_steps, world, dt), 3), "unit": "views/s",
+           "ms_per_step": round(1e3 * dt / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
+           "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
+           "params": sum(p.numel() for p in enc.parameters()), "grad_bytes_all_reduced_per_step": grad_bytes if world > 1 else 0,
+           "grad_bytes": grad_bytes, "buckets": len(step.reducer.buckets), "bucket_MiB": 64,
+           "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward" if world > 1 else "none (1 rank)"),
+           "linear_arithmetic": vit_ops.LINEAR_MODE, "dtype": "f32", "data": "synthetic, random-init weights",
+           "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
+    if not cpu:
+        out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+    return out
+
+
+# ------------------------------------------------------------------ dry run (CPU launch-path test)
+def dry_leg(args, rank, world, dist):
+    """--dry-cpu: no kernels, no oracle.  Exercises the launch path only: rank -> shard mapping, barrier-bracketed timing,
+    MAX over ranks, whole-job aggregation, one JSON line from rank 0."""
+    import torch
+    from styl3r_amd import dist_utils
+    seeds = dist_utils.scene_seeds(rank, args.scenes)
+    calls = []
+    dt = dist_utils.timed_steps(lambda: calls.append(1), args.steps, lambda: None, dist)
+    # all ranks' first seed, gathered: shows the shards are disjoint
+    mine = torch.tensor([seeds[0]], dtype=torch.int64)
+    allv = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(allv, mine)
+    else:
+        allv = [mine]
+    V = args.scenes * args.views
+    return {"metric": "256x256 stylized views/sec (fwd+bwd) @ ~65k Gaussians", "value": round(dist_utils.aggregate_throughput(V, args.steps, world, max(dt, 1e-9)), 2),
+            "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "DRY RUN on CPU: launch-path test, no kernels executed -- not a measurement", "dry_cpu": True,
+            "config": {"workload": "none (dry run)", "views_per_step_per_gpu": V, "parallelism": f"dp{world} (scenes sharded)",
+                       "first_scene_seed_per_rank": [int(t.item()) for t in allv], "timed_calls_rank0": len(calls)}}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
+    import torch
+    from styl3r_amd import dist_utils
+    rank, local_rank, world = dist_utils.env_world()
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size", file=sys.stderr)
+    if args.dry_cpu:
+        dev, backend = torch.device("cpu"), "gloo"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (use --dry-cpu for the CPU launch-path test)"
+        assert local_rank < torch.cuda.device_count(), f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPUs visible"
+        torch.cuda.set_device(local_rank)
+        dev, backend = torch.device("cuda", local_rank), "nccl"   # "nccl" is RCCL on ROCm
+    dist = dist_utils.init_distributed(backend, dev if backend == "nccl" else None)
+
+    if args.dry_cpu:
+        res, scenes = dry_leg(args, rank, world, dist), None
+    else:
+        res, scenes = raster_leg(args, rank, world, dev, dist)
+    res["launch"] = {"backend": ("rccl (torch 'nccl')" if backend == "nccl" else backend) if dist is not None else "none (single process)",
+                     "ranks": dist.get_world_size() if dist is not None else 1,
+                     "spawned_by": "bench.py self-spawn -> torch.distributed.run" if os.environ.get("STYL3R_BENCH_SPAWNED") else
+                                   ("torch.distributed.run" if "WORLD_SIZE" in os.environ else "direct"),
+                     "device": (torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu")}
+    if not args.no_train_leg and not args.dry_cpu:
+        try:
+            res["train_step"] = train_leg(args, rank, world, dev, dist)
+            res["train_step"]["n_gpus"] = world
+        except Exception as e:   # the headline line must survive a failure of the secondary leg; it is reported, not hidden
+            res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
-        res = {
-            "metric": "256x256 stylized views/sec (fwd+bwd) @ ~65k Gaussians",
-            "value": round(dist_utils.aggregate_throughput(V, args.steps, world, dt), 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
-                                   f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x {args.grid}x{args.grid}), sh_degree="
-                                   f"{args.sh_degree}, make_scale_invariant, all views in one batched launch",
-                       "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
-            "roofline": roofline,
-        }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.dry_cpu:
             res["cpu_baseline"] = cpu_baseline(args, scenes)
         print(json.dumps(res), flush=True)
     if dist is not None:

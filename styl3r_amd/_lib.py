@@ -37,20 +37,50 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """Compile csrc/*.hip for gfx950 into styl3r_amd/lib/libgsr_hip.so (cross-compiles without a GPU)."""
+def sources_digest(paths, cmd) -> str:
+    """sha256 over the command line and the bytes of every source / header: the build stamp (a stale shipped .so whose
+    sources changed -- even with a newer mtime -- is rebuilt) and the key that ties a PMC profile to the build it measured."""
+    import hashlib
+    h = hashlib.sha256(" ".join(map(str, cmd)).encode())
+    for q in sorted(map(str, paths)):
+        h.update(Path(q).name.encode())
+        h.update(Path(q).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def _build_cmd():
     srcs = [_CSRC / s for s in _SOURCES]
     deps = srcs + [(_CSRC / h).resolve() for h in _HEADERS]
+    # the command is recorded with repo-relative paths so that the digest is the same here and on the GPU box
+    cmd = ["hipcc", *HIPCC_FLAGS, *os.environ.get("GSR_HIPCC_EXTRA", "").split(), *_SOURCES, "-o", LIB_PATH.name]
+    return srcs, deps, cmd
+
+
+def build_digest() -> str:
+    """digest of the sources + flags the CURRENT tree would build libgsr_hip.so from"""
+    _, deps, cmd = _build_cmd()
+    return sources_digest(deps, cmd)
+
+
+def built_digest() -> str:
+    """digest recorded when the shipped libgsr_hip.so was built ('' if unknown)"""
+    stamp = LIB_PATH.with_suffix(".stamp")
+    return stamp.read_text().strip() if stamp.exists() and LIB_PATH.exists() else ""
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 into styl3r_amd/lib/libgsr_hip.so (cross-compiles without a GPU).  The library is
+    rebuilt whenever the digest of (sources, headers, command line) differs from the one stamped next to it."""
+    srcs, deps, cmd = _build_cmd()
     _LIBDIR.mkdir(exist_ok=True)
-    cmd = [_hipcc(), *HIPCC_FLAGS, *os.environ.get("GSR_HIPCC_EXTRA", "").split(), *map(str, srcs), "-o", str(LIB_PATH)]
-    stamp = LIB_PATH.with_suffix(".cmd")          # rebuild when the sources OR the command line change
-    same_cmd = stamp.exists() and stamp.read_text() == " ".join(cmd)
-    if not force and same_cmd and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+    want = sources_digest(deps, cmd)
+    if not force and built_digest() == want:
         return LIB_PATH
+    real = [_hipcc(), *cmd[1:-2], "-o", str(LIB_PATH)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=str(_CSRC))
-    stamp.write_text(" ".join(cmd))
+        print(" ".join(real))
+    subprocess.run(real, check=True, cwd=str(_CSRC))
+    LIB_PATH.with_suffix(".stamp").write_text(want)
     return LIB_PATH
 
 

@@ -77,14 +77,30 @@ def load_pretrained_encoder(encoder: nn.Module, ckpt: dict) -> Tuple[list, list]
         return tuple(encoder.load_state_dict(convert_mast3r_state_dict(ckpt["model"], encoder), strict=False))
     if "state_dict" in ckpt:
         sd = {k[len("encoder."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("encoder.")}
-        missing, unexpected = encoder.load_state_dict(sd, strict=False)
-        # NoPoSplat's single gs head carries opacity+scale+rot+SH; its trailing 3*d_sh channels seed the appearance head
+        # NoPoSplat's single gs head carries opacity + scale + rotation AND 3*d_sh SH channels in head.4; here the structure
+        # rows stay in gaussian_param_head{,2} ([:-3 d_sh], main_style.py:144-146) and the trailing 3*d_sh rows seed the
+        # appearance head (main_style.py:148-150).  The rows are split BEFORE load_state_dict: strict=False does not
+        # forgive a size mismatch.
         d3 = 3 * encoder.gaussian_adapter.d_sh
         gs = {k[len("gaussian_param_head."):]: v for k, v in sd.items() if k.startswith("gaussian_param_head.")}
-        if gs and gs["dpt.head.4.weight"].shape[0] > encoder.gaussian_param_head.dpt.head[4].weight.shape[0]:
-            app = dict(gs)
-            app["dpt.head.4.bias"], app["dpt.head.4.weight"] = gs["dpt.head.4.bias"][-d3:], gs["dpt.head.4.weight"][-d3:]
-            encoder.gaussian_appearance_head.load_state_dict({k: v for k, v in app.items() if "input_merger" not in k}, strict=False)
+        app = None
+        for head in ("gaussian_param_head", "gaussian_param_head2"):
+            mod = getattr(encoder, head, None)
+            wk = f"{head}.dpt.head.4.weight"
+            if mod is None or wk not in sd:
+                continue
+            rows = mod.dpt.head[4].weight.shape[0]
+            if sd[wk].shape[0] == rows + d3:
+                if head == "gaussian_param_head":
+                    app = dict(gs)
+                    app["dpt.head.4.bias"], app["dpt.head.4.weight"] = gs["dpt.head.4.bias"][-d3:], gs["dpt.head.4.weight"][-d3:]
+                for pn in ("weight", "bias"):
+                    sd[f"{head}.dpt.head.4.{pn}"] = sd[f"{head}.dpt.head.4.{pn}"][:rows]
+        missing, unexpected = encoder.load_state_dict(sd, strict=False)
+        if app is not None:
+            own = encoder.gaussian_appearance_head.state_dict()
+            encoder.gaussian_appearance_head.load_state_dict(
+                {k: v for k, v in app.items() if k in own and own[k].shape == v.shape}, strict=False)
         return list(missing), list(unexpected)
     raise ValueError("Invalid checkpoint format: expected a 'model' or a 'state_dict' entry")
 

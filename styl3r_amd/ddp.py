@@ -10,7 +10,14 @@ one accumulate kernel per parameter: ~1 800 tiny launches per step on the full e
 at the bucket slices (the optimizer then reads the reduced values in place, no unpack) and the bucket is
 all-reduced on RCCL's own stream while the backward keeps running.  xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU):
 large buckets (default 64 MiB) keep every link busy and amortise the launch latency of the collective.
-Parameters that never receive a gradient (mask_token) are reduced as zeros at `finish()`.
+Parameters that never receive a gradient on ANY rank (mask_token; head2 when v == 1) keep `grad = None` after
+`finish()`, as under the reference's `find_unused_parameters=True`: AdamW then skips them (no weight decay, no moment
+update).  The used / unused map is exchanged once (first step, one small MAX all-reduce) and cached -- the graph is static;
+it is re-exchanged if the local arrival set ever changes.
+
+Contract: exactly ONE backward between `prepare()` and `finish()`, and the same gradient-arrival order on every rank
+(identical replicas of a static graph).  A second backward after a bucket was launched would race with the collective and
+is refused with a RuntimeError.
 """
 from __future__ import annotations
 
@@ -38,6 +45,10 @@ class BucketedGradReducer:
             self.buckets.append(self._make_bucket(cur))
         self._handles: list = []
         self._armed = False
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._arrived: set = set()
+        self._arrived_key = None        # the local arrival set the cached map was computed for
+        self._unused: List[nn.Parameter] = []
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -57,6 +68,11 @@ class BucketedGradReducer:
             if not self._armed:                 # a backward outside prepare()/finish() is left alone
                 return
             b = self.buckets[bi]
+            if b["launched"]:
+                raise RuntimeError("BucketedGradReducer: a gradient arrived for a bucket that was already all-reduced -- "
+                                   "only ONE backward is allowed between prepare() and finish() (no gradient accumulation / "
+                                   "retain_graph re-runs through the reducer)")
+            self._arrived.add(self._index[id(p)])
             b["pending"] -= 1
             if b["pending"] == 0:
                 self._launch(b)
@@ -77,6 +93,7 @@ class BucketedGradReducer:
         """call before backward: zero the buckets (parameters without a gradient reduce as zeros) and drop old grads."""
         self._handles.clear()
         self._armed = True
+        self._arrived = set()
         torch._foreach_zero_([b["flat"] for b in self.buckets])
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
@@ -100,6 +117,19 @@ class BucketedGradReducer:
                 p._grad_slot = None            # a backward outside prepare()/finish() must not write into the buckets
         if self.world > 1:
             torch._foreach_mul_([b["flat"] for b in self.buckets], 1.0 / self.world)
+        # parameters no rank produced a gradient for: grad = None (the optimizer skips them), as DDP(find_unused_parameters)
+        key = frozenset(self._arrived)
+        if key != self._arrived_key:
+            used = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device if self.params else "cpu")
+            if self._arrived:
+                used[torch.tensor(sorted(self._arrived), device=used.device)] = 1
+            if self.dist is not None and self.world > 1:
+                self.dist.all_reduce(used, op=self.dist.ReduceOp.MAX)
+            flags = used.cpu().tolist()            # one host sync, on the first step only (static graph)
+            self._unused = [p for p, u in zip(self.params, flags) if not u]
+            self._arrived_key = key
+        for p in self._unused:
+            p.grad = None
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ (L2, eps 1e-6, coefficient clamped to 1) evaluated on the flat buckets:

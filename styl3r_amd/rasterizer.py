@@ -13,6 +13,7 @@ all rasterization runs in libgsr_hip.so.  There is no CPU or eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -24,7 +25,9 @@ from . import _lib
 _CAP_HINT: dict = {}
 # longest per-tile list seen per problem shape (x1.25): picks the LDS budget of the per-tile sort
 _MAX_TILE_HINT: dict = {}
-# per device: (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward
+# per (device, stream, host thread): (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward.
+# Keyed that way because two forwards on different streams or threads of one device would otherwise race on the buffer
+# (and read each other's pair count / overflow flag).
 _STATUS_HOST: dict = {}
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
 KEEP_DEBUG = False
@@ -111,10 +114,11 @@ class _Rasterize(torch.autograd.Function):
             dims.flags = flags
             _lib.check(rc, "gsr_forward")
 
-        host = _STATUS_HOST.get(dev.index)
+        hkey = (dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
+        host = _STATUS_HOST.get(hkey)
         if host is None:
-            host = _STATUS_HOST[dev.index] = (torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, pin_memory=True),
-                                              torch.cuda.Event())
+            host = _STATUS_HOST[hkey] = (torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, pin_memory=True),
+                                         torch.cuda.Event())
         st, ev = host
         while True:
             L = _lib.workspace_layout(dims, cap)

@@ -31,17 +31,24 @@ _lib = None
 
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
-    srcs = [_CSRC / s for s in _SOURCES if (_CSRC / s).exists()]
+    """hipcc --offload-arch=gfx950 of csrc/vit_*.hip into lib/libvit_hip.so; rebuilt whenever the digest of
+    (sources, header, command line) differs from the stamp written next to the library (same scheme as _lib.py)."""
+    from ._lib import sources_digest
+    names = [s for s in _SOURCES if (_CSRC / s).exists()]
+    srcs = [_CSRC / s for s in names]
     deps = srcs + [(_PKG.parent / "include" / "vit_ops.h")]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *names, "-o", LIB_PATH.name]
+    want = sources_digest(deps, cmd)
+    stamp = LIB_PATH.with_suffix(".stamp")
+    if not force and LIB_PATH.exists() and stamp.exists() and stamp.read_text().strip() == want:
         return LIB_PATH
     LIB_PATH.parent.mkdir(exist_ok=True)
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           *map(str, srcs), "-o", str(LIB_PATH)]
+    real = [hipcc, *cmd[1:-2], "-o", str(LIB_PATH)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=str(_CSRC))
+        print(" ".join(real))
+    subprocess.run(real, check=True, cwd=str(_CSRC))
+    stamp.write_text(want)
     return LIB_PATH
 
 
@@ -495,6 +502,7 @@ class _FusedLinear(torch.autograd.Function):
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
         ctx.save_for_backward(x2, w, pre)
         ctx.weight_ref = weight if x6 else None
+        ctx.weight_version = weight._version      # dX re-splits the LIVE parameter: it must still be the forward's value
         ctx.bias_ref = bias if x6 else None
         ctx.meta = (shp, bias is not None, residual is not None, act)
         return out.reshape(*shp[:-1], N)
@@ -503,6 +511,9 @@ class _FusedLinear(torch.autograd.Function):
     def backward(ctx, g):
         x2, w, pre = ctx.saved_tensors
         shp, has_bias, has_res, act = ctx.meta
+        if ctx.weight_ref is not None and ctx.weight_ref._version != ctx.weight_version:
+            raise RuntimeError("fused Linear: the weight was modified in place between forward and backward (optimizer step / "
+                               "EMA under retain_graph?); dX would be computed with the new value")
         g2 = g.reshape(-1, g.shape[-1])
         g_res = g if has_res else None
         if act == 1:

@@ -46,3 +46,28 @@ def test_wrapper_checkpoint_roundtrip_and_stylizer_init():
     ck.init_token_stylizer(c, wrapper)
     assert torch.equal(c.token_stylizer.enc_blocks[0].mlp.fc2.weight, a.backbone.enc_blocks[0].mlp.fc2.weight)
     assert torch.equal(c.token_stylizer.patch_embed.proj.weight, a.backbone.patch_embed.proj.weight)
+
+
+def test_noposplat_state_dict_splits_gs_head_into_structure_and_appearance():
+    """ADVICE r1 (medium): a NoPoSplat checkpoint's gaussian_param_head.dpt.head.4 has raw_gs_dim = structure + 3*d_sh rows;
+    the structure rows load into gaussian_param_head{,2}, the trailing 3*d_sh rows seed the appearance head
+    (src/main_style.py:139-150)."""
+    enc = _enc()
+    d3 = 3 * enc.gaussian_adapter.d_sh
+    sd = {"encoder." + k: torch.randn_like(v) for k, v in enc.state_dict().items()
+          if not k.startswith(("gaussian_appearance_head", "token_stylizer"))}
+    rows = enc.gaussian_param_head.dpt.head[4].weight.shape[0]
+    for h in ("gaussian_param_head", "gaussian_param_head2"):
+        w = enc.state_dict()[f"{h}.dpt.head.4.weight"]
+        sd[f"encoder.{h}.dpt.head.4.weight"] = torch.randn(rows + d3, *w.shape[1:])
+        sd[f"encoder.{h}.dpt.head.4.bias"] = torch.randn(rows + d3)
+    missing, unexpected = ck.load_pretrained_encoder(enc, {"state_dict": sd})
+    assert not unexpected
+    assert all(m.startswith(("gaussian_appearance_head", "token_stylizer")) for m in missing), missing[:5]
+    src_w = sd["encoder.gaussian_param_head.dpt.head.4.weight"]
+    assert torch.equal(enc.gaussian_param_head.dpt.head[4].weight, src_w[:rows])
+    assert torch.equal(enc.gaussian_param_head2.dpt.head[4].weight, sd["encoder.gaussian_param_head2.dpt.head.4.weight"][:rows])
+    assert torch.equal(enc.gaussian_appearance_head.dpt.head[4].weight, src_w[-d3:])
+    assert torch.equal(enc.gaussian_appearance_head.dpt.head[4].bias, sd["encoder.gaussian_param_head.dpt.head.4.bias"][-d3:])
+    # the rest of the appearance head is seeded from the gs head's trunk where the shapes agree
+    assert torch.equal(enc.gaussian_appearance_head.dpt.head[0].weight, sd["encoder.gaussian_param_head.dpt.head.0.weight"])

@@ -36,9 +36,10 @@ WORKER = textwrap.dedent("""
         red.prepare()
         model(x).pow(2).mean().backward()
         red.finish()
-        for p, w in zip(params, want):
+        for p, w in zip(params[:-1], want[:-1]):
             ok &= bool(torch.allclose(p.grad, w, atol=1e-7))
-        ok &= all(p.grad.data_ptr() != 0 for p in params)
+        ok &= all(p.grad.data_ptr() != 0 for p in params[:-1])
+        ok &= unused.grad is None              # unused on every rank -> None, as DDP(find_unused_parameters=True)
     print(json.dumps(dict(rank=rank, ok=ok, buckets=red.bucket_sizes_bytes())), flush=True)
     dist.barrier(); dist.destroy_process_group()
 """) % str(ROOT)
@@ -85,3 +86,32 @@ def test_flat_clip_matches_torch_clip():
     assert total > 0.5
     for p, w in zip(m.parameters(), want):
         assert torch.allclose(p.grad, w, rtol=1e-6, atol=1e-8)
+
+
+def test_second_backward_inside_prepare_finish_is_refused():
+    import pytest
+    import torch
+    from torch import nn
+    from styl3r_amd.ddp import BucketedGradReducer
+    m = nn.Linear(4, 3)
+    red = BucketedGradReducer(m.parameters(), None)
+    red.prepare()
+    m(torch.ones(2, 4)).sum().backward()
+    with pytest.raises(RuntimeError, match="ONE backward"):
+        m(torch.ones(2, 4)).sum().backward()
+    red.finish()
+
+
+def test_unused_parameter_keeps_grad_none_and_adamw_skips_it():
+    import torch
+    from torch import nn
+    from styl3r_amd.ddp import BucketedGradReducer
+    m = nn.Linear(4, 3)
+    dead = nn.Parameter(torch.ones(5))
+    opt = torch.optim.AdamW([*m.parameters(), dead], lr=0.1, weight_decay=0.5)
+    red = BucketedGradReducer([*m.parameters(), dead], None)
+    for _ in range(2):
+        red.prepare(); m(torch.ones(2, 4)).sum().backward(); red.finish()
+        assert dead.grad is None and m.weight.grad is not None
+        opt.step()
+    assert torch.equal(dead.detach(), torch.ones(5))       # no weight decay applied to a parameter without gradient

@@ -52,3 +52,33 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert a["n"] == b["n"] == 4                                       # exactly K timed steps each
     assert abs(a["dt"] - b["dt"]) < 1e-9 and a["dt"] >= 4 * 0.1 - 1e-3  # MAX over ranks = the slow rank
     assert abs(a["thr"] - 6 * 2 * 4 / a["dt"]) < 1e-9                 # whole-job aggregate
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment must start 2 ranks itself (the driver's command
+    form; round-1 VERDICT: the flag was parsed and ignored).  --dry-cpu = launch path only: gloo, no kernels, no oracle."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-cpu", "--steps", "4", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                                   # ONE line, from rank 0
+    d = __import__("json").loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launch"]["ranks"] == 2 and d["launch"]["backend"] == "gloo"
+    assert d["launch"]["spawned_by"].startswith("bench.py self-spawn")
+    assert d["config"]["first_scene_seed_per_rank"] == [1234, 2234]    # disjoint scene shards
+    assert d["config"]["timed_calls_rank0"] == 4 and d["steps"] == 4
+    assert d["dry_cpu"] is True and "DRY RUN" in d["data"]            # can never be mistaken for a measurement
+    assert d["scaling"] == "weak" and d["config"]["parallelism"].startswith("dp2")
+
+
+def test_bench_single_process_line_unchanged_keys():
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-cpu", "--steps", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = __import__("json").loads(p.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["launch"]["ranks"] == 1
