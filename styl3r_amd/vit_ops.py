@@ -347,7 +347,9 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # tools/probes/conv_small.py); smaller problems stay on the library path
 _CONV_X6_MIN_TILES = 100
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
-CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0}   # how often each bf16x6 convolution kernel was taken (tests)
+# how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
+CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
+         "layernorm_framework": 0}
 
 
 def _conv_tiles(out_channels: int, x: Tensor) -> int:
@@ -626,6 +628,7 @@ class _LayerNormHip(torch.autograd.Function):
             return gskip, None, None, None, None
         g = g.contiguous().float()
         gs = gskip.contiguous().float() if gskip is not None else None
+        CALLS["layernorm_hip_bwd"] += 1
         dx = torch.empty_like(xc)
         dwb = torch.empty((2, Cn), dtype=torch.float32, device=dev)
         scratch = torch.empty(load().vit_layernorm_scratch_bytes(M, Cn), dtype=torch.uint8, device=dev)
@@ -648,6 +651,7 @@ class LayerNorm(nn.LayerNorm):
 
     def forward(self, x: Tensor) -> Tensor:
         if self._hip_ok(x):
+            CALLS["layernorm_hip_fwd"] += 1
             if not torch.is_grad_enabled():          # serving path: no autograd node
                 xc = x if x.is_contiguous() else x.contiguous()
                 Cn = xc.shape[-1]
@@ -660,9 +664,11 @@ class LayerNorm(nn.LayerNorm):
                                                 _stream(x.device)), "vit_layernorm_fwd")
                 return y
             return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, False)
+        CALLS["layernorm_framework"] += 1
         return super().forward(x)
 
     def forward_skip(self, x: Tensor):
         if self._hip_ok(x) and torch.is_grad_enabled() and x.requires_grad:
+            CALLS["layernorm_hip_fwd"] += 1
             return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, True)
         return self.forward(x), x

@@ -57,3 +57,35 @@ def deterministic_init_(module, scale=1.0):
                 val = 0.02 * torch.randn(t.shape, generator=g)
             t.copy_(val.to(t.device))
     return module
+
+
+def closed_form_weights(shape, k):
+    """Loss weights for the large fixtures, as a closed form of the flat index (bounded, sign-changing, non-periodic over
+    the tensor): identical on the generator and the test side without storing them or relying on an RNG stream."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    i = torch.arange(n, dtype=torch.float64)
+    w = torch.cos(0.7390851 * i + 1.3 * (k + 1)) + 0.5 * torch.sin(0.0113 * i * (k + 2) + 0.4)
+    return w.reshape(shape).float()
+
+
+def deterministic_vgg_(module):
+    """VGG19 `features` weights keyed by the torchvision layer index (the trailing `<N>.weight` / `<N>.bias` of the state-dict
+    key), He-scaled so activations keep their magnitude through the nine convolutions: the reference's VGGEncoder
+    (`slice2.5.weight`, buffers after convert_to_buffer) and this repo's (`features.5.weight`) receive identical values."""
+    import zlib
+    sd = dict(module.named_parameters())
+    sd.update(dict(module.named_buffers()))
+    with torch.no_grad():
+        for name, t in sd.items():
+            if not t.is_floating_point():
+                continue
+            tail = ".".join(name.split(".")[-2:])
+            g = torch.Generator().manual_seed(zlib.crc32(("vgg19.features." + tail).encode()))
+            if t.dim() == 4:
+                val = torch.randn(t.shape, generator=g) * (2.0 / t[0].numel()) ** 0.5
+            else:
+                val = 0.05 * torch.randn(t.shape, generator=g)
+            t.copy_(val.to(t.device, t.dtype))
+    return module

@@ -71,3 +71,46 @@ def test_noposplat_state_dict_splits_gs_head_into_structure_and_appearance():
     assert torch.equal(enc.gaussian_appearance_head.dpt.head[4].bias, sd["encoder.gaussian_param_head.dpt.head.4.bias"][-d3:])
     # the rest of the appearance head is seeded from the gs head's trunk where the shapes agree
     assert torch.equal(enc.gaussian_appearance_head.dpt.head[0].weight, sd["encoder.gaussian_param_head.dpt.head.0.weight"])
+
+
+def test_checkpoint_filter_matches_the_reference_function():
+    """`convert_mast3r_state_dict` against outputs of the reference's own `checkpoint_filter_fn` (weight_modify.py:144-197) on a
+    synthetic MASt3R 'model' dict with 8 x 8 patches (-> `resample_patch_embed`), a 4-channel mean head (confidence dropped)
+    and no second decoder; plus the adapters' known answers.  Fixture: tests/golden/make_loss_fixtures.py."""
+    from pathlib import Path
+    import numpy as np
+    G = np.load(Path(__file__).resolve().parent / "golden" / "checkpoint_ref.npz")
+    tiny = dict(enc_depth=1, dec_depth=12, enc_embed_dim=128, dec_embed_dim=64, enc_num_heads=2, dec_num_heads=1,
+                pos_embed="RoPE100", img_size=(512, 512))
+    enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(), trunk_params=tiny)
+    # rebuild the generator's source dict from its seed (same call order => same values); the stored inputs double-check it
+    gg = torch.Generator().manual_seed(int(G["seed"]))
+    src = {}
+    for k, t in enc.backbone.state_dict().items():
+        if k.startswith(("dec_blocks2", "intrinsic_encoder")):
+            continue
+        src[k] = torch.randn(t.shape, generator=gg)
+    src["patch_embed.proj.weight"] = torch.randn(128, 3, 8, 8, generator=gg)
+    src["decoder_embed.weight"] = torch.randn(64, 128, generator=gg)
+    for h in ("downstream_head1", "downstream_head2"):
+        for k, t in getattr(enc, h).state_dict().items():
+            src[f"{h}.{k}"] = torch.randn((4, *t.shape[1:]) if k.startswith("dpt.head.4.") else t.shape, generator=gg)
+    for k in G.files:
+        if k.startswith("src:"):
+            assert np.array_equal(src[k[4:]].numpy(), G[k]), k
+    out = ck.convert_mast3r_state_dict(src, enc)
+    ref_keys = set(G["out_keys"].tolist())
+    assert ref_keys <= set(out.keys())
+    assert all(k.startswith("backbone.dec_blocks2") for k in set(out.keys()) - ref_keys)   # the only addition: the decoder duplication
+    for k in G.files:
+        if k.startswith("out:"):
+            got, want = out[k[4:]].numpy(), G[k]
+            assert got.shape == want.shape, k
+            assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-12), k
+    got = ck.resample_patch_embed(torch.tensor(G["rpe_in"]), (12, 20)).numpy()
+    assert np.abs(got - G["rpe_out_12x20"]).max() <= 2e-5 * np.abs(G["rpe_out_12x20"]).max()
+    assert np.allclose(ck._adapt_input_conv(1, torch.tensor(G["aic_in"])).numpy(), G["aic_out_1"], atol=1e-6)
+    assert np.allclose(ck._adapt_input_conv(7, torch.tensor(G["aic_in"])).numpy(), G["aic_out_7"], atol=1e-6)
+    assert np.allclose(ck._adapt_linear(torch.tensor(G["al_in"])).numpy(), G["al_out"], atol=1e-6)
+    missing, unexpected = ck.load_pretrained_encoder(enc, {"model": src})
+    assert not unexpected

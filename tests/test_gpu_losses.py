@@ -65,3 +65,32 @@ def test_vgg_encoder_runs_on_the_bf16x6_convolutions_and_matches_fp64(monkeypatc
     sum(f.square().mean() for f in net(x32)).backward()
     err_lib = float((x32.grad.double() - x64.grad).abs().max() / x64.grad.abs().max())
     assert err_x6 < max(1e-4, 3 * err_lib), (err_x6, err_lib)
+
+
+def test_style_and_identity_losses_match_the_reference_modules_on_the_gpu():
+    """the same reference-derived fixture as tests/test_losses.py, through the GPU path: VGG layers with >= 96 output channels on
+    the bf16x6 convolution kernels (asserted), value within 1e-4 of the float64 reference, d/d(prediction) to the fp32 bar of tests/test_losses.py"""
+    import numpy as np
+    from pathlib import Path
+    from styl3r_amd import vit_ops
+    from styl3r_amd.decoder import DecoderOutput
+    from styl3r_amd.losses import IdentityLoss, LossStyle, LossStyleCfg, VGGEncoder
+    from tests.helpers import deterministic_vgg_
+    G = np.load(Path(__file__).resolve().parent / "golden" / "losses_ref.npz")
+    dev = torch.device("cuda:0")
+    vgg = deterministic_vgg_(VGGEncoder()).to(dev)
+    T = lambda k: torch.tensor(G[k], device=dev)
+    batch = {"target": {"image": T("target")}, "style": {"image": T("style")}}
+    before = dict(vit_ops.CALLS)
+    for name, mod in (("style", LossStyle(LossStyleCfg(float(G["style_weight"])), vgg)), ("identity", IdentityLoss(70, 1, vgg))):
+        p = T("pred").clone().requires_grad_(True)
+        val = mod(DecoderOutput(p, None), batch, None, 0)
+        val.backward()
+        want, gwant = float(G[f"{name}_value"]), G[f"{name}_grad"]
+        assert abs(float(val.detach()) - want) <= 1e-4 * abs(want), (name, float(val.detach()), want)
+        # gradient: element-wise 1e-4 except where a ReLU / max-pool tie flips in fp32 (see tests/test_losses.py)
+        err = np.abs(p.grad.cpu().numpy() - gwant)
+        scale = np.abs(gwant).max()
+        assert (err <= 1e-4 * scale).mean() >= 0.97, (name, (err <= 1e-4 * scale).mean())
+        assert np.linalg.norm(err) <= 2e-2 * np.linalg.norm(gwant), name
+    assert vit_ops.CALLS["conv_x6_fwd"] > before["conv_x6_fwd"]

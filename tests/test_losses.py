@@ -79,3 +79,45 @@ def test_lpips_structure_and_gating():
     l = loss(other, batch, None, 10)
     l.backward()
     assert torch.isfinite(l) and other.color.grad.abs().sum() > 0
+
+
+def _ref_case():
+    from pathlib import Path
+    from tests.helpers import deterministic_vgg_
+    G = np.load(Path(__file__).resolve().parent / "golden" / "losses_ref.npz")
+    return G, deterministic_vgg_(VGGEncoder())
+
+
+def test_style_and_identity_losses_match_the_reference_modules():
+    """LossStyle / IdentityLoss against the REFERENCE's own modules (src/loss/loss_style.py:35-79, loss_identity.py:26-49,
+    src/test/vgg_model.py:79-98) evaluated in float64 on deterministic VGG19 weights (tests/golden/make_loss_fixtures.py).
+    (a) this repo's modules in float64 reproduce value and d/d(prediction) to the fixture's storage precision: the arithmetic
+        is pinned;
+    (b) the fp32 path gives the value to 2e-5; its gradient agrees element-wise except where a ReLU / max-pool decision sits
+        within fp32 round-off of a tie and flips (a flip at relu4_1 moves a 44 x 44-pixel patch of the input gradient; the
+        reference's own fp32 run has the same property), so the bar is: >= 97 % of the elements within 1e-4 of max|g| and a
+        2 % relative L2 error."""
+    G, vgg = _ref_case()
+    T = lambda k: torch.tensor(G[k])
+    from styl3r_amd.losses import _imagenet_normalize
+    feats = vgg(_imagenet_normalize(T("pred").reshape(4, 3, 64, 64)))
+    for k, f in enumerate(feats):
+        want = G[f"vgg_h{k + 1}_mean"]
+        assert np.abs(f.mean(dim=(2, 3)).numpy() - want).max() <= 2e-5 * np.abs(want).max(), k
+    for dt in (torch.float64, torch.float32):
+        net = vgg.double() if dt == torch.float64 else vgg.float()
+        batch = {"target": {"image": T("target").to(dt)}, "style": {"image": T("style").to(dt)}}
+        for name, mod in (("style", LossStyle(LossStyleCfg(float(G["style_weight"])), net)), ("identity", IdentityLoss(70, 1, net))):
+            p = T("pred").to(dt).clone().requires_grad_(True)
+            val = mod(DecoderOutput(p, None), batch, None, 0)
+            val.backward()
+            want, gwant = float(G[f"{name}_value"]), G[f"{name}_grad"].astype(np.float64)
+            err = np.abs(p.grad.numpy() - gwant)
+            scale = np.abs(gwant).max()
+            if dt == torch.float64:
+                assert abs(float(val.detach()) - want) <= 1e-12 * abs(want), (name, float(val.detach()), want)
+                assert err.max() <= 2e-7 * scale, (name, err.max() / scale)       # the fixture stores float32
+            else:
+                assert abs(float(val.detach()) - want) <= 2e-5 * abs(want), (name, float(val.detach()), want)
+                assert (err <= 1e-4 * scale).mean() >= 0.97, (name, (err <= 1e-4 * scale).mean())
+                assert np.linalg.norm(err) <= 2e-2 * np.linalg.norm(gwant), name

@@ -3,6 +3,7 @@
 //   build:  hipcc --offload-arch=gfx950 -O3 tools/probes/issue_cost3.hip -o build/issue_cost3
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #define G8(pre, post) pre "%0" post "\n\t" pre "%1" post "\n\t" pre "%2" post "\n\t" pre "%3" post "\n\t" pre "%4" post "\n\t" pre "%5" post "\n\t" pre "%6" post "\n\t" pre "%7" post
 // two-register forms: dst %n, src %n
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) k(float *out, int iters)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             switch (OP) {
-#define X(name, n, str) case OP_##name: asm volatile(str : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b), "+v"(c), "+s"(m), "+s"(m2), "+s"(sc) : : "vcc"); break;
+#define X(name, n, str) case OP_##name: asm volatile(str : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b), "+v"(c), "+s"(m), "+s"(m2), "+s"(sc) : : "vcc", "scc"); break;
                 OPS(X)
 #undef X
             }
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) k(float *out, int iters)
 template <int OP>
 static void run(float *out, int ncu)
 {
-    const int iters = 1024;
+    const int iters = (OP == OP_cndmask_vcc_stale) ? 256 : 2048;
     printf("%-30s", NAMES[OP]);
     for (int w : {1, 2, 4, 8}) {
         const int blocks = ncu * w;
@@ -108,14 +109,15 @@ static void run(float *out, int ncu)
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const int first = argc > 1 ? atoi(argv[1]) : 0, last = argc > 2 ? atoi(argv[2]) : 1000;
     hipDeviceProp_t p;
     (void)hipGetDeviceProperties(&p, 0);
     const int ncu = p.multiProcessorCount;
     float *out;
     (void)hipMalloc(&out, (size_t)ncu * 8 * 256 * 4);
-#define X(name, n, str) run<OP_##name>(out, ncu);
+#define X(name, n, str) if (OP_##name >= first && OP_##name <= last) run<OP_##name>(out, ncu);
     OPS(X)
 #undef X
     return 0;
