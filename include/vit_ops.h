@@ -154,6 +154,30 @@ int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W
 /* its input gradient: dout (planes, 2H, 2W) -> din (planes, H, W), a gather (no atomics), overwritten */
 int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream);
 
+/*
+ * Head tails + Gaussian adapter in one pass: reg_dense_depth(mode='exp') (postprocess.py:22-60),
+ * sigmoid + map_pdf_to_opacity (encoder_noposplat_multi_token_style.py:115-128,205-209), UnifiedGaussianAdapter.forward
+ * (gaussian_adapter.py:122-153) and build_covariance / quaternion_to_matrix (gaussians.py:8-44), from the DPT heads' NCHW
+ * outputs straight to the Gaussians in the rasterizer's layout (Gaussian g = view * H*W + pixel of scene bi):
+ *   means (b, v*H*W, 3), cov (b, v*H*W, 3, 3), sh (b, v*H*W, 3, d_sh), opac (b, v*H*W); scales (.., 3) / rot (.., 4,
+ *   normalised xyzw) are optional (visualization_dump) and may be NULL.
+ * Inputs: pts0 (b,3,H,W) = downstream_head1's raw output for view 0, ptsr (b*(v-1),3,H,W) = downstream_head2's for views
+ * 1..v-1 (NULL when v == 1); par0 / parr likewise with par_channels >= 8 channels [density, scale x3, rotation xyzw x4, ...];
+ * app (b*v, 3*d_sh, H, W) = the appearance head (channel c*d_sh + k), or NULL: the SH channels are then channels 8.. of
+ * par0 / parr (the non-style encoders' single gs head, par_channels == 8 + 3*d_sh).  sh_mask: (d_sh) device floats.
+ * opacity_exponent = 2^x of map_pdf_to_opacity (1 at the reference's settings).
+ * The backward overwrites every input gradient (same shapes as the inputs; d_par* only channels it owns: all of them).
+ */
+typedef struct VitAdapterArgs {
+    int32_t b, v, H, W, d_sh, par_channels;
+    float opacity_exponent;
+    const float *pts0, *ptsr, *par0, *parr, *app, *sh_mask;
+} VitAdapterArgs;
+int vit_adapter_fwd(const VitAdapterArgs *a, float *means, float *cov, float *sh, float *opac, float *scales, float *rot,
+                    void *stream);
+int vit_adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_cov, const float *d_sh, const float *d_opac,
+                    float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app, void *stream);
+
 const char *vit_version(void);
 const char *vit_last_error(void);
 

@@ -34,6 +34,7 @@
  * (cuda_splatting.py:76).  Tiles are 16x16, tile id = ty*grid_x + tx.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -154,6 +155,10 @@ static void sh_basis_grad(int deg, real x, real y, real z, real *dx, real *dy, r
 void gso_sh_basis(int deg, real x, real y, real z, real *b) { sh_basis(deg, x, y, z, b); }
 void gso_sh_basis_grad(int deg, real x, real y, real z, real *dx, real *dy, real *dz) { sh_basis_grad(deg, x, y, z, dx, dy, dz); }
 int gso_sizeof_real(void) { return (int)sizeof(real); }
+/* OpenMP threads of the per-Gaussian stages (preprocess, key emission + radix sort, preprocess backward); the per-tile
+ * stages take theirs as an argument.  Every parallel loop writes disjoint outputs: results do not depend on the count. */
+static int g_threads = 1;
+void gso_set_threads(int n) { g_threads = n > 0 ? n : 1; }
 int gso_sizeof_params(void) { return (int)sizeof(gso_params); }
 
 /* ------------------------------------------------------------------------
@@ -236,6 +241,7 @@ void gso_preprocess(const gso_params *p, const real *means, const real *cov6, co
                     int32_t *radii, int32_t *tiles_touched, int32_t *rect, uint8_t *clamped)
 {
     int gx = (p->W + TILE - 1) / TILE, gy = (p->H + TILE - 1) / TILE;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int i = 0; i < p->G; ++i) {
         radii[i] = 0; tiles_touched[i] = 0;
         depth[i] = 0; xy[2 * i] = xy[2 * i + 1] = 0;
@@ -303,11 +309,18 @@ int64_t gso_bin_sort(const gso_params *p, const real *depth, const int32_t *tile
     uint32_t *vals = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)R * 2);
     uint64_t *k0 = keys, *k1 = keys + R;
     uint32_t *v0 = vals, *v1 = vals + R;
-    int64_t off = 0;
+    /* key emission in Gaussian order: offsets = exclusive scan of tiles_touched (serial, cheap), emission in parallel */
+    int64_t *goff = (int64_t *)malloc(sizeof(int64_t) * (size_t)p->G);
+    {
+        int64_t acc = 0;
+        for (int i = 0; i < p->G; ++i) { goff[i] = acc; acc += tiles_touched[i]; }
+    }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int i = 0; i < p->G; ++i) {
         if (tiles_touched[i] == 0) continue;
         float d = (float)depth[i];
         uint32_t bits; memcpy(&bits, &d, 4);
+        int64_t off = goff[i];
         for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
             for (int x = rect[4 * i + 0]; x < rect[4 * i + 2]; ++x) {
                 k0[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | bits;
@@ -315,18 +328,40 @@ int64_t gso_bin_sort(const gso_params *p, const real *depth, const int32_t *tile
                 ++off;
             }
     }
-    for (int pass = 0; pass < 8; ++pass) {
-        size_t hist[257]; memset(hist, 0, sizeof(hist));
-        int sh = pass * 8;
-        for (int64_t j = 0; j < R; ++j) hist[((k0[j] >> sh) & 0xff) + 1]++;
-        for (int d = 0; d < 256; ++d) hist[d + 1] += hist[d];
-        for (int64_t j = 0; j < R; ++j) {
-            size_t dst = hist[(k0[j] >> sh) & 0xff]++;
-            k1[dst] = k0[j]; v1[dst] = v0[j];
+    free(goff);
+    /* stable LSD radix sort, 8 passes of 8 bits; each thread owns a contiguous chunk: per-(digit, thread) offsets keep the
+     * order inside a digit = (thread, position) = the input order, i.e. the pass is stable exactly like the serial one */
+    {
+        int nt = g_threads;
+        if ((int64_t)nt > R) nt = (int)R;
+        size_t *hist = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)nt);
+        for (int pass = 0; pass < 8; ++pass) {
+            int sh = pass * 8;
+#pragma omp parallel num_threads(nt)
+            {
+                int t = omp_get_thread_num();
+                int64_t lo = R * t / nt, hi = R * (t + 1) / nt;
+                size_t *h = hist + 256 * (size_t)t;
+                memset(h, 0, sizeof(size_t) * 256);
+                for (int64_t j = lo; j < hi; ++j) h[(k0[j] >> sh) & 0xff]++;
+#pragma omp barrier
+#pragma omp single
+                {
+                    size_t acc = 0;
+                    for (int d = 0; d < 256; ++d)
+                        for (int u = 0; u < nt; ++u) { size_t c = hist[256 * (size_t)u + d]; hist[256 * (size_t)u + d] = acc; acc += c; }
+                }
+                for (int64_t j = lo; j < hi; ++j) {
+                    size_t dst = h[(k0[j] >> sh) & 0xff]++;
+                    k1[dst] = k0[j]; v1[dst] = v0[j];
+                }
+            }
+            uint64_t *tk = k0; k0 = k1; k1 = tk;
+            uint32_t *tv = v0; v0 = v1; v1 = tv;
         }
-        uint64_t *tk = k0; k0 = k1; k1 = tk;
-        uint32_t *tv = v0; v0 = v1; v1 = tv;
+        free(hist);
     }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int64_t j = 0; j < R; ++j) {
         point_list[j] = (int32_t)v0[j];
         uint32_t tile = (uint32_t)(k0[j] >> 32);
@@ -513,6 +548,7 @@ void gso_preprocess_bwd(const gso_params *p, const real *means, const real *cov6
     real fx = (real)p->W / ((real)2 * p->tanfovx);
     real fy = (real)p->H / ((real)2 * p->tanfovy);
     int n = (p->sh_degree + 1) * (p->sh_degree + 1);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int i = 0; i < p->G; ++i) {
         for (int k = 0; k < 3; ++k) dL_dmeans[3 * i + k] = 0;
         for (int k = 0; k < 6; ++k) dL_dcov6[6 * i + k] = 0;

@@ -112,6 +112,7 @@ class Oracle:
         if proj_raw is None:
             proj_raw = np.eye(4)
         p = self.make_params(G, H, W, tanfovx, tanfovy, bg, view, proj, proj_raw, campos, sh_degree, M)
+        self.lib.gso_set_threads(C.c_int(int(nthreads)))     # per-Gaussian stages (results do not depend on the count)
         dt = self.dtype
         depth = np.zeros(G, dt); xy = np.zeros((G, 2), dt); co = np.zeros((G, 4), dt); rgb = np.zeros((G, 3), dt)
         radii = np.zeros(G, np.int32); tt = np.zeros(G, np.int32); rect = np.zeros((G, 4), np.int32)
@@ -138,6 +139,7 @@ class Oracle:
     def backward(self, st: FwdState, ctx, dL_dimage, dL_ddepth_img=None, want_tau=False, nthreads=1):
         p = ctx["p"]
         p.want_tau = int(want_tau)
+        self.lib.gso_set_threads(C.c_int(int(nthreads)))
         G, M = p.G, ctx["M"]
         dt = self.dtype
         P = self._ptr

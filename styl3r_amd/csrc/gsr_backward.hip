@@ -1,10 +1,11 @@
 // gsr_backward.hip -- backward pipeline of the gfx950 rasterizer.
 //
-//   K6 composite_bwd    same tiling as the forward; the per-tile lists are walked
-//                       back-to-front from the tile's deepest contributor; each splat's
-//                       ten partial gradients are summed across the 64 lanes with DPP row
-//                       operations, across the 4 waves in LDS, and leave the CU as ONE
-//                       atomic per (tile, splat, component).                  (upstream R7)
+//   K6 composite_bwd    same tiling as the forward (one wavefront per tile, 4 pixels per
+//                       lane); the per-tile queues are walked back-to-front from the
+//                       tile's deepest contributor; each splat's ten partial gradients are
+//                       summed across the 64 lanes in registers (permlane swaps + DPP row
+//                       sums, no LDS) and leave the wave as ONE atomic per (tile, splat,
+//                       component).                                           (upstream R7)
 //   K7 preprocess_bwd   per Gaussian, loops over the scene's views and sums their
 //                       contributions in registers (no atomics, deterministic): conic ->
 //                       cov2D -> cov3D / mean, projection, depth, SH, pose (tau).   (R8)
@@ -21,8 +22,11 @@ enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_
 // ten-value wave reduction per splat (wave_reduce10) and ten lanes issue the tile's single
 // atomic per component.  No LDS atomics, no workgroup barriers.
 // DEPTH = false: no dL/ddepth was passed (Styl3R trains on colour only): the depth terms drop out of the evaluation
+#ifndef GSR_K6_MIN_WAVES
+#define GSR_K6_MIN_WAVES 1
+#endif
 template <bool DEPTH>
-__global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+__global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      const float *__restrict__ dL_dimage,
                                                      const float *__restrict__ dL_ddepth)
 {
@@ -43,11 +47,16 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
     const GsrView &vw = views[v];
 
-    // Per pixel the colour/depth recurrences of upstream (accum_rec[ch], last_color[ch]) only ever enter
-    // through their dot product with the pixel's incoming gradient, and both are linear, so ONE scalar
-    // recurrence on u = rgb.g + depth*gd replaces four (identical up to rounding).
-    float fx[4], fy[4], Tr[4], g0[4], g1[4], g2[4], gd[4], bgT[4];
-    float accu[4], last_alpha[4], last_u[4];
+    // Per pixel the colour/depth recurrences of upstream (accum_rec[ch], last_color[ch]) only ever enter through their dot
+    // product with the pixel's incoming gradient, and both are linear, so ONE scalar on u = rgb.g + depth*gd replaces four.
+    // It is kept in ABSOLUTE form: S = T_final (bg.g) + sum over the splats behind the current one of w_i u_i.  With
+    // T_j accum_rec_j = (sum_{i>j} w_i u_i) / (1 - alpha_j), upstream's
+    //     dL/dalpha_j = (u_j - accum_rec_j) T_j - T_final (bg.g) / (1 - alpha_j)        becomes      T_j u_j - S / (1 - alpha_j)
+    // (identical up to rounding): one live register per pixel instead of four (accum_rec, last_alpha, last_u, the background
+    // term) and 3 instructions instead of 8 per evaluation -- the 12 VGPRs this frees are a sixth wave per SIMD.
+    // The pixel coordinates are the lane's base (fx0, fy0) plus the quadrant's constant offset, not eight more registers.
+    const float fx0 = (float)ox, fy0 = (float)oy;
+    float Tr[4], g0[4], g1[4], g2[4], gd[4], S[4];
     uint32_t last[4];
     uint32_t mx = 0;
 #pragma unroll
@@ -55,16 +64,14 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
         const bool inside = px < d.W && py < d.H;
         const size_t pix = (size_t)py * d.W + px;
-        fx[k] = (float)px; fy[k] = (float)py;
         const float Tf = inside ? ws.final_T[v * P + pix] : 0.f;
         last[k] = inside ? ws.n_contrib[v * P + pix] : 0u;
         g0[k] = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
         g1[k] = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
         g2[k] = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
         gd[k] = (DEPTH && inside) ? dL_ddepth[v * P + pix] : 0.f;
-        bgT[k] = -Tf * (vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k]);
+        S[k] = Tf * (vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k]);
         Tr[k] = Tf;
-        accu[k] = last_alpha[k] = last_u[k] = 0.f;
         mx = max(mx, last[k]);
     }
     const float ddelx_dx = 0.5f * (float)d.W, ddely_dy = 0.5f * (float)d.H;
@@ -74,18 +81,19 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     const int max_last = (int)mx;
     const int slot = reduce10_slot(lane);
 
-    // entries [0, max_last) of the queue, in batches from the back; slot l of a batch = entry hi-1-l
-    float4 r0, r1, r2;
-    if (max_last - 1 - lane >= 0) { const int e = max_last - 1 - lane; r0 = q[e * 3 + 0]; r1 = q[e * 3 + 1]; r2 = q[e * 3 + 2]; }
+    // entries [0, max_last) of the queue, in batches from the back; slot l of a batch = entry hi-1-l.  The batch goes
+    // global -> registers -> LDS at its start: holding the NEXT batch in 12 registers across the whole evaluation (round 1)
+    // hid one ~1 us load per 64 entries (< 1 % of a batch's time) and cost the kernel two waves per SIMD of occupancy.
     for (int hi = max_last; hi > 0; hi -= 64) {
         const int cnt = min(64, hi);
         __syncthreads();
-        if (lane < cnt) { s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2; }
-        __syncthreads();
-        {
-            const int e = hi - 64 - 1 - lane;
-            if (e >= 0) { r0 = q[e * 3 + 0]; r1 = q[e * 3 + 1]; r2 = q[e * 3 + 2]; }
+        if (lane < cnt) {
+            const int e = hi - 1 - lane;
+            const float4 r0 = q[e * 3 + 0], r1 = q[e * 3 + 1], r2 = q[e * 3 + 2];
+            s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2;
         }
+        __syncthreads();
+        // (reading entry j + 1 ahead of time was measured: +12 VGPRs drop the kernel from 5 to 4 waves per SIMD, -6 %)
         for (int j = 0; j < cnt; ++j) {
             const uint32_t entry = (uint32_t)(hi - 1 - j);  // 0-based position in the list
             const float4 a = s_q[j * 3 + 0];                // x, y, A, B
@@ -102,9 +110,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             for (int k = 0; k < 4; ++k) {
                 if (!(quad & (1u << k))) continue;  // scalar branch: the only control flow of the evaluation
                 // Straight-line, predicated by `valid`: an invalid (pixel, splat) pair runs with alpha = G = 0, which
-                // leaves T unchanged, contributes exactly 0 to every sum and keeps the recurrence equivalent
-                // (accu' = la*lu + (1-la)*accu, then la = 0 makes the next step reproduce accu').
-                const float dx = a.x - fx[k], dy = a.y - fy[k];
+                // leaves T and S unchanged (w = 0) and contributes exactly 0 to every sum.
+                const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 const float Graw = __expf(fminf(power, 0.f));
                 const float araw = fminf(0.99f, b.y * Graw);
@@ -117,10 +124,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 const float w = alpha * Tr[k];
                 float u = c.x * g0[k] + c.y * g1[k] + c.z * g2[k];
                 if (DEPTH) u += b.z * gd[k];
-                accu[k] = last_alpha[k] * last_u[k] + (1.f - last_alpha[k]) * accu[k];
-                last_u[k] = u;
-                last_alpha[k] = alpha;
-                const float dL_dalpha = (u - accu[k]) * Tr[k] + bgT[k] * inv;
+                const float dL_dalpha = Tr[k] * u - S[k] * inv;
+                S[k] += w * u;
                 s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
                 if (DEPTH) s[GR_DEPTH] += w * gd[k];
                 // dL/dmean2D = sum dL_dG * (-G dx A - G dy B, -G dy C - G dx B) * (W/2, H/2) is linear in the two sums

@@ -312,18 +312,20 @@ __device__ inline uint32_t wave_agg_inc(uint32_t *__restrict__ counters, uint32_
 // row r = lane>>4 holds, in out[0..2], the totals of values
 //     out[0]: {0,1,5,6}[r]   out[1]: {2,3,7,8}[r]   out[2]: {4,-,9,-}[r]
 // (inline asm, not __builtin_amdgcn_permlane{32,16}_swap: hipcc 7.2 folds r[0]+r[1] of the builtin's
-// result pair into r[0]+r[0] -- tools/probes/permlane_probe.hip.  The two v_nop are the wait states
-// the gfx950 rule "VALU write -> v_permlane*_swap read" asks for; hipcc pads nothing inside asm.)
+// result pair into r[0]+r[0] -- tools/probes/permlane_probe.hip.  `s_nop 1` = the two wait states the gfx950 rule
+// "VALU write -> v_permlane*_swap read" asks for (what hipcc emits in front of the builtin; it pads nothing inside asm).
+// NOT v_nop: one v_nop holds the SIMD's VALU port for ~9.5 ns (~20 cycles) against 0.55 ns for an s_nop state
+// (tools/probes/issue_cost3.hip, profiles/r02_issue_cost.md) -- four of them were a fifth of the composite backward.)
 __device__ inline float swap_add32(float x, float y)
 {
     // x' = [x.lo, y.lo], y' = [x.hi, y.hi]  ->  x'+y' = [sum of x pair, sum of y pair]
-    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return x + y;
 }
 __device__ inline float swap_add16(float x, float y)
 {
     // rows: x' = [x.r0, y.r0, x.r2, y.r2], y' = [x.r1, y.r1, x.r3, y.r3]
-    asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     return x + y;
 }
 __device__ inline float row_allsum(float v)
@@ -338,14 +340,14 @@ __device__ inline void wave_reduce10(const float *a, float *out)
 {
     // level 1: five v_permlane32_swap back to back (independent registers: one pair of wait states covers all five)
     float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], y0 = a[5], y1 = a[6], y2 = a[7], y3 = a[8], y4 = a[9];
-    asm volatile("v_nop\n\tv_nop\n\t"
+    asm volatile("s_nop 1\n\t"
                  "v_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
                  "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9"
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4));
     float b0 = x0 + y0, b1 = x1 + y1, b2 = x2 + y2, b3 = x3 + y3, b4 = x4 + y4;   // lanes<32: a_i, lanes>=32: a_{i+5}
     // level 2: rows.  (b0,b1) -> a0 a1 a5 a6 ; (b2,b3) -> a2 a3 a7 a8 ; (b4,0) -> a4 - a9 -
     float z = 0.f;
-    asm volatile("v_nop\n\tv_nop\n\t"
+    asm volatile("s_nop 1\n\t"
                  "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5"
                  : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(z));
     out[0] = row_allsum(b0 + b1); out[1] = row_allsum(b2 + b3); out[2] = row_allsum(b4 + z);

@@ -6,11 +6,13 @@
 //   K2 scan_tiles      exclusive scan of the V*T tile counters (one workgroup).   (R2)
 //   K3 scatter         every (view, Gaussian, tile) pair -> its tile bucket as
 //                      (depth_bits<<32 | id).                                     (R3)
-//   K4 tile_sort       per-tile depth sort in LDS (normalised bitonic network on the
-//                      64-bit keys -> order = depth, then id == upstream's stable radix
-//                      order); writes the sorted id list AND the tile's splat queue: the
-//                      48-B records gathered once, in order, with a 4-bit mask of the 8x8
-//                      quadrants the splat's alpha>=1/255 footprint can reach.   (R4,R5)
+//   K4 tile_sort       per-tile depth sort in LDS: one MSD radix pass over the 8 most
+//                      significant VARYING depth bits of the tile (LDS-atomic histogram,
+//                      scan, scatter), then an exact rank inside each bucket on the full
+//                      64-bit (depth, id) key == upstream's stable radix order; writes
+//                      the sorted id list AND the tile's splat queue: the 48-B records
+//                      gathered once, in order, with a 4-bit mask of the 8x8 quadrants
+//                      the splat's alpha>=1/255 footprint can reach.             (R4,R5)
 //   K5 composite_fwd   ONE WAVEFRONT per 16x16 tile, 4 pixels per lane (one per quadrant):
 //                      streams the contiguous queue through a wave-private LDS slot
 //                      (coalesced dwordx4 loads, next batch prefetched in registers, LDS
@@ -18,9 +20,13 @@
 //                      as its 256 pixels are saturated.  No workgroup barriers.      (R6)
 //
 // The upstream design sorts all pairs of one view globally on 64-bit keys (6-8 radix
-// passes over HBM).  Here the tile id never enters a sort: pairs are bucketed by tile
-// with one counting pass and each bucket is depth-sorted inside the CU's LDS, which cuts
-// the binning traffic from ~140 B/pair to ~20 B/pair and needs no host round trip.
+// passes over HBM, ~120 B/pair) and reads R back to the host.  Here the tile id never
+// enters a sort: pairs are bucketed by tile with one counting pass (K1 counters + K3
+// scatter, 8 B/pair written) and each bucket is depth-sorted inside the CU's LDS (8 B/pair
+// read + 4 B/pair written), with no host round trip.  K4 ALSO gathers the 48-B record of
+// every pair and writes the 48-B queue entry -- measured 115 B/pair in total for this
+// kernel (PMC), i.e. the binning + queue traffic is on par with upstream's sort alone;
+// what it buys is that K5 / K6 stream contiguous queues instead of gathering by id.
 #include "gsr_common.h"
 
 namespace gsr {
@@ -391,6 +397,28 @@ __device__ inline void bitonic_sort_1024(unsigned long long *s, uint32_t n, int 
 
 constexpr uint32_t SORT_LDS_KEYS = 4096;  // at most 32 KiB of (dynamic) LDS per workgroup; GSR_FLAG_SORT_KEYS_* ask for less
 
+// ---- per-tile radix (bucket) sort -----------------------------------------------------------------------------
+// One most-significant-digit radix pass over the DEPTH bits that actually vary inside the tile, then an exact rank
+// inside every bucket:
+//   1. min / max of the depth words of the tile's n keys (keys stay in registers, <= 16 per thread);
+//   2. digit = (depth - min) >> shift, shift chosen so that max maps into [0, 255]: the 8 most significant VARYING bits
+//      (the constant high bytes of the float never enter -- what a byte-aligned LSD sort would spend passes on);
+//   3. 256-bin histogram with LDS atomics, exclusive scan, scatter into the buckets (returning LDS atomics; the order
+//      inside a bucket is arbitrary and does not matter);
+//   4. every key's final position = bucket start + number of keys of its bucket that compare smaller on the full 64-bit
+//      (depth, id) key -- buckets hold n / 256 keys on average, so this is a short loop over LDS words that neighbouring
+//      lanes read at the same address (broadcast); the sorted id and the queue record go straight to global memory;
+//   5. a bucket with more than RANK_MAX keys (depth clustered into a sliver of the tile's range: a near outlier in front
+//      of a far plane, or all depths equal) is sorted by the bitonic network instead, in place, by the whole workgroup.
+// O(n) + O(n * bucket size) instead of O(n log^2 n); no stability requirement anywhere because positions come from
+// comparisons of unique keys: the result is bit-identical to any other correct sort of the (depth, id) keys.
+constexpr uint32_t RADIX_BINS = 256, RANK_MAX = 128, RADIX_MAX_PER_THREAD = SORT_LDS_KEYS / 256;
+
+__device__ inline uint32_t radix_digit(unsigned long long key, uint32_t dmin, uint32_t shift)
+{
+    return ((uint32_t)(key >> 32) - dmin) >> shift;
+}
+
 // gather one record into the tile's queue slot and mark the 8x8 quadrants its footprint can touch
 __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *__restrict__ out, uint32_t id, int ox,
                                   int oy)
@@ -439,6 +467,8 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
     extern __shared__ unsigned long long s_key[];   // lds_keys entries: lists longer than that sort in global memory
+    __shared__ uint32_t s_hist[RADIX_BINS], s_start[RADIX_BINS + 1], s_big[RADIX_BINS];
+    __shared__ uint32_t s_red[12], s_nbig;
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists first (as K5 / K6)
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
@@ -446,26 +476,106 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
     const uint32_t start = ws.tile_offset[t];
     const uint32_t n = ws.tile_offset[t + 1] - start;
     if (n == 0) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ox = (tile % gx) * TILE, oy = (tile / gx) * TILE;
     const SplatRec *recs = ws.records + (size_t)v * d.G;
     unsigned long long *gk = ws.pairs + start;
-    if (n <= lds_keys) {
+    if (n <= 64) {
+        // short list: the register-blocked bitonic network (a handful of passes at this size)
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
-#if !(defined(GSR_EXP) && GSR_EXP == 5)
-        if (n > 1024) bitonic_sort_block(s_key, n, tid, 256);
-        else if (n > 1) bitonic_sort_1024(s_key, n, tid);
-#endif
+        if (n > 1) bitonic_sort_1024(s_key, n, tid);
         for (uint32_t i = tid; i < n; i += 256) {
             const uint32_t id = (uint32_t)(s_key[i] & 0xffffffffull);
             ws.point_list[start + i] = id;
-#if !(defined(GSR_EXP) && GSR_EXP == 4)
             emit_queue(recs, ws.queue + start + i, id, ox, oy);
-#endif
+        }
+    } else if (n <= lds_keys) {
+        // ---- 1. keys to registers, depth range of the tile ----
+        unsigned long long k[RADIX_MAX_PER_THREAD];
+        uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e) {
+            const uint32_t i = (uint32_t)tid + 256u * e;
+            if (i < n) {
+                k[e] = gk[i];
+                const uint32_t dep = (uint32_t)(k[e] >> 32);
+                mn = min(mn, dep); mx = max(mx, dep);
+            }
+        }
+        s_hist[tid] = 0u;
+        if (tid == 0) s_nbig = 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        }
+        if (lane == 0) { s_red[wid] = mn; s_red[4 + wid] = mx; }
+        __syncthreads();
+        const uint32_t dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        const uint32_t dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+        const uint32_t range = dmax - dmin;
+        const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
+        const uint32_t shift = nbits > 8u ? nbits - 8u : 0u;
+        // ---- 2. histogram of the 8 most significant varying depth bits ----
+#pragma unroll
+        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e)
+            if ((uint32_t)tid + 256u * e < n) atomicAdd(&s_hist[radix_digit(k[e], dmin, shift)], 1u);
+        __syncthreads();
+        // ---- 3. exclusive scan of the 256 bins (thread = bin), oversized bins noted ----
+        {
+            const uint32_t c = s_hist[tid];
+            uint32_t x = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) s_red[8 + wid] = x;
+            __syncthreads();
+            uint32_t off = x - c;
+            for (int w = 0; w < wid; ++w) off += s_red[8 + w];
+            s_start[tid] = off;
+            if (tid == 255) s_start[256] = off + c;
+            if (c > RANK_MAX) s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
+            s_hist[tid] = 0u;                    // becomes the bucket cursor
+        }
+        __syncthreads();
+        // ---- 4. scatter into the buckets ----
+#pragma unroll
+        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e)
+            if ((uint32_t)tid + 256u * e < n) {
+                const uint32_t dg = radix_digit(k[e], dmin, shift);
+                s_key[s_start[dg] + atomicAdd(&s_hist[dg], 1u)] = k[e];
+            }
+        __syncthreads();
+        // ---- 5. exact rank inside the bucket; sorted id + queue record straight to global memory ----
+        for (uint32_t p = tid; p < n; p += 256) {
+            const unsigned long long key = s_key[p];
+            const uint32_t dg = radix_digit(key, dmin, shift);
+            const uint32_t s0 = s_start[dg], s1 = s_start[dg + 1];
+            if (s1 - s0 > RANK_MAX) continue;
+            uint32_t rank = s0;
+            for (uint32_t q = s0; q < s1; ++q) rank += (s_key[q] < key) ? 1u : 0u;
+            const uint32_t id = (uint32_t)(key & 0xffffffffull);
+            ws.point_list[start + rank] = id;
+            emit_queue(recs, ws.queue + start + rank, id, ox, oy);
+        }
+        // ---- 6. oversized buckets: bitonic network in place (whole workgroup), then linear output ----
+        const uint32_t nbig = s_nbig;
+        for (uint32_t b = 0; b < nbig; ++b) {
+            const uint32_t dg = s_big[b];
+            const uint32_t s0 = s_start[dg], m = s_start[dg + 1] - s0;
+            __syncthreads();                      // rank phase (and the previous bucket's output) done with s_key
+            bitonic_sort_block(s_key + s0, m, tid, 256);
+            for (uint32_t i = tid; i < m; i += 256) {
+                const uint32_t id = (uint32_t)(s_key[s0 + i] & 0xffffffffull);
+                ws.point_list[start + s0 + i] = id;
+                emit_queue(recs, ws.queue + start + s0 + i, id, ox, oy);
+            }
         }
     } else {
-        // oversize bucket: same network, in place in global memory (one workgroup owns the
+        // oversize bucket: bitonic network in place in global memory (one workgroup owns the
         // bucket; __syncthreads orders its own global accesses through the CU's L1/L2 path)
         __syncthreads();
         bitonic_sort_block(gk, n, tid, 256);
@@ -522,20 +632,33 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
         last[k] = 0; done[k] = !inside[k];
     }
 
-    float4 r0, r1, r2;
-    if (lane < n) { r0 = q[lane * 3 + 0]; r1 = q[lane * 3 + 1]; r2 = q[lane * 3 + 2]; }
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);
         __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
-        if (lane < cnt) { s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2; }
+        if (lane < cnt) {   // global -> registers -> LDS at the start of the batch (no register-held prefetch: see k_composite_bwd)
+            const int e = base + lane;
+            const float4 r0 = q[e * 3 + 0], r1 = q[e * 3 + 1], r2 = q[e * 3 + 2];
+            s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2;
+        }
         __syncthreads();
-        const int nb = base + 64 + lane;
-        if (nb < n) { r0 = q[nb * 3 + 0]; r1 = q[nb * 3 + 1]; r2 = q[nb * 3 + 2]; }  // in flight during the batch
 
+#if defined(GSR_K5_PIPELINE)
+        // software pipeline over the staged batch: entry j + 1 is read from LDS while entry j is evaluated
+        float4 na = s_q[0], nb = s_q[1], nc = s_q[2];
+#endif
         for (int j = 0; j < cnt; ++j) {
+#if defined(GSR_K5_PIPELINE)
+            const float4 a = na, b = nb, c = nc;
+            {
+                const int jn = min(j + 1, 63);
+                na = s_q[jn * 3 + 0]; nb = s_q[jn * 3 + 1]; nc = s_q[jn * 3 + 2];
+            }
+#else
             const float4 a = s_q[j * 3 + 0];
             const float4 b = s_q[j * 3 + 1];
-            const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(s_q[j * 3 + 2].w));
+            const float4 c = s_q[j * 3 + 2];
+#endif
+            const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
             uint32_t touched = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -554,7 +677,6 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 if (alpha < (1.f / 255.f)) continue;
                 const float test_T = Tr[k] * (1.f - alpha);
                 if (test_T < 0.0001f) { done[k] = true; continue; }
-                const float4 c = s_q[j * 3 + 2];
                 const float w = alpha * Tr[k];
                 C0[k] += c.x * w; C1[k] += c.y * w; C2[k] += c.z * w;
                 D[k] += b.z * w;

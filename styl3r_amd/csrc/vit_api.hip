@@ -25,6 +25,9 @@ int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *
 int layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, const float *dskip,
                   float *dx, float *dgamma, float *dbeta, float *scratch, int M, int C, int accumulate, hipStream_t stream);
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
+int adapter_fwd(const VitAdapterArgs *a, float *means, float *cov, float *sh, float *opac, float *scales, float *rot, hipStream_t s);
+int adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_cov, const float *d_sh, const float *d_opac,
+                float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app, hipStream_t s);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
                     hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
@@ -121,6 +124,19 @@ VIT_EXPORT int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, i
 VIT_EXPORT int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream)
 {
     return vit::upsample2x_bwd(dout, din, planes, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_adapter_fwd(const VitAdapterArgs *a, float *means, float *cov, float *sh, float *opac, float *scales, float *rot,
+                               void *stream)
+{
+    return vit::adapter_fwd(a, means, cov, sh, opac, scales, rot, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_cov, const float *d_sh,
+                               const float *d_opac, float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app,
+                               void *stream)
+{
+    return vit::adapter_bwd(a, d_means, d_cov, d_sh, d_opac, d_pts0, d_ptsr, d_par0, d_parr, d_app, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT const char *vit_version(void) { return "vit-hip gfx950 0.1.0"; }

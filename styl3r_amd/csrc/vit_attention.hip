@@ -36,7 +36,7 @@ __device__ inline float wave_xor32(float x)
 {
     // value of lane ^ 32 (the other half-wave of the same query)
     float y = x;
-    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
     // after the swap: x = [x.lo, y.lo] , y = [x.hi, y.hi] with y == old x  ->  lanes<32 read y (= x.hi), lanes>=32 read x (= x.lo)
     return (threadIdx.x & 32) ? x : y;
 }

@@ -340,9 +340,11 @@ class PixelwiseTaskWithDPT(nn.Module):
         self.kind = kind
         self.dpt = DPTAdapter(num_channels, [ed, dd, dd, dd], [0, l2 * 2 // 4, l2 * 3 // 4, l2], kind)
 
-    def forward(self, tokens, image_size, imgs=None):
+    def forward(self, tokens, image_size, imgs=None, raw: bool = False):
+        """raw=True: the DPT output (B, C, H, W) as it leaves the last convolution -- the fused adapter kernel
+        (vit_adapter_fwd) applies reg_dense_depth itself"""
         out = self.dpt(tokens, image_size, imgs)
-        if self.kind == "pts3d":
+        if self.kind == "pts3d" and not raw:
             return {"pts3d": reg_dense_depth_exp(out.permute(0, 2, 3, 1))}
         return out
 
@@ -446,6 +448,8 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
 
     head_streams = False     # inference option: run the five independent head calls on their own HIP streams
+    fused_adapter = True     # E10-E12 on vit_adapter_fwd / vit_adapter_bwd (device tensors, landscape / square images);
+                             # False = the element-wise framework expression of the same math (the kernel's test reference)
 
     def _run_heads(self, jobs, like: Tensor):
         """The head calls only depend on the trunk outputs.  At serving batch sizes (one scene) none of their kernels fills
@@ -479,6 +483,9 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         enc_feat, enc_pos, dec_feat, shape, images = self.backbone(context)
         sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
 
+        x_op = self.cfg.opacity_mapping
+        exponent = 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
+        fused = self.fused_adapter and images.is_cuda and w >= h
         with torch.autocast("cuda", enabled=False):
             # The reference calls a head once per view (encoder_noposplat_multi_token_style.py:152-177: head1 for view 0,
             # head2 for every other view, the appearance head for each view).  The heads act on every sample independently,
@@ -492,14 +499,31 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
                     return first.unsqueeze(1)
                 return torch.cat((first.unsqueeze(1), others.reshape(b, v - 1, *others.shape[1:])), dim=1)
 
-            jobs = [lambda: landscape_mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat], h, w),
+            if fused:
+                mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
+            else:
+                mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
+            jobs = [lambda: mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat]),
                     lambda: self.gaussian_param_head([t[:, 0].float() for t in dec_feat], (h, w), images[:, 0, :3]),
                     lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
             if v > 1:
-                jobs += [lambda: landscape_mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat], h, w),
+                jobs += [lambda: mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat]),
                          lambda: self.gaussian_param_head2([rest(t).float() for t in dec_feat], (h, w), rest(images)[:, :3])]
             res = self._run_heads(jobs, images)
             pts_0, par_0, app = res[:3]
+            if fused:
+                # E10-E12 in one kernel each way: head outputs (NCHW) -> Gaussians in the rasterizer's layout
+                from .vit_ops import gaussian_adapter_hip
+                out = gaussian_adapter_hip(pts_0, res[3] if v > 1 else None, par_0, res[4] if v > 1 else None, app,
+                                           self.gaussian_adapter.sh_mask, exponent, v, visualization_dump is not None)
+                means, cov, sh, opac = out[:4]
+                if visualization_dump is not None:
+                    visualization_dump["depth"] = means[..., 2].reshape(b, v, h, w, 1, 1)
+                    visualization_dump["scales"] = out[4]
+                    visualization_dump["rotations"] = out[5]
+                    visualization_dump["means"] = means.reshape(b, v, h, w, 1, 3)
+                    visualization_dump["opacities"] = opac.reshape(b, v, h, w, 1, 1)
+                return Gaussians(means, cov, sh, opac)
             pts_r, par_r = (res[3], res[4].flatten(2).transpose(1, 2)) if v > 1 else (None, None)
             pts = per_view(pts_0, pts_r)
             params = per_view(par_0.flatten(2).transpose(1, 2), par_r)

@@ -22,10 +22,10 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
            "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
-           "vit_version", "vit_last_error")
+           "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -50,6 +50,13 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     subprocess.run(real, check=True, cwd=str(_CSRC))
     stamp.write_text(want)
     return LIB_PATH
+
+
+class VitAdapterArgs(C.Structure):
+    _fields_ = [("b", C.c_int32), ("v", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("d_sh", C.c_int32),
+                ("par_channels", C.c_int32), ("opacity_exponent", C.c_float),
+                ("pts0", C.c_void_p), ("ptsr", C.c_void_p), ("par0", C.c_void_p), ("parr", C.c_void_p), ("app", C.c_void_p),
+                ("sh_mask", C.c_void_p)]
 
 
 class VitAttnArgs(C.Structure):
@@ -104,6 +111,10 @@ def load() -> C.CDLL:
     lib.vit_layernorm_fwd.restype = C.c_int
     lib.vit_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_layernorm_bwd.restype = C.c_int
+    lib.vit_adapter_fwd.argtypes = [C.POINTER(VitAdapterArgs), vp, vp, vp, vp, vp, vp, vp]
+    lib.vit_adapter_fwd.restype = C.c_int
+    lib.vit_adapter_bwd.argtypes = [C.POINTER(VitAdapterArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.vit_adapter_bwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -349,7 +360,7 @@ _CONV_X6_MIN_TILES = 100
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
 CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
-         "layernorm_framework": 0}
+         "layernorm_framework": 0, "adapter_hip": 0}
 
 
 def _conv_tiles(out_channels: int, x: Tensor) -> int:
@@ -471,6 +482,63 @@ def upsample2x(x: Tensor) -> Tensor:
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0:
         return _Upsample2x.apply(x)
     return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+class _GaussianAdapterHip(torch.autograd.Function):
+    """vit_adapter_fwd / vit_adapter_bwd (include/vit_ops.h): DPT head outputs (NCHW, per view group) -> Gaussians in the
+    rasterizer's layout, one launch each way (reg_dense_depth + sigmoid / opacity map + UnifiedGaussianAdapter +
+    build_covariance + the per-view cat / transposes).  Returns (means, cov, sh, opac[, scales, rot])."""
+
+    @staticmethod
+    def forward(ctx, pts0, ptsr, par0, parr, app, sh_mask, exponent, v, want_dump):
+        b, _, H, W = pts0.shape
+        dev = pts0.device
+        c = lambda t: None if t is None else t.contiguous().float()
+        pts0, ptsr, par0, parr, app = c(pts0), c(ptsr), c(par0), c(parr), c(app)
+        d_sh = sh_mask.numel()
+        a = VitAdapterArgs(b, v, H, W, d_sh, par0.shape[1], float(exponent), pts0.data_ptr(), ptsr.data_ptr() if ptsr is not None else None,
+                           par0.data_ptr(), parr.data_ptr() if parr is not None else None, app.data_ptr() if app is not None else None,
+                           sh_mask.data_ptr())
+        G = v * H * W
+        means = torch.empty((b, G, 3), dtype=torch.float32, device=dev)
+        cov = torch.empty((b, G, 3, 3), dtype=torch.float32, device=dev)
+        sh = torch.empty((b, G, 3, d_sh), dtype=torch.float32, device=dev)
+        opac = torch.empty((b, G), dtype=torch.float32, device=dev)
+        scales = torch.empty((b, G, 3), dtype=torch.float32, device=dev) if want_dump else None
+        rot = torch.empty((b, G, 4), dtype=torch.float32, device=dev) if want_dump else None
+        _check(load().vit_adapter_fwd(C.byref(a), means.data_ptr(), cov.data_ptr(), sh.data_ptr(), opac.data_ptr(),
+                                      scales.data_ptr() if want_dump else None, rot.data_ptr() if want_dump else None,
+                                      _stream(dev)), "vit_adapter_fwd")
+        CALLS["adapter_hip"] += 1
+        ctx.save_for_backward(pts0, ptsr, par0, parr, app, sh_mask)
+        ctx.meta = (b, v, H, W, d_sh, float(exponent))
+        if want_dump:
+            ctx.mark_non_differentiable(scales, rot)
+            return means, cov, sh, opac, scales, rot
+        return means, cov, sh, opac
+
+    @staticmethod
+    def backward(ctx, g_means, g_cov, g_sh, g_opac, *_):
+        pts0, ptsr, par0, parr, app, sh_mask = ctx.saved_tensors
+        b, v, H, W, d_sh, exponent = ctx.meta
+        dev = pts0.device
+        G = v * H * W
+        z = lambda g, shape: (g.contiguous().float() if g is not None else torch.zeros(shape, dtype=torch.float32, device=dev))
+        g_means, g_cov = z(g_means, (b, G, 3)), z(g_cov, (b, G, 3, 3))
+        g_sh, g_opac = z(g_sh, (b, G, 3, d_sh)), z(g_opac, (b, G))
+        a = VitAdapterArgs(b, v, H, W, d_sh, par0.shape[1], exponent, pts0.data_ptr(), ptsr.data_ptr() if ptsr is not None else None,
+                           par0.data_ptr(), parr.data_ptr() if parr is not None else None, app.data_ptr() if app is not None else None,
+                           sh_mask.data_ptr())
+        e = lambda t: None if t is None else torch.empty_like(t)
+        d_pts0, d_ptsr, d_par0, d_parr, d_app = e(pts0), e(ptsr), e(par0), e(parr), e(app)
+        p = lambda t: None if t is None else t.data_ptr()
+        _check(load().vit_adapter_bwd(C.byref(a), g_means.data_ptr(), g_cov.data_ptr(), g_sh.data_ptr(), g_opac.data_ptr(),
+                                      p(d_pts0), p(d_ptsr), p(d_par0), p(d_parr), p(d_app), _stream(dev)), "vit_adapter_bwd")
+        return d_pts0, d_ptsr, d_par0, d_parr, d_app, None, None, None, None
+
+
+def gaussian_adapter_hip(pts0, ptsr, par0, parr, app, sh_mask, exponent: float, v: int, want_dump: bool = False):
+    return _GaussianAdapterHip.apply(pts0, ptsr, par0, parr, app, sh_mask, exponent, v, want_dump)
 
 
 def invalidate_split_cache() -> None:
