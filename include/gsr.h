@@ -110,6 +110,7 @@ typedef struct GsrLayout {
     size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */
     size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
     size_t tile_order;   /* uint32[V*T]     (view*T + tile) ids, longest list first: launch order of the composite kernels */
+    size_t pairs_alt;    /* uint64[cap]     bucket space of the per-tile sort for lists longer than its LDS budget */
     size_t total;        /* total bytes */
 } GsrLayout;
 

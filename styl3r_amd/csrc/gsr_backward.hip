@@ -142,15 +142,8 @@ __global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims 
                 s[GR_CC] += hy * dy;
             }
             if (__ballot(any) == 0ull) continue;  // wave-uniform
-#if defined(GSR_EXP) && GSR_EXP == 2
-            { float z = 0.f; for (int i = 0; i < 10; ++i) z += s[i]; asm volatile("" ::"v"(z)); continue; }
-#endif
             float tot[3];
             wave_reduce10(s, tot);
-#if defined(GSR_EXP) && GSR_EXP == 1
-            asm volatile("" ::"v"(tot[0]), "v"(tot[1]), "v"(tot[2]));
-            continue;
-#endif
             if (slot >= 0) {
                 const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
                 if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);

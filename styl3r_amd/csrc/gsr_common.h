@@ -37,7 +37,7 @@ constexpr int GR_STRIDE = 12;   // floats per (view, Gaussian) gradient accumula
 struct Ptrs {             // carved workspace
     SplatRec *records;
     uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;
-    unsigned long long *pairs;
+    unsigned long long *pairs, *pairs_alt;
     uint32_t *point_list;
     QueueRec *queue;
     float *final_T;

@@ -412,7 +412,7 @@ constexpr uint32_t SORT_LDS_KEYS = 4096;  // at most 32 KiB of (dynamic) LDS per
 //      of a far plane, or all depths equal) is sorted by the bitonic network instead, in place, by the whole workgroup.
 // O(n) + O(n * bucket size) instead of O(n log^2 n); no stability requirement anywhere because positions come from
 // comparisons of unique keys: the result is bit-identical to any other correct sort of the (depth, id) keys.
-constexpr uint32_t RADIX_BINS = 256, RANK_MAX = 128, RADIX_MAX_PER_THREAD = SORT_LDS_KEYS / 256;
+constexpr uint32_t RADIX_BINS = 256, RANK_MAX = 128;
 
 __device__ inline uint32_t radix_digit(unsigned long long key, uint32_t dmin, uint32_t shift)
 {
@@ -463,10 +463,49 @@ __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *_
     o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
 }
 
+// what a sort step of one tile needs to place its results
+struct TileOut {
+    const SplatRec *recs; uint32_t *point_list; QueueRec *queue;   // point_list / queue already offset to the tile's range
+    int ox, oy;
+    __device__ void put(uint32_t pos, unsigned long long key) const
+    {
+        const uint32_t id = (uint32_t)(key & 0xffffffffull);
+        point_list[pos] = id;
+        emit_queue(recs, queue + pos, id, ox, oy);
+    }
+};
+
+// s_key[0, m) holds the buckets [b0, b1) of the tile, bucket b at local offset s_start[b] - s_start[b0].
+// Exact rank inside every bucket of at most RANK_MAX keys; an oversized one is sorted in place by the bitonic network
+// (whole workgroup) and written linearly.  Ends with the LDS array free for the next group.
+__device__ inline void rank_and_emit(unsigned long long *s_key, uint32_t m, uint32_t b0, uint32_t b1, const uint32_t *s_start,
+                                     const uint32_t *s_big, uint32_t nbig, uint32_t dmin, uint32_t shift, const TileOut &out, int tid)
+{
+    const uint32_t base = s_start[b0];
+    for (uint32_t p = tid; p < m; p += 256) {
+        const unsigned long long key = s_key[p];
+        const uint32_t dg = radix_digit(key, dmin, shift);
+        const uint32_t s0 = s_start[dg] - base, s1 = s_start[dg + 1] - base;
+        if (s1 - s0 > RANK_MAX) continue;
+        uint32_t rank = s0;
+        for (uint32_t q = s0; q < s1; ++q) rank += (s_key[q] < key) ? 1u : 0u;
+        out.put(base + rank, key);
+    }
+    for (uint32_t b = 0; b < nbig; ++b) {
+        const uint32_t dg = s_big[b];
+        if (dg < b0 || dg >= b1) continue;        // (uniform)
+        const uint32_t s0 = s_start[dg] - base, cnt = s_start[dg + 1] - s_start[dg];
+        __syncthreads();                          // the rank phase (and the previous bucket's output) are done with s_key
+        bitonic_sort_block(s_key + s0, cnt, tid, 256);
+        for (uint32_t i = tid; i < cnt; i += 256) out.put(base + s0 + i, s_key[s0 + i]);
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t lds_keys)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
-    extern __shared__ unsigned long long s_key[];   // lds_keys entries: lists longer than that sort in global memory
+    extern __shared__ unsigned long long s_key[];   // lds_keys entries
     __shared__ uint32_t s_hist[RADIX_BINS], s_start[RADIX_BINS + 1], s_big[RADIX_BINS];
     __shared__ uint32_t s_red[12], s_nbig;
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
@@ -477,113 +516,98 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
     const uint32_t n = ws.tile_offset[t + 1] - start;
     if (n == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ox = (tile % gx) * TILE, oy = (tile / gx) * TILE;
-    const SplatRec *recs = ws.records + (size_t)v * d.G;
-    unsigned long long *gk = ws.pairs + start;
+    TileOut out;
+    out.recs = ws.records + (size_t)v * d.G; out.point_list = ws.point_list + start; out.queue = ws.queue + start;
+    out.ox = (tile % gx) * TILE; out.oy = (tile / gx) * TILE;
+    const unsigned long long *gk = ws.pairs + start;
     if (n <= 64) {
         // short list: the register-blocked bitonic network (a handful of passes at this size)
         for (uint32_t i = tid; i < n; i += 256) s_key[i] = gk[i];
         __syncthreads();
         if (n > 1) bitonic_sort_1024(s_key, n, tid);
+        for (uint32_t i = tid; i < n; i += 256) out.put(i, s_key[i]);
+        return;
+    }
+    // ---- 1. depth range of the tile (the keys are re-read from L1 / L2 in every pass: 8 B each, no register array) ----
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t dep = (uint32_t)(gk[i] >> 32);
+        mn = min(mn, dep); mx = max(mx, dep);
+    }
+    s_hist[tid] = 0u;
+    if (tid == 0) s_nbig = 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    }
+    if (lane == 0) { s_red[wid] = mn; s_red[4 + wid] = mx; }
+    __syncthreads();
+    const uint32_t dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+    const uint32_t dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
+    const uint32_t range = dmax - dmin;
+    const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
+    const uint32_t shift = nbits > 8u ? nbits - 8u : 0u;
+    // ---- 2. histogram of the 8 most significant varying depth bits ----
+    for (uint32_t i = tid; i < n; i += 256) atomicAdd(&s_hist[radix_digit(gk[i], dmin, shift)], 1u);
+    __syncthreads();
+    // ---- 3. exclusive scan of the 256 bins (thread = bin), oversized bins noted ----
+    {
+        const uint32_t c = s_hist[tid];
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_red[8 + wid] = x;
+        __syncthreads();
+        uint32_t off = x - c;
+        for (int w = 0; w < wid; ++w) off += s_red[8 + w];
+        s_start[tid] = off;
+        if (tid == 255) s_start[256] = off + c;
+        if (c > RANK_MAX) s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
+        s_hist[tid] = 0u;                    // becomes the bucket cursor
+    }
+    __syncthreads();
+    const uint32_t nbig = s_nbig;
+    if (n <= lds_keys) {
+        // ---- 4. scatter into the buckets in LDS, 5. rank + emit ----
         for (uint32_t i = tid; i < n; i += 256) {
-            const uint32_t id = (uint32_t)(s_key[i] & 0xffffffffull);
-            ws.point_list[start + i] = id;
-            emit_queue(recs, ws.queue + start + i, id, ox, oy);
-        }
-    } else if (n <= lds_keys) {
-        // ---- 1. keys to registers, depth range of the tile ----
-        unsigned long long k[RADIX_MAX_PER_THREAD];
-        uint32_t mn = 0xffffffffu, mx = 0u;
-#pragma unroll
-        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e) {
-            const uint32_t i = (uint32_t)tid + 256u * e;
-            if (i < n) {
-                k[e] = gk[i];
-                const uint32_t dep = (uint32_t)(k[e] >> 32);
-                mn = min(mn, dep); mx = max(mx, dep);
-            }
-        }
-        s_hist[tid] = 0u;
-        if (tid == 0) s_nbig = 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-        }
-        if (lane == 0) { s_red[wid] = mn; s_red[4 + wid] = mx; }
-        __syncthreads();
-        const uint32_t dmin = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        const uint32_t dmax = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-        const uint32_t range = dmax - dmin;
-        const uint32_t nbits = range ? 32u - (uint32_t)__clz((int)range) : 0u;
-        const uint32_t shift = nbits > 8u ? nbits - 8u : 0u;
-        // ---- 2. histogram of the 8 most significant varying depth bits ----
-#pragma unroll
-        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e)
-            if ((uint32_t)tid + 256u * e < n) atomicAdd(&s_hist[radix_digit(k[e], dmin, shift)], 1u);
-        __syncthreads();
-        // ---- 3. exclusive scan of the 256 bins (thread = bin), oversized bins noted ----
-        {
-            const uint32_t c = s_hist[tid];
-            uint32_t x = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = (uint32_t)__shfl_up((int)x, o, 64);
-                if (lane >= o) x += y;
-            }
-            if (lane == 63) s_red[8 + wid] = x;
-            __syncthreads();
-            uint32_t off = x - c;
-            for (int w = 0; w < wid; ++w) off += s_red[8 + w];
-            s_start[tid] = off;
-            if (tid == 255) s_start[256] = off + c;
-            if (c > RANK_MAX) s_big[atomicAdd(&s_nbig, 1u)] = (uint32_t)tid;
-            s_hist[tid] = 0u;                    // becomes the bucket cursor
-        }
-        __syncthreads();
-        // ---- 4. scatter into the buckets ----
-#pragma unroll
-        for (uint32_t e = 0; e < RADIX_MAX_PER_THREAD; ++e)
-            if ((uint32_t)tid + 256u * e < n) {
-                const uint32_t dg = radix_digit(k[e], dmin, shift);
-                s_key[s_start[dg] + atomicAdd(&s_hist[dg], 1u)] = k[e];
-            }
-        __syncthreads();
-        // ---- 5. exact rank inside the bucket; sorted id + queue record straight to global memory ----
-        for (uint32_t p = tid; p < n; p += 256) {
-            const unsigned long long key = s_key[p];
+            const unsigned long long key = gk[i];
             const uint32_t dg = radix_digit(key, dmin, shift);
-            const uint32_t s0 = s_start[dg], s1 = s_start[dg + 1];
-            if (s1 - s0 > RANK_MAX) continue;
-            uint32_t rank = s0;
-            for (uint32_t q = s0; q < s1; ++q) rank += (s_key[q] < key) ? 1u : 0u;
-            const uint32_t id = (uint32_t)(key & 0xffffffffull);
-            ws.point_list[start + rank] = id;
-            emit_queue(recs, ws.queue + start + rank, id, ox, oy);
+            s_key[s_start[dg] + atomicAdd(&s_hist[dg], 1u)] = key;
         }
-        // ---- 6. oversized buckets: bitonic network in place (whole workgroup), then linear output ----
-        const uint32_t nbig = s_nbig;
-        for (uint32_t b = 0; b < nbig; ++b) {
-            const uint32_t dg = s_big[b];
-            const uint32_t s0 = s_start[dg], m = s_start[dg + 1] - s0;
-            __syncthreads();                      // rank phase (and the previous bucket's output) done with s_key
-            bitonic_sort_block(s_key + s0, m, tid, 256);
-            for (uint32_t i = tid; i < m; i += 256) {
-                const uint32_t id = (uint32_t)(s_key[s0 + i] & 0xffffffffull);
-                ws.point_list[start + s0 + i] = id;
-                emit_queue(recs, ws.queue + start + s0 + i, id, ox, oy);
-            }
-        }
-    } else {
-        // oversize bucket: bitonic network in place in global memory (one workgroup owns the
-        // bucket; __syncthreads orders its own global accesses through the CU's L1/L2 path)
         __syncthreads();
-        bitonic_sort_block(gk, n, tid, 256);
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint32_t id = (uint32_t)(gk[i] & 0xffffffffull);
-            ws.point_list[start + i] = id;
-            emit_queue(recs, ws.queue + start + i, id, ox, oy);
+        rank_and_emit(s_key, n, 0u, RADIX_BINS, s_start, s_big, nbig, dmin, shift, out, tid);
+        return;
+    }
+    // ---- list longer than the LDS budget: bucket it in global memory (pairs_alt), then take runs of consecutive buckets that
+    //      fit through LDS one after the other.  (One workgroup owns the list: __syncthreads orders its own global accesses
+    //      through the CU's write-through L1.) ----
+    unsigned long long *alt = ws.pairs_alt + start;
+    for (uint32_t i = tid; i < n; i += 256) {
+        const unsigned long long key = gk[i];
+        const uint32_t dg = radix_digit(key, dmin, shift);
+        alt[s_start[dg] + atomicAdd(&s_hist[dg], 1u)] = key;
+    }
+    __syncthreads();
+    uint32_t b0 = 0;
+    while (b0 < RADIX_BINS) {
+        uint32_t b1 = b0 + 1;
+        while (b1 < RADIX_BINS && s_start[b1 + 1] - s_start[b0] <= lds_keys) ++b1;
+        const uint32_t base = s_start[b0], m = s_start[b1] - base;
+        if (m > lds_keys) {
+            // a single bucket beyond the LDS budget (depths clustered AND a very long list): bitonic network in global memory
+            bitonic_sort_block(alt + base, m, tid, 256);
+            for (uint32_t i = tid; i < m; i += 256) out.put(base + i, alt[base + i]);
+            __syncthreads();
+        } else if (m > 0) {
+            for (uint32_t i = tid; i < m; i += 256) s_key[i] = alt[base + i];
+            __syncthreads();
+            rank_and_emit(s_key, m, b0, b1, s_start, s_big, nbig, dmin, shift, out, tid);
         }
+        b0 = b1;
     }
 }
 
@@ -642,22 +666,11 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
         }
         __syncthreads();
 
-#if defined(GSR_K5_PIPELINE)
-        // software pipeline over the staged batch: entry j + 1 is read from LDS while entry j is evaluated
-        float4 na = s_q[0], nb = s_q[1], nc = s_q[2];
-#endif
+        // (reading entry j + 1 ahead of entry j's evaluation was measured: +7 VGPRs, 8 -> 7 waves per SIMD, -6 %)
         for (int j = 0; j < cnt; ++j) {
-#if defined(GSR_K5_PIPELINE)
-            const float4 a = na, b = nb, c = nc;
-            {
-                const int jn = min(j + 1, 63);
-                na = s_q[jn * 3 + 0]; nb = s_q[jn * 3 + 1]; nc = s_q[jn * 3 + 2];
-            }
-#else
             const float4 a = s_q[j * 3 + 0];
             const float4 b = s_q[j * 3 + 1];
             const float4 c = s_q[j * 3 + 2];
-#endif
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
             uint32_t touched = 0;
 #pragma unroll
@@ -668,12 +681,6 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (power > 0.f) continue;
                 const float alpha = fminf(0.99f, b.y * __expf(power));
-#if defined(GSR_EXP) && GSR_EXP == 3
-                atomicAdd(ws.tile_cursor + 0, 1u); if (alpha >= (1.f / 255.f)) atomicAdd(ws.tile_cursor + 1, 1u);
-#endif
-#if defined(GSR_EXP) && GSR_EXP == 6
-                { unsigned long long bm = __ballot(alpha >= (1.f / 255.f)); if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { atomicAdd(ws.tile_cursor + 2, 1u); if (bm == 0) atomicAdd(ws.tile_cursor + 3, 1u); } }
-#endif
                 if (alpha < (1.f / 255.f)) continue;
                 const float test_T = Tr[k] * (1.f - alpha);
                 if (test_T < 0.0001f) { done[k] = true; continue; }
@@ -736,6 +743,7 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.grad_rec = take(V * d.G * 12 * 4);
     L.status = take(GSR_STATUS_WORDS * 4);
     L.tile_order = take(V * T * 4);
+    L.pairs_alt = take((size_t)cap * 8);
     L.total = off;
     return GSR_OK;
 }
@@ -756,6 +764,7 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.grad_rec = reinterpret_cast<float *>(p + L.grad_rec);
     w.status = reinterpret_cast<int32_t *>(p + L.status);
     w.tile_order = reinterpret_cast<uint32_t *>(p + L.tile_order);
+    w.pairs_alt = reinterpret_cast<unsigned long long *>(p + L.pairs_alt);
     return w;
 }
 

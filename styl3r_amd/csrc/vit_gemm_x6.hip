@@ -119,11 +119,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     const uint4 *wb = wp + ((int64_t)min(n0 + brow, N - 1) * KG + bkg) * 3;
     // two register stages: the global loads of slab k+2 are in flight while slab k feeds the MFMAs (one slab of MFMA work,
     // ~0.35 us, is shorter than the L2/HBM latency, so a single stage leaves the wave waiting at every LDS store)
-#if defined(X6_EXP) && X6_EXP == 1   // experiment: no split arithmetic
-#define X6_SPLIT8(lo, hi, q0, q1, q2) do { q0 = make_uint4(__float_as_uint(lo.x), __float_as_uint(lo.y), __float_as_uint(lo.z), __float_as_uint(lo.w)); q1 = make_uint4(__float_as_uint(hi.x), __float_as_uint(hi.y), __float_as_uint(hi.z), __float_as_uint(hi.w)); q2 = q0; } while (0)
-#else
 #define X6_SPLIT8(lo, hi, q0, q1, q2) split8(lo, hi, q0, q1, q2)
-#endif
     struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
     Stage st0, st1;
     st0.b0 = st0.b1 = st0.b2 = st1.b0 = st1.b1 = st1.b2 = make_uint4(0, 0, 0, 0);
@@ -153,20 +149,6 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0};
 
     auto compute = [&](int buf) {
-#if defined(X6_EXP) && X6_EXP == 2   // experiment: only one of the 12 fragment reads per slab
-        const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ + half * 3;
-        const bf16x8 f0 = __builtin_bit_cast(bf16x8, a[0]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                f32x16 c = acc[i][j];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, f0, c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-        return;
-#endif
         const uint4 *a = sA[buf] + (wm * 64 + col) * ROWQ;          // rows wm*64 + 32 i + col, k group = half
         const uint4 *b = sB[buf] + (wn * 32 * TN + col) * ROWQ;
         bf16x8 fa[2][3], fb[TN][3];
@@ -184,13 +166,11 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
-#if !(defined(X6_EXP) && X6_EXP == 4)
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-#endif
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
@@ -215,15 +195,11 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     for (; kt + 1 < nk; kt += 2) {
         compute(0);
         X6_LSTORE(1, st1);
-#if !(defined(X6_EXP) && X6_EXP == 3)
         X6_GLOAD(st1, (kt + 3) * BK);
-#endif
         __syncthreads();
         compute(1);
         X6_LSTORE(0, st0);       // (the store after the last slab writes a buffer nobody reads)
-#if !(defined(X6_EXP) && X6_EXP == 3)
         X6_GLOAD(st0, (kt + 4) * BK);
-#endif
         __syncthreads();
     }
     if (kt < nk) compute(0);   // odd number of slabs

@@ -68,8 +68,7 @@ def test_vgg_encoder_runs_on_the_bf16x6_convolutions_and_matches_fp64(monkeypatc
 
 
 def test_style_and_identity_losses_match_the_reference_modules_on_the_gpu():
-    """the same reference-derived fixture as tests/test_losses.py, through the GPU path: VGG layers with >= 96 output channels on
-    the bf16x6 convolution kernels (asserted), value within 1e-4 of the float64 reference, d/d(prediction) to the fp32 bar of tests/test_losses.py"""
+    """the same reference-derived fixture as tests/test_losses.py, through the GPU path, value within 1e-4 of the float64 reference, d/d(prediction) to the fp32 bar of tests/test_losses.py"""
     import numpy as np
     from pathlib import Path
     from styl3r_amd import vit_ops
@@ -81,7 +80,6 @@ def test_style_and_identity_losses_match_the_reference_modules_on_the_gpu():
     vgg = deterministic_vgg_(VGGEncoder()).to(dev)
     T = lambda k: torch.tensor(G[k], device=dev)
     batch = {"target": {"image": T("target")}, "style": {"image": T("style")}}
-    before = dict(vit_ops.CALLS)
     for name, mod in (("style", LossStyle(LossStyleCfg(float(G["style_weight"])), vgg)), ("identity", IdentityLoss(70, 1, vgg))):
         p = T("pred").clone().requires_grad_(True)
         val = mod(DecoderOutput(p, None), batch, None, 0)
@@ -93,4 +91,5 @@ def test_style_and_identity_losses_match_the_reference_modules_on_the_gpu():
         scale = np.abs(gwant).max()
         assert (err <= 1e-4 * scale).mean() >= 0.90, (name, (err <= 1e-4 * scale).mean())
         assert np.linalg.norm(err) <= 3e-2 * np.linalg.norm(gwant), name
-    assert vit_ops.CALLS["conv_x6_fwd"] > before["conv_x6_fwd"]
+    # (at this fixture's 64 x 64 x 4 images no VGG layer reaches the >= 100-tile gate of the bf16x6 convolutions: the layers run on
+    #  MIOpen here; the x6 VGG path has its own test above at 128 x 128 x 8)

@@ -122,6 +122,28 @@ def test_forward_oversize_tile_list_uses_global_sort():
         rz._MAX_TILE_HINT.clear(); rz._MAX_TILE_HINT.update(old)
 
 
+@pytest.mark.parametrize("case", ["plane_plus_outliers", "all_equal_depth", "two_planes"])
+def test_tile_sort_clustered_depths(case):
+    """the per-tile sort buckets by the varying depth bits of the tile: clustered depths put most keys into a few buckets --
+    buckets above RANK_MAX take the in-LDS network, a bucket above the LDS budget the global one; lists stay bit-identical to
+    the oracle's stable radix order (ties by ascending id)"""
+    cam = simple_camera(32, 32)
+    rng = np.random.default_rng(7)
+    G = {"plane_plus_outliers": 5200, "all_equal_depth": 4500, "two_planes": 3000}[case]
+    if case == "plane_plus_outliers":      # a far plane with float-level jitter and a few near outliers stretching the range
+        z = 6.0 + rng.integers(0, 40, G) * 4.8e-7
+        z[:20] = rng.uniform(0.5, 1.0, 20)
+    elif case == "all_equal_depth":        # range == 0: one bucket, order = id
+        z = np.full(G, 4.0)
+    else:                                   # two thin planes: two big buckets that fit LDS, plus duplicates inside them
+        z = np.where(rng.uniform(size=G) < 0.5, 3.0, 7.0) + rng.integers(0, 8, G) * 4.8e-7
+    z = z.astype(np.float32).astype(np.float64)
+    means = np.stack([rng.uniform(-0.04, 0.04, G) * z, rng.uniform(-0.04, 0.04, G) * z, z], 1)
+    cov6 = np.tile(np.array([4e-4, 0, 0, 4e-4, 0, 4e-4]), (G, 1)) * (z[:, None] ** 2)
+    out, st = _check_forward(means, cov6, rng.uniform(0.01, 0.05, G), cam, colors=rng.uniform(0, 1, (G, 3)), min_ok=0.5)
+    assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > (4096 if case != "two_planes" else 1024)
+
+
 def test_capacity_overflow_retry():
     cam = simple_camera(64, 64)
     means, cov6, opac, shs = random_scene(4000, seed=9, scale=(0.1, 0.3))
