@@ -9,6 +9,8 @@
 //   K7 preprocess_bwd   per Gaussian, loops over the scene's views and sums their
 //                       contributions in registers (no atomics, deterministic): conic ->
 //                       cov2D -> cov3D / mean, projection, depth, SH, pose (tau).   (R8)
+#include <type_traits>
+
 #include "gsr_common.h"
 
 namespace gsr {
@@ -103,12 +105,13 @@ __global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims 
             if (quad == 0) continue;   // footprint misses the tile: nothing to evaluate, nothing to reduce
             const float kop = -0.5f * b.y;
             float s[10];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) s[i] = 0.f;
+            s[GR_DEPTH] = 0.f;
             bool any = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!(quad & (1u << k))) continue;  // scalar branch: the only control flow of the evaluation
+            // one evaluation of quadrant k.  FIRST (the first quadrant of this entry, wave-uniform) ASSIGNS the ten partial
+            // sums, later ones accumulate: no per-entry zeroing of ten registers (a tenth of the kernel's VALU slots when
+            // 1.4 quadrants are evaluated per entry)
+            auto eval = [&](auto first_tag, const int k) {
+                constexpr bool FIRST = decltype(first_tag)::value;
                 // Straight-line, predicated by `valid`: an invalid (pixel, splat) pair runs with alpha = G = 0, which
                 // leaves T and S unchanged (w = 0) and contributes exactly 0 to every sum.
                 const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
@@ -126,20 +129,29 @@ __global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims 
                 if (DEPTH) u += b.z * gd[k];
                 const float dL_dalpha = Tr[k] * u - S[k] * inv;
                 S[k] += w * u;
-                s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
-                if (DEPTH) s[GR_DEPTH] += w * gd[k];
                 // dL/dmean2D = sum dL_dG * (-G dx A - G dy B, -G dy C - G dx B) * (W/2, H/2) is linear in the two sums
                 // hx = sum(-dL_dG/2 * G dx), hy = sum(-dL_dG/2 * G dy), which the conic gradients need anyway: accumulate
                 // those (two adds per evaluation instead of six multiply-adds) and apply A, B, C once per Gaussian in K7
                 const float t = Gv * dL_dalpha;            // dL/dopacity term; dL_dG * G = opacity * t
-                s[GR_OP] += t;
                 const float hgG = kop * t;                  // -1/2 dL_dG G, kop = -opacity / 2 (per entry)
                 const float hx = hgG * dx, hy = hgG * dy;
-                s[GR_MX] += hx;
-                s[GR_MY] += hy;
-                s[GR_CA] += hx * dx;
-                s[GR_CB] += hx * dy;
-                s[GR_CC] += hy * dy;
+                if (FIRST) {
+                    s[GR_RGB + 0] = w * g0[k]; s[GR_RGB + 1] = w * g1[k]; s[GR_RGB + 2] = w * g2[k];
+                    if (DEPTH) s[GR_DEPTH] = w * gd[k];
+                    s[GR_OP] = t; s[GR_MX] = hx; s[GR_MY] = hy;
+                    s[GR_CA] = hx * dx; s[GR_CB] = hx * dy; s[GR_CC] = hy * dy;
+                } else {
+                    s[GR_RGB + 0] += w * g0[k]; s[GR_RGB + 1] += w * g1[k]; s[GR_RGB + 2] += w * g2[k];
+                    if (DEPTH) s[GR_DEPTH] += w * gd[k];
+                    s[GR_OP] += t; s[GR_MX] += hx; s[GR_MY] += hy;
+                    s[GR_CA] += hx * dx; s[GR_CB] += hx * dy; s[GR_CC] += hy * dy;
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(quad & (1u << k))) continue;  // scalar branches: the only control flow of the evaluation
+                if ((quad & ((1u << k) - 1u)) == 0u) eval(std::true_type{}, k);
+                else eval(std::false_type{}, k);
             }
             if (__ballot(any) == 0ull) continue;  // wave-uniform
             float tot[3];

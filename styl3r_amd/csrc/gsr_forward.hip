@@ -419,13 +419,9 @@ __device__ inline uint32_t radix_digit(unsigned long long key, uint32_t dmin, ui
     return ((uint32_t)(key >> 32) - dmin) >> shift;
 }
 
-// gather one record into the tile's queue slot and mark the 8x8 quadrants its footprint can touch
-__device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *__restrict__ out, uint32_t id, int ox,
-                                  int oy)
+// 4-bit mask of the 8x8 quadrants of the tile at (ox, oy) that the splat's alpha >= 1/255 footprint can touch
+__device__ inline uint32_t quadrant_mask(const float4 q0, const float4 q1, uint32_t ext, int ox, int oy)
 {
-    const float4 *r = reinterpret_cast<const float4 *>(recs + id);
-    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-    const uint32_t ext = __float_as_uint(q2.w);
     uint32_t quad = 0;
     if (ext) {
         const float hx = (float)(ext & 0xffffu), hy = (float)(ext >> 16);
@@ -457,21 +453,28 @@ __device__ inline void emit_queue(const SplatRec *__restrict__ recs, QueueRec *_
             if (best <= lim) quad |= 1u << k;
         }
     }
-    float4 *o = reinterpret_cast<float4 *>(out);
-    o[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
-    o[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
-    o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
+    return quad;
 }
 
 // what a sort step of one tile needs to place its results
 struct TileOut {
     const SplatRec *recs; uint32_t *point_list; QueueRec *queue;   // point_list / queue already offset to the tile's range
     int ox, oy;
+    // sorted id + the tile's queue entry for list position `pos`: the 48-B record gathered once, with the quadrant mask.
+    // (Splitting this into "write the ids, barrier, then gather four positions per thread with overlapped loads and
+    // coalesced queue stores" was measured: 7 % slower -- the kernel is bound by the bytes of the random 48-B gathers,
+    // not by their latency.)
     __device__ void put(uint32_t pos, unsigned long long key) const
     {
         const uint32_t id = (uint32_t)(key & 0xffffffffull);
         point_list[pos] = id;
-        emit_queue(recs, queue + pos, id, ox, oy);
+        const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+        const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+        const uint32_t quad = quadrant_mask(q0, q1, __float_as_uint(q2.w), ox, oy);
+        float4 *o = reinterpret_cast<float4 *>(queue + pos);
+        o[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
+        o[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+        o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
     }
 };
 
@@ -509,7 +512,21 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
     __shared__ uint32_t s_hist[RADIX_BINS], s_start[RADIX_BINS + 1], s_big[RADIX_BINS];
     __shared__ uint32_t s_red[12], s_nbig;
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
+#if defined(GSR_K4_LPT)
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists first (as K5 / K6)
+#else
+    // Natural (view, tile-row, tile) order, cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8 -- a
+    // placement that is observed, not promised: it only affects speed).  A splat lies in ~2.5 neighbouring tiles; with the
+    // neighbours sorted on the same XCD around the same time, the second and third gather of its 48-B record hit that
+    // XCD's L2 instead of HBM.  (The composite kernels keep the longest-first order: they are VALU-bound and balance
+    // matters; this kernel is bound by the gather bytes.)
+    uint32_t tv;
+    {
+        const uint32_t nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        const uint32_t x = b & 7u, q = nwg >> 3, r = nwg & 7u;       // XCD x owns q + (x < r) consecutive tiles: exact partition
+        tv = x * q + min(x, r) + (b >> 3);
+    }
+#endif
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];

@@ -9,10 +9,14 @@ Own restatement (same parameter names, so reference checkpoints load unchanged) 
   * `reg_dense_depth('exp')`        src/model/encoder/heads/postprocess.py:22-60
   * `UnifiedGaussianAdapter`        src/model/encoder/common/gaussian_adapter.py:122-153, gaussians.py:8-44
   * `EncoderNoPoSplatMultiTokenStyle.forward`  src/model/encoder/encoder_noposplat_multi_token_style.py:136-251
+  * `StructureBuilder`, `EncoderNoPoSplatTokenStyle`   src/model/encoder/token_stylizer/structure_builder.py:36-150,
+                                    src/model/encoder/encoder_noposplat_token_style.py:69-295
   * `get_encoder`                   src/model/encoder/__init__.py:20-25
-Transformer blocks run on styl3r_amd.vit (fp32-MFMA flash attention with fused RoPE); convolutions,
-Linear and LayerNorm go through torch (MIOpen / hipBLASLt) in fp32 like the reference
-(heads under autocast(enabled=False), encoder_noposplat_multi_token_style.py:150).
+Everything heavy runs on hand-written gfx950 kernels, all fp32-accurate like the reference (heads under
+autocast(enabled=False), encoder_noposplat_multi_token_style.py:150): transformer blocks on styl3r_amd.vit (f32-MFMA flash
+attention with fused RoPE, bf16x6 Linear layers with bias / GELU / residual epilogues, HIP LayerNorm), the DPT heads' 3x3 /
+1x1 stride-1 convolutions and x2 resampling on vit_conv_x6_* / vit_upsample2x_*, the head tails + Gaussian adapter on
+vit_adapter_*.  Only the small-resolution / strided / transposed / 7x7 convolutions stay on MIOpen.
 """
 from __future__ import annotations
 
@@ -239,6 +243,43 @@ class TokenStylizer(CrocoTrunk):
             outs.append(cf.view(b, v, l, -1))
         outs[-1] = self.dec_norm(cf).view(b, v, l, -1)
         return [t[:, :, :-1] for t in outs]                            # drop the last (intrinsics) token per view (:151-152)
+
+
+class StructureBuilder(nn.Module):
+    """`StructureBuilder` (token_stylizer/structure_builder.py:36-150): decoder_embed, then `dec_depth` SELF-attention
+    blocks over the concatenated tokens of the two views, dec_norm; returns per view the 13 hooked outputs without the
+    trailing intrinsics token.  Parameter names equal the reference's (decoder_embed, dec_blocks.N.*, dec_norm)."""
+
+    def __init__(self, params: Optional[dict] = None, model: str = "ViTLarge_BaseDecoder"):
+        super().__init__()
+        pr = params or CROCO_PARAMS[model]
+        assert pr["pos_embed"].startswith("RoPE")
+        self.rope = RopeCfg(float(pr["pos_embed"][len("RoPE"):]), max_pos=64)
+        self.enc_embed_dim, self.dec_embed_dim, self.dec_depth = pr["enc_embed_dim"], pr["dec_embed_dim"], pr["dec_depth"]
+        self.decoder_embed = nn.Linear(self.enc_embed_dim, self.dec_embed_dim, bias=True)
+        self.dec_blocks = nn.ModuleList([Block(self.dec_embed_dim, pr["dec_num_heads"], 4, qkv_bias=True, norm_layer=LayerNorm6,
+                                               rope=self.rope) for _ in range(self.dec_depth)])
+        self.dec_norm = LayerNorm6(self.dec_embed_dim)
+        self.depth_mode, self.conf_mode = ("exp", -inf, inf), None
+
+    def forward(self, feat1: Tensor, pos1: Tensor, feat2: Tensor, pos2: Tensor):
+        outs = [(feat1, feat2)]
+        x = torch.cat((self.decoder_embed(feat1), self.decoder_embed(feat2)), dim=1)
+        pos = torch.cat((pos1, pos2), dim=1)
+        for blk in self.dec_blocks:
+            x = blk(x, pos)
+            outs.append(tuple(x.chunk(2, dim=1)))
+        outs[-1] = tuple(self.dec_norm(x).chunk(2, dim=1))
+        d1, d2 = zip(*outs)
+        return [t[:, :-1] for t in d1], [t[:, :-1] for t in d2]
+
+    @property
+    def patch_size(self) -> int:
+        return 16
+
+    @property
+    def d_out(self) -> int:
+        return 1024
 
 
 # --------------------------------------------------------------------------- DPT heads
@@ -624,8 +665,76 @@ class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
                          g.harmonics.reshape(b, -1, 3, self.gaussian_adapter.d_sh), g.opacities.reshape(b, -1))
 
 
+class EncoderNoPoSplatTokenStyle(EncoderNoPoSplatMultiTokenStyle):
+    """`EncoderNoPoSplatTokenStyle` (encoder_noposplat_token_style.py:69-295), the 2-view style encoder of the registry entry
+    `noposplat_token_style`: the CroCo encoder trunk, a `StructureBuilder` (self-attention over both views) feeding ONE mean
+    head and ONE `gaussian_structure_head` shared by the two views, and the `TokenStylizer` feeding the appearance head.
+    Same modules / state-dict keys as the reference's constructor (pinned: tests/test_encoder.py).  The reference's forward
+    is stale against its own current modules -- it unpacks eight values from a backbone that returns four and calls the
+    token stylizer with a five-argument signature that no longer exists (`:163,188`), and every documented run overrides
+    `model.encoder.name=noposplat_multi_token_style` -- so the forward here is that method restated on the CURRENT
+    interfaces: encoder features (with the intrinsics token) -> structure tokens / stylized tokens -> heads -> adapter."""
+
+    def __init__(self, cfg: EncoderNoPoSplatTokenStyleCfg, trunk_params: Optional[dict] = None):
+        nn.Module.__init__(self)
+        self.cfg = cfg
+        assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1 and cfg.gs_sh_head_type == "dpt"
+        self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)     # `croco`: same parameter layout, v = 2
+        self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
+        self.patch_size = 16
+        self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
+        d_sh3 = 3 * self.gaussian_adapter.d_sh
+        self.stylized = cfg.stylized
+        self.structure_builder = StructureBuilder(trunk_params)
+        self.token_stylizer = TokenStylizer(cfg.token_stylizer, trunk_params)
+        self.downstream_head1 = head_factory("dpt", "pts3d", self.structure_builder)
+        self.gaussian_structure_head = head_factory("dpt_gs_sh", "gs_params", self.structure_builder, out_nchan=self.raw_gs_dim - d_sh3)
+        self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
+
+    def forward(self, context: dict, style: dict, global_step: int = 0, visualization_dump: Optional[dict] = None) -> Gaussians:
+        b, v, _, h, w = context["image"].shape
+        assert v == 2, "noposplat_token_style is the 2-view encoder"
+        bb = self.backbone
+        images = context["image"].reshape(b * v, -1, h, w)
+        token = bb.intrinsic_encoder(context["intrinsics"].flatten(2)).reshape(b * v, 1, -1)
+        feat, pos = bb._encode_image(images, token)
+        feat, pos = feat.view(b, v, feat.shape[1], -1), pos.view(b, v, pos.shape[1], 2)
+        st1, st2 = self.structure_builder(feat[:, 0], pos[:, 0], feat[:, 1], pos[:, 1])
+        sty = self.token_stylizer(style, feat, pos)
+        x_op = self.cfg.opacity_mapping
+        exponent = 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
+        with torch.autocast("cuda", enabled=False):
+            both = [torch.cat((a, c), dim=0).float() for a, c in zip(st1, st2)]       # the shared heads see both views as one batch
+            fused = self.fused_adapter and images.is_cuda and w >= h
+            pts = self.downstream_head1(both, (h, w), raw=True) if fused else landscape_mean_head(self.downstream_head1, both, h, w)
+            par = self.gaussian_structure_head(both, (h, w))
+            app = self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty], (h, w))       # (b*v, 3 d_sh, h, w), b-major
+            if fused:
+                from .vit_ops import gaussian_adapter_hip
+                out = gaussian_adapter_hip(pts[:b], pts[b:], par[:b], par[b:], app, self.gaussian_adapter.sh_mask, exponent, v,
+                                           visualization_dump is not None)
+                means, cov, sh, opac = out[:4]
+                if visualization_dump is not None:
+                    visualization_dump.update(depth=means[..., 2].reshape(b, v, h, w, 1, 1), scales=out[4], rotations=out[5],
+                                              means=means.reshape(b, v, h, w, 1, 3), opacities=opac.reshape(b, v, h, w, 1, 1))
+                return Gaussians(means, cov, sh, opac)
+            pts_all = torch.stack((pts[:b], pts[b:]), dim=1).reshape(b, v, h * w, 1, 3)
+            params = torch.stack((par[:b], par[b:]), dim=1).flatten(3).transpose(2, 3)
+            appearance = app.flatten(2).transpose(1, 2).reshape(b, v, h * w, -1)
+        depths = pts_all[..., -1].unsqueeze(-1)
+        raw = torch.cat((params, appearance), dim=-1).reshape(b, v, h * w, 1, -1)
+        densities = raw[..., 0].sigmoid().unsqueeze(-1)
+        g = self.gaussian_adapter(pts_all.unsqueeze(-2), depths, self.map_pdf_to_opacity(densities, global_step), raw[..., 1:].unsqueeze(-2))
+        if visualization_dump is not None:
+            visualization_dump.update(depth=depths.reshape(b, v, h, w, 1, 1), scales=g.scales.reshape(b, -1, 3),
+                                      rotations=g.rotations.reshape(b, -1, 4), means=g.means.reshape(b, v, h, w, 1, 3),
+                                      opacities=g.opacities.reshape(b, v, h, w, 1, 1))
+        return Gaussians(g.means.reshape(b, -1, 3), g.covariances.reshape(b, -1, 3, 3),
+                         g.harmonics.reshape(b, -1, 3, self.gaussian_adapter.d_sh), g.opacities.reshape(b, -1))
+
+
 ENCODERS = {"noposplat_multi_token_style": EncoderNoPoSplatMultiTokenStyle, "noposplat_multi": EncoderNoPoSplatMulti,
-            "noposplat": EncoderNoPoSplatMulti}
+            "noposplat": EncoderNoPoSplatMulti, "noposplat_token_style": EncoderNoPoSplatTokenStyle}
 
 
 def get_encoder(cfg: EncoderNoPoSplatTokenStyleCfg):

@@ -177,3 +177,71 @@ def test_head_streams_option_gives_the_same_gaussians():
                 assert_close_rel(a.cpu().numpy(), b.cpu().numpy(), 1e-4, name)
         assert len(m._head_stream_pool) == 5
     m.head_streams = False
+
+
+# ---- StructureBuilder + the 2-view `noposplat_token_style` registry entry ------------------------------------------------
+SB = np.load(Path(__file__).resolve().parent / "golden" / "structure_builder.npz")
+SB_TINY = dict(enc_depth=1, dec_depth=12, enc_embed_dim=128, dec_embed_dim=128, enc_num_heads=2, dec_num_heads=2,
+               pos_embed="RoPE100", img_size=(512, 512))
+
+
+def test_noposplat_token_style_keys_match_reference_constructor():
+    """state-dict key set and parameter count of the reference's EncoderNoPoSplatTokenStyle.__init__
+    (encoder_noposplat_token_style.py:73-116), and the registry entry (src/model/encoder/__init__.py:10-15)"""
+    from styl3r_amd.encoder import ENCODERS, EncoderNoPoSplatTokenStyle, EncoderNoPoSplatTokenStyleCfg, GaussianAdapterCfg, get_encoder
+    cfg = EncoderNoPoSplatTokenStyleCfg(name="noposplat_token_style", gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 1))
+    m = EncoderNoPoSplatTokenStyle(cfg, trunk_params=SB_TINY)
+    assert sorted(m.state_dict().keys()) == list(SB["enc_keys"])
+    assert sum(p.numel() for p in m.parameters()) == int(SB["enc_nparams"])
+    assert ENCODERS["noposplat_token_style"] is EncoderNoPoSplatTokenStyle
+    assert set(ENCODERS) == {"noposplat", "noposplat_multi", "noposplat_token_style", "noposplat_multi_token_style"}
+
+
+@pytest.mark.gpu
+def test_structure_builder_matches_reference():
+    """StructureBuilder.forward (structure_builder.py:128-141) against the reference module's outputs and gradients"""
+    from styl3r_amd.encoder import StructureBuilder
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(StructureBuilder(SB_TINY).eval()).to(dev)
+    T = lambda k: torch.tensor(SB[k], device=dev)
+    f1, f2 = T("f1").requires_grad_(True), T("f2").requires_grad_(True)
+    d1, d2 = m(f1, T("pos"), f2, T("pos"))
+    assert len(d1) == len(d2) == int(SB["n_out"])
+    for i in (0, 1, 6, 12):
+        assert_close_rel(d1[i].detach().cpu().numpy(), SB[f"d1_{i}"], 2e-5, f"view 1 output {i}")
+        assert_close_rel(d2[i].detach().cpu().numpy(), SB[f"d2_{i}"], 2e-5, f"view 2 output {i}")
+    ((d1[-1] * T("w0")).sum() + (d2[-1] * T("w1")).sum() + (d1[6] * T("w2")).sum()).backward()
+    assert_close_rel(f1.grad.cpu().numpy(), SB["gf1"], 1e-4, "d feat1")
+    assert_close_rel(f2.grad.cpu().numpy(), SB["gf2"], 1e-4, "d feat2")
+    assert_close_rel(m.dec_blocks[5].attn.qkv.weight.grad.cpu().numpy(), SB["g_qkv5"], 1e-4, "d dec_blocks.5 qkv")
+
+
+@pytest.mark.gpu
+def test_noposplat_token_style_forward_backward_runs_and_fused_adapter_agrees():
+    """the 2-view style encoder end to end on the GPU (the reference's forward cannot run against its own current modules, see
+    the class docstring): shapes, finiteness, gradients reach both trunks, fused adapter == element-wise path"""
+    from styl3r_amd.encoder import EncoderNoPoSplatTokenStyle, EncoderNoPoSplatTokenStyleCfg, GaussianAdapterCfg
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    cfg = EncoderNoPoSplatTokenStyleCfg(name="noposplat_token_style", gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 1))
+    m = deterministic_init_(EncoderNoPoSplatTokenStyle(cfg, trunk_params=SB_TINY).eval()).to(dev)
+    g = torch.Generator(dev).manual_seed(4)
+    img = torch.rand(2, 2, 3, 32, 48, device=dev, generator=g) * 2 - 1
+    K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]], device=dev).expand(2, 2, 3, 3).contiguous()
+    style = torch.rand(2, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    res = {}
+    for fused in (True, False):
+        m.fused_adapter = fused
+        gs = m(dict(image=img, intrinsics=K), dict(image=style), 0)
+        assert gs.means.shape == (2, 2 * 32 * 48, 3) and gs.harmonics.shape == (2, 2 * 32 * 48, 3, 4)
+        res[fused] = gs
+    for name in ("means", "covariances", "harmonics", "opacities"):
+        a, e = getattr(res[True], name), getattr(res[False], name)
+        assert torch.isfinite(a).all()
+        assert_close_rel(a.detach().cpu().numpy(), e.detach().cpu().numpy(), 1e-5, name)
+    m.fused_adapter = True
+    (res[True].means.sum() * 1e-3 + res[True].harmonics.sum() + res[True].opacities.sum()).backward()
+    assert m.structure_builder.dec_blocks[0].attn.qkv.weight.grad.abs().sum() > 0
+    assert m.token_stylizer.dec_blocks[0].cross_attn.projk.weight.grad.abs().sum() > 0
+    assert m.backbone.enc_blocks[0].mlp.fc1.weight.grad.abs().sum() > 0
