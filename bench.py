@@ -94,13 +94,13 @@ def build_batch(args, rank, dev):
 
 def algorithmic_bytes(stage, V, B, G, P, n_sh, R, R_eff):
     """SURVEY.md section 8d per-view figures x the views one launch processes.
-    tile_sort: what this design's K4 moves per (tile, Gaussian) pair -- 8 B key read + 4 B sorted id written (the 12R of
-    the sort proper) + the 48-B record gathered and the 48-B queue entry written (96R)."""
+    tile_sort: what this design's K4 moves per (tile, Gaussian) pair -- 8 B key read + 4 B sorted id written (12R).  The
+    composite stages stay priced with SURVEY 8d's 44 B per staged entry (they now gather the 48-B record themselves)."""
     return {
         "preprocess": B * G * (40 + 12 * n_sh) + V * G * (48 + 4),
         "scan_tiles": 0,
         "scatter": V * G * 16 + 8 * R,
-        "tile_sort": 12 * R + 96 * R,
+        "tile_sort": 12 * R,
         "composite_fwd": 44 * R_eff + 28 * V * P,
         "composite_bwd": 44 * R_eff + 24 * V * P + 44 * V * G,
         "preprocess_bwd": B * G * (40 + 12 * n_sh) + V * G * (48 + 16) + B * G * (40 + 12 * n_sh),

@@ -103,14 +103,13 @@ typedef struct GsrLayout {
     size_t tile_cursor;  /* uint32[V*T]     scatter cursors */
     size_t pairs;        /* uint64[cap]     (depth_bits << 32 | id), bucketed by (view, tile) */
     size_t point_list;   /* uint32[cap]     per-tile depth-sorted Gaussian ids */
-    size_t queue;        /* QueueRec[cap]   per-tile depth-sorted splat queue, 48 B each:
-                                            x,y,A,B | C,opacity,depth,id | r,g,b,quadrant mask */
     size_t final_T;      /* float[V*H*W] */
     size_t n_contrib;    /* uint32[V*H*W] */
     size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */
     size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
     size_t tile_order;   /* uint32[V*T]     (view*T + tile) ids, longest list first: launch order of the composite kernels */
     size_t pairs_alt;    /* uint64[cap]     bucket space of the per-tile sort for lists longer than its LDS budget */
+    size_t quad_mask;    /* uint8[cap]      per list entry: 8x8 quadrants of its tile the splat can touch (forward -> backward) */
     size_t total;        /* total bytes */
 } GsrLayout;
 

@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims 
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
     if (start == end) return;
-    const float4 *__restrict__ q = reinterpret_cast<const float4 *>(ws.queue + start);
+    const uint32_t *__restrict__ plist = ws.point_list + start;
+    const SplatRec *__restrict__ recs = ws.records + (size_t)v * d.G;
     float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
     const GsrView &vw = views[v];
 
@@ -83,17 +84,14 @@ __global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims 
     const int max_last = (int)mx;
     const int slot = reduce10_slot(lane);
 
-    // entries [0, max_last) of the queue, in batches from the back; slot l of a batch = entry hi-1-l.  The batch goes
-    // global -> registers -> LDS at its start: holding the NEXT batch in 12 registers across the whole evaluation (round 1)
-    // hid one ~1 us load per 64 entries (< 1 % of a batch's time) and cost the kernel two waves per SIMD of occupancy.
+    // entries [0, max_last) of the sorted list, in batches from the back; slot l of a batch = entry hi-1-l.  Each lane
+    // gathers one entry's record and parks it in LDS at the start of the batch (stage_entry): holding the NEXT batch in 12
+    // registers across the whole evaluation (round 1) hid one ~1 us load per 64 entries (< 1 % of a batch's time) and cost
+    // the kernel two waves per SIMD of occupancy.
     for (int hi = max_last; hi > 0; hi -= 64) {
         const int cnt = min(64, hi);
         __syncthreads();
-        if (lane < cnt) {
-            const int e = hi - 1 - lane;
-            const float4 r0 = q[e * 3 + 0], r1 = q[e * 3 + 1], r2 = q[e * 3 + 2];
-            s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2;
-        }
+        if (lane < cnt) stage_entry_bwd(recs, plist[hi - 1 - lane], ws.quad_mask[start + hi - 1 - lane], s_q + lane * 3);
         __syncthreads();
         // (reading entry j + 1 ahead of time was measured: +12 VGPRs drop the kernel from 5 to 4 waves per SIMD, -6 %)
         for (int j = 0; j < cnt; ++j) {

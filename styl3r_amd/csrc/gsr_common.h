@@ -12,8 +12,9 @@ constexpr int TILE = GSR_TILE;
 constexpr int TILE_PIX = TILE * TILE;   // 256 pixels = 4 wavefronts
 constexpr int WAVE = 64;
 
-// 48-byte per-(view,Gaussian) splat record; three aligned float4 so a lane
-// gathers it with three dwordx4 loads.
+// 48-byte per-(view,Gaussian) splat record; three aligned float4 so a lane gathers it with three dwordx4 loads.
+// (Padding it to a 64-byte slot, so that the per-tile sort's random gather touches exactly one 64-byte line instead of
+// 1.5 on average, was measured: that kernel did not move, the kernels that stream the records got 10-30 % slower.)
 struct alignas(16) SplatRec {
     float x, y, depth;
     uint32_t rad_flags;     // bits 0..23 radius (0 => culled / not rasterized), bits 24..26 SH channel clamped at 0
@@ -23,8 +24,8 @@ struct alignas(16) SplatRec {
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 
-// 48-byte per-(tile, list position) record written by the tile sort: the queue the
-// composite kernels stream through, already in front-to-back order.
+// 48-byte list entry as the composite kernels park it in LDS (three float4 per entry): the splat record re-ordered for
+// their broadcast reads, plus the Gaussian id and the quadrant mask.
 struct alignas(16) QueueRec {
     float x, y, A, B;
     float C, opacity, depth; uint32_t id;
@@ -39,7 +40,7 @@ struct Ptrs {             // carved workspace
     uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;
     unsigned long long *pairs, *pairs_alt;
     uint32_t *point_list;
-    QueueRec *queue;
+    uint8_t *quad_mask;
     float *final_T;
     uint32_t *n_contrib;
     float *grad_rec;
@@ -247,6 +248,66 @@ __device__ inline int tile_rect(float px, float py, int rad, int gx, int gy, int
 }
 
 #pragma clang fp contract(fast)
+
+// 4-bit mask of the 8x8 quadrants of the tile at (ox, oy) that the splat's alpha >= 1/255 footprint can touch
+__device__ inline uint32_t quadrant_mask(const float4 q0, const float4 q1, uint32_t ext, int ox, int oy)
+{
+    uint32_t quad = 0;
+    if (ext) {
+        const float hx = (float)(ext & 0xffffu), hy = (float)(ext >> 16);
+        const float fox = (float)ox - q0.x, foy = (float)oy - q0.y;      // tile origin relative to the splat centre
+        // a quadrant can see the splat only if min over its pixel rectangle of d^T conic d <= 2 ln(255 opacity):
+        // bounding box first, then the exact minimum of the convex quadratic over the rectangle (centre inside -> 0,
+        // otherwise it sits on one of the four edges at the clamped 1-D minimiser).  Conservative by the 0.2 % margin.
+        const float A = q1.x, B = q1.y, C = q1.z;
+        const float lim = 2.0f * __logf(255.0f * q1.w) * 1.002f + 1e-3f;
+#pragma unroll         // (rolled, the loop costs the composite kernels 45 MORE registers: measured)
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = fox + (float)((k & 1) * 8), x1 = x0 + 7.f;
+            const float y0 = foy + (float)((k >> 1) * 8), y1 = y0 + 7.f;
+            if (x0 > hx || x1 < -hx || y0 > hy || y1 < -hy) continue;
+            float best = 0.f;
+            if (!(x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f)) {
+                best = 3.0e38f;
+                const float iC = -B / C, iA = -B / A;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float xe = e ? x1 : x0;
+                    const float dy = fminf(fmaxf(iC * xe, y0), y1);
+                    best = fminf(best, A * xe * xe + 2.f * B * xe * dy + C * dy * dy);
+                    const float ye = e ? y1 : y0;
+                    const float dx = fminf(fmaxf(iA * ye, x0), x1);
+                    best = fminf(best, A * dx * dx + 2.f * B * dx * ye + C * ye * ye);
+                }
+            }
+            if (best <= lim) quad |= 1u << k;
+        }
+    }
+    return quad;
+}
+
+// One list entry of a composite batch: gather the splat record of Gaussian `id` (three dwordx4 loads) and park it as a
+// QueueRec in the three float4 LDS slots at `dst`.  The forward also marks the quadrants of the tile at (ox, oy) the
+// footprint can touch and leaves that mask in `quad_out` (one byte per list entry); the backward reads it back instead of
+// recomputing it (the mask code is ~150 instructions and 15 registers the backward's 8-waves-per-SIMD budget does not have).
+__device__ inline uint32_t stage_entry_fwd(const SplatRec *__restrict__ recs, uint32_t id, int ox, int oy, float4 *dst)
+{
+    const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    const uint32_t quad = quadrant_mask(q0, q1, __float_as_uint(q2.w), ox, oy);
+    dst[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
+    dst[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+    dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
+    return quad;
+}
+__device__ inline void stage_entry_bwd(const SplatRec *__restrict__ recs, uint32_t id, uint32_t quad, float4 *dst)
+{
+    const float4 *r = reinterpret_cast<const float4 *>(recs + id);
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2];
+    dst[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
+    dst[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+    dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
+}
 
 // ---- wave64 helpers ------------------------------------------------------
 // Sum over the 64 lanes with DPP row operations (no LDS traffic); the total

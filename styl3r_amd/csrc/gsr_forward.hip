@@ -10,23 +10,20 @@
 //                      significant VARYING depth bits of the tile (LDS-atomic histogram,
 //                      scan, scatter), then an exact rank inside each bucket on the full
 //                      64-bit (depth, id) key == upstream's stable radix order; writes
-//                      the sorted id list AND the tile's splat queue: the 48-B records
-//                      gathered once, in order, with a 4-bit mask of the 8x8 quadrants
-//                      the splat's alpha>=1/255 footprint can reach.             (R4,R5)
+//                      the sorted id list.                                       (R4,R5)
 //   K5 composite_fwd   ONE WAVEFRONT per 16x16 tile, 4 pixels per lane (one per quadrant):
-//                      streams the contiguous queue through a wave-private LDS slot
-//                      (coalesced dwordx4 loads, next batch prefetched in registers, LDS
-//                      broadcast reads), skips quadrants by scalar branch, exits as soon
-//                      as its 256 pixels are saturated.  No workgroup barriers.      (R6)
+//                      walks the sorted list 64 entries at a time -- each lane gathers one
+//                      entry's 48-B splat record, computes the 4-bit mask of the 8x8
+//                      quadrants its alpha>=1/255 footprint can reach, and parks both in a
+//                      wave-private LDS slot; the wave then reads the entries back as LDS
+//                      broadcasts, skips quadrants by scalar branch, and exits as soon as
+//                      its 256 pixels are saturated.  No workgroup barriers.         (R6)
 //
 // The upstream design sorts all pairs of one view globally on 64-bit keys (6-8 radix
 // passes over HBM, ~120 B/pair) and reads R back to the host.  Here the tile id never
 // enters a sort: pairs are bucketed by tile with one counting pass (K1 counters + K3
 // scatter, 8 B/pair written) and each bucket is depth-sorted inside the CU's LDS (8 B/pair
-// read + 4 B/pair written), with no host round trip.  K4 ALSO gathers the 48-B record of
-// every pair and writes the 48-B queue entry -- measured 115 B/pair in total for this
-// kernel (PMC), i.e. the binning + queue traffic is on par with upstream's sort alone;
-// what it buys is that K5 / K6 stream contiguous queues instead of gathering by id.
+// read + 4 B/pair written), with no host round trip: ~28 B/pair of binning traffic.
 #include "gsr_common.h"
 
 namespace gsr {
@@ -419,63 +416,16 @@ __device__ inline uint32_t radix_digit(unsigned long long key, uint32_t dmin, ui
     return ((uint32_t)(key >> 32) - dmin) >> shift;
 }
 
-// 4-bit mask of the 8x8 quadrants of the tile at (ox, oy) that the splat's alpha >= 1/255 footprint can touch
-__device__ inline uint32_t quadrant_mask(const float4 q0, const float4 q1, uint32_t ext, int ox, int oy)
-{
-    uint32_t quad = 0;
-    if (ext) {
-        const float hx = (float)(ext & 0xffffu), hy = (float)(ext >> 16);
-        const float fox = (float)ox - q0.x, foy = (float)oy - q0.y;      // tile origin relative to the splat centre
-        // a quadrant can see the splat only if min over its pixel rectangle of d^T conic d <= 2 ln(255 opacity):
-        // bounding box first, then the exact minimum of the convex quadratic over the rectangle (centre inside -> 0,
-        // otherwise it sits on one of the four edges at the clamped 1-D minimiser).  Conservative by the 0.2 % margin.
-        const float A = q1.x, B = q1.y, C = q1.z;
-        const float lim = 2.0f * __logf(255.0f * q1.w) * 1.002f + 1e-3f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float x0 = fox + (float)((k & 1) * 8), x1 = x0 + 7.f;
-            const float y0 = foy + (float)((k >> 1) * 8), y1 = y0 + 7.f;
-            if (x0 > hx || x1 < -hx || y0 > hy || y1 < -hy) continue;
-            float best = 0.f;
-            if (!(x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f)) {
-                best = 3.0e38f;
-                const float iC = -B / C, iA = -B / A;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float xe = e ? x1 : x0;
-                    const float dy = fminf(fmaxf(iC * xe, y0), y1);
-                    best = fminf(best, A * xe * xe + 2.f * B * xe * dy + C * dy * dy);
-                    const float ye = e ? y1 : y0;
-                    const float dx = fminf(fmaxf(iA * ye, x0), x1);
-                    best = fminf(best, A * dx * dx + 2.f * B * dx * ye + C * ye * ye);
-                }
-            }
-            if (best <= lim) quad |= 1u << k;
-        }
-    }
-    return quad;
-}
-
-// what a sort step of one tile needs to place its results
+// where a sort step of one tile places its results: the sorted id list (== upstream's sorted value list).
+// Round 1 (and the first half of round 2) also gathered the 48-B splat record of every list entry here and wrote it, with
+// the quadrant mask, into a per-tile QUEUE that the composite kernels streamed.  Measured (GSR_K4X builds, r02l): the
+// sort proper is 0.04 ms of this kernel's 0.17 at the headline size and 0.24 of 0.77 at 262 144 Gaussians -- the rest
+// was that gather + queue write, bound by bytes (4.5-4.8 TB/s), and the composite kernels then read the 48 B a third
+// and a fourth time.  Now the composite kernels gather the record themselves while they stage a batch (one gather per
+// lane per 64 entries, under VALU-bound work that leaves the memory system idle): 192 -> 104 bytes moved per pair.
 struct TileOut {
-    const SplatRec *recs; uint32_t *point_list; QueueRec *queue;   // point_list / queue already offset to the tile's range
-    int ox, oy;
-    // sorted id + the tile's queue entry for list position `pos`: the 48-B record gathered once, with the quadrant mask.
-    // (Splitting this into "write the ids, barrier, then gather four positions per thread with overlapped loads and
-    // coalesced queue stores" was measured: 7 % slower -- the kernel is bound by the bytes of the random 48-B gathers,
-    // not by their latency.)
-    __device__ void put(uint32_t pos, unsigned long long key) const
-    {
-        const uint32_t id = (uint32_t)(key & 0xffffffffull);
-        point_list[pos] = id;
-        const float4 *r = reinterpret_cast<const float4 *>(recs + id);
-        const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-        const uint32_t quad = quadrant_mask(q0, q1, __float_as_uint(q2.w), ox, oy);
-        float4 *o = reinterpret_cast<float4 *>(queue + pos);
-        o[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
-        o[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
-        o[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
-    }
+    uint32_t *point_list;   // already offset to the tile's range
+    __device__ void put(uint32_t pos, unsigned long long key) const { point_list[pos] = (uint32_t)(key & 0xffffffffull); }
 };
 
 // s_key[0, m) holds the buckets [b0, b1) of the tile, bucket b at local offset s_start[b] - s_start[b0].
@@ -512,21 +462,9 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
     __shared__ uint32_t s_hist[RADIX_BINS], s_start[RADIX_BINS + 1], s_big[RADIX_BINS];
     __shared__ uint32_t s_red[12], s_nbig;
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
-#if defined(GSR_K4_LPT)
+    // (a natural (view, tile) order cut into one contiguous range per XCD, so that the ~2.5 tiles a splat lies in would gather
+    //  its record through one L2, was measured: 2-6 % SLOWER than this order at every size)
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists first (as K5 / K6)
-#else
-    // Natural (view, tile-row, tile) order, cut into 8 contiguous ranges, one per XCD (workgroup b runs on XCD b % 8 -- a
-    // placement that is observed, not promised: it only affects speed).  A splat lies in ~2.5 neighbouring tiles; with the
-    // neighbours sorted on the same XCD around the same time, the second and third gather of its 48-B record hit that
-    // XCD's L2 instead of HBM.  (The composite kernels keep the longest-first order: they are VALU-bound and balance
-    // matters; this kernel is bound by the gather bytes.)
-    uint32_t tv;
-    {
-        const uint32_t nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
-        const uint32_t x = b & 7u, q = nwg >> 3, r = nwg & 7u;       // XCD x owns q + (x < r) consecutive tiles: exact partition
-        tv = x * q + min(x, r) + (b >> 3);
-    }
-#endif
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
@@ -534,8 +472,7 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
     if (n == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     TileOut out;
-    out.recs = ws.records + (size_t)v * d.G; out.point_list = ws.point_list + start; out.queue = ws.queue + start;
-    out.ox = (tile % gx) * TILE; out.oy = (tile / gx) * TILE;
+    out.point_list = ws.point_list + start;
     const unsigned long long *gk = ws.pairs + start;
     if (n <= 64) {
         // short list: the register-blocked bitonic network (a handful of passes at this size)
@@ -659,7 +596,9 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
     const int n = (int)(ws.tile_offset[t + 1] - start);
-    const float4 *__restrict__ q = reinterpret_cast<const float4 *>(ws.queue + start);
+    const uint32_t *__restrict__ plist = ws.point_list + start;
+    const SplatRec *__restrict__ recs = ws.records + (size_t)v * d.G;
+    const int tile_ox = (tile % gx) * TILE, tile_oy = (tile / gx) * TILE;
 
     float fx[4], fy[4], Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
     uint32_t last[4];
@@ -676,11 +615,8 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);
         __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
-        if (lane < cnt) {   // global -> registers -> LDS at the start of the batch (no register-held prefetch: see k_composite_bwd)
-            const int e = base + lane;
-            const float4 r0 = q[e * 3 + 0], r1 = q[e * 3 + 1], r2 = q[e * 3 + 2];
-            s_q[lane * 3 + 0] = r0; s_q[lane * 3 + 1] = r1; s_q[lane * 3 + 2] = r2;
-        }
+        if (lane < cnt)   // one list entry per lane; the quadrant mask is kept for the backward
+            ws.quad_mask[start + base + lane] = (uint8_t)stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
         __syncthreads();
 
         // (reading entry j + 1 ahead of entry j's evaluation was measured: +7 VGPRs, 8 -> 7 waves per SIMD, -6 %)
@@ -754,13 +690,13 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.tile_cursor = take(V * T * 4);
     L.pairs = take((size_t)cap * 8);
     L.point_list = take((size_t)cap * 4);
-    L.queue = take((size_t)cap * sizeof(QueueRec));
     L.final_T = take(V * P * 4);
     L.n_contrib = take(V * P * 4);
     L.grad_rec = take(V * d.G * 12 * 4);
     L.status = take(GSR_STATUS_WORDS * 4);
     L.tile_order = take(V * T * 4);
     L.pairs_alt = take((size_t)cap * 8);
+    L.quad_mask = take((size_t)cap);
     L.total = off;
     return GSR_OK;
 }
@@ -775,13 +711,13 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.tile_cursor = reinterpret_cast<uint32_t *>(p + L.tile_cursor);
     w.pairs = reinterpret_cast<unsigned long long *>(p + L.pairs);
     w.point_list = reinterpret_cast<uint32_t *>(p + L.point_list);
-    w.queue = reinterpret_cast<QueueRec *>(p + L.queue);
     w.final_T = reinterpret_cast<float *>(p + L.final_T);
     w.n_contrib = reinterpret_cast<uint32_t *>(p + L.n_contrib);
     w.grad_rec = reinterpret_cast<float *>(p + L.grad_rec);
     w.status = reinterpret_cast<int32_t *>(p + L.status);
     w.tile_order = reinterpret_cast<uint32_t *>(p + L.tile_order);
     w.pairs_alt = reinterpret_cast<unsigned long long *>(p + L.pairs_alt);
+    w.quad_mask = reinterpret_cast<uint8_t *>(p + L.quad_mask);
     return w;
 }
 

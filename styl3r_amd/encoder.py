@@ -194,29 +194,64 @@ class AsymmetricCroCoMulti(CrocoTrunk):
             out.append(torch.cat([x[:, j] for j in range(v) if j != i], dim=1))
         return torch.stack(out, dim=1)
 
-    def _decoder(self, feat: Tensor, pos: Tensor):
+    def _decoder_split(self, feat: Tensor, pos: Tensor):
+        """The dual decoders (:147-188) with view 0 and views 1.. kept as SEPARATE tensors from start to end:
+        returns a list of 13 pairs (first (b,l,c), rest (b*(v-1),l,c)).  The reference -- and round 1 of this build --
+        re-assembles a (b,v,l,c) tensor after every block and re-slices it for the next one (the "ctx concat" copies
+        SURVEY 8a E7 flags: two cats, a stack and four strided-slice copies per layer, forward and backward).  The memory of
+        view 0's cross-attention, "all other views in view order", IS the rest tensor viewed as (b, (v-1) l, c); at v = 2
+        the memory of the other decoder is the first tensor itself, so the C2 / C3 path copies nothing at all.  For
+        v > 2 the memory of view i >= 1 (view 0 followed by the other rest views) is gathered once per layer."""
         b, v, l, c = feat.shape
-        outs = [feat]
         cur = self.decoder_embed(feat)
-        pos_ctx = self._other_views(pos)
+        f1, f2 = cur[:, 0].contiguous(), cur[:, 1:].reshape(b * (v - 1), l, -1)
+        p1 = pos[:, 0].contiguous()
+        p2 = pos[:, 1:].reshape(b * (v - 1), l, 2)
+        pm1 = pos[:, 1:].reshape(b, (v - 1) * l, 2)                    # memory positions of view 0
+        outs = [(feat[:, 0], feat[:, 1:].reshape(b * (v - 1), l, c))]
+
+        def mem_of_rest(first, rest, width):                           # (b(v-1), (v-1) l, width): for view i, view 0 then the others
+            if v == 2:
+                return first
+            r = rest.view(b, v - 1, l, width)
+            parts = [torch.cat([first.unsqueeze(1)] + [r[:, j:j + 1] for j in range(v - 1) if j != i - 1], dim=1).reshape(b, (v - 1) * l, width)
+                     for i in range(1, v)]
+            return torch.stack(parts, dim=1).reshape(b * (v - 1), (v - 1) * l, width)
+
+        pm2 = mem_of_rest(p1, p2, 2)
         for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
-            ctx = self._other_views(cur)
-            f1, _ = blk1(cur[:, 0].contiguous(), ctx[:, 0].contiguous(), pos[:, 0].contiguous(), pos_ctx[:, 0].contiguous())
-            f2, _ = blk2(cur[:, 1:].reshape(b * (v - 1), l, -1), ctx[:, 1:].reshape(b * (v - 1), ctx.shape[2], -1),
-                         pos[:, 1:].reshape(b * (v - 1), l, 2), pos_ctx[:, 1:].reshape(b * (v - 1), pos_ctx.shape[2], 2))
-            cur = torch.cat((f1.unsqueeze(1), f2.view(b, v - 1, l, -1)), dim=1)
-            outs.append(cur)
-        outs[-1] = self.dec_norm(outs[-1])
+            n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
+            n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
+            f1, f2 = n1, n2
+            outs.append((f1, f2))
+        outs[-1] = (self.dec_norm(f1), self.dec_norm(f2))
         return outs
 
-    def forward(self, context: dict):
+    def _decoder(self, feat: Tensor, pos: Tensor):
+        """list[13] of (b, v, l, c): the reference's return layout, assembled from the split form"""
+        b, v, l, _ = feat.shape
+        return [torch.cat((a.unsqueeze(1), r.view(b, v - 1, l, -1)), dim=1) for a, r in self._decoder_split(feat, pos)]
+
+    def encode(self, context: dict):
+        """first half of forward(): the 24 encoder blocks over all views -> (feat (b,v,l,c), pos (b,v,l,2))"""
         b, v, _, h, w = context["image"].shape
         images = context["image"].reshape(b * v, -1, h, w)
         token = self.intrinsic_encoder(context["intrinsics"].flatten(2)).reshape(b * v, 1, -1)
         feat, pos = self._encode_image(images, token)
-        feat = feat.view(b, v, feat.shape[1], -1)
-        pos = pos.view(b, v, pos.shape[1], 2)
-        dec_feat = [t[:, :, :-1] for t in self._decoder(feat, pos)]   # strip the intrinsics token (:222-225)
+        return feat.view(b, v, feat.shape[1], -1), pos.view(b, v, pos.shape[1], 2)
+
+    def decode(self, feat: Tensor, pos: Tensor):
+        """second half: the dual decoders; strips the intrinsics token (:222-225)"""
+        return [t[:, :, :-1] for t in self._decoder(feat, pos)]
+
+    def decode_split(self, feat: Tensor, pos: Tensor):
+        """the same as pairs (view 0 (b,l-1,c), views 1.. (b*(v-1),l-1,c)) -- what the per-view-group heads consume, no re-assembly"""
+        return [(a[:, :-1], r[:, :-1]) for a, r in self._decoder_split(feat, pos)]
+
+    def forward(self, context: dict):
+        b, v, _, h, w = context["image"].shape
+        feat, pos = self.encode(context)
+        dec_feat = self.decode(feat, pos)
         shape = torch.tensor([h, w]).repeat(b, v, 1)
         return feat, pos, dec_feat, shape, context["image"]
 
@@ -488,7 +523,7 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         self.token_stylizer = TokenStylizer(cfg.token_stylizer, trunk_params)
         self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
 
-    head_streams = False     # inference option: run the five independent head calls on their own HIP streams
+    head_streams = False     # inference option: the style branch next to the backbone and the five head calls, each on its own HIP stream
     fused_adapter = True     # E10-E12 on vit_adapter_fwd / vit_adapter_bwd (device tensors, landscape / square images);
                              # False = the element-wise framework expression of the same math (the kernel's test reference)
 
@@ -521,8 +556,28 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
     def forward(self, context: dict, style: dict, global_step: int = 0,
                 visualization_dump: Optional[dict] = None) -> Gaussians:
         b, v, _, h, w = context["image"].shape
-        enc_feat, enc_pos, dec_feat, shape, images = self.backbone(context)
-        sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
+        images = context["image"]
+        if self.head_streams and images.is_cuda and not torch.is_grad_enabled():
+            # Serving: the style image's 24 encoder blocks do not depend on the content views, and the stylizer's decoder only
+            # needs the backbone's ENCODER features -- at batch 1 none of these kernels fills the chip, so the style branch
+            # runs on a side stream next to the backbone (fork at entry, join before the heads).
+            cur = torch.cuda.current_stream(images.device)
+            side = self.__dict__.setdefault("_style_stream", torch.cuda.Stream(images.device))
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                encoded = self.token_stylizer.encode_style(style)
+            enc_feat, enc_pos = self.backbone.encode(context)
+            side.wait_stream(cur)                                   # the encoder features are ready on `cur` from here on
+            with torch.cuda.stream(side):
+                sty_feat = self.token_stylizer(style, enc_feat, enc_pos, encoded=encoded)
+            dec_feat = self.backbone.decode_split(enc_feat, enc_pos)
+            cur.wait_stream(side)
+            for t in sty_feat:
+                t.record_stream(cur)
+        else:
+            enc_feat, enc_pos = self.backbone.encode(context)
+            dec_feat = self.backbone.decode_split(enc_feat, enc_pos)
+            sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
 
         x_op = self.cfg.opacity_mapping
         exponent = 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
@@ -544,12 +599,12 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
                 mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
             else:
                 mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
-            jobs = [lambda: mean_head(self.downstream_head1, [t[:, 0].float() for t in dec_feat]),
-                    lambda: self.gaussian_param_head([t[:, 0].float() for t in dec_feat], (h, w), images[:, 0, :3]),
+            jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat]),
+                    lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3]),
                     lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
             if v > 1:
-                jobs += [lambda: mean_head(self.downstream_head2, [rest(t).float() for t in dec_feat]),
-                         lambda: self.gaussian_param_head2([rest(t).float() for t in dec_feat], (h, w), rest(images)[:, :3])]
+                jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat]),
+                         lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest(images)[:, :3])]
             res = self._run_heads(jobs, images)
             pts_0, par_0, app = res[:3]
             if fused:

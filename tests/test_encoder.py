@@ -225,7 +225,7 @@ def test_noposplat_token_style_forward_backward_runs_and_fused_adapter_agrees():
     from tests.gpu_utils import assert_close_rel
     dev = "cuda:0"
     cfg = EncoderNoPoSplatTokenStyleCfg(name="noposplat_token_style", gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 1))
-    m = deterministic_init_(EncoderNoPoSplatTokenStyle(cfg, trunk_params=SB_TINY).eval()).to(dev)
+    m = deterministic_init_(EncoderNoPoSplatTokenStyle(cfg, trunk_params=TINY).eval()).to(dev)   # (the intrinsics token is 1024 wide)
     g = torch.Generator(dev).manual_seed(4)
     img = torch.rand(2, 2, 3, 32, 48, device=dev, generator=g) * 2 - 1
     K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]], device=dev).expand(2, 2, 3, 3).contiguous()

@@ -34,20 +34,17 @@ def test_tile_lists_sorted_and_consistent_at_full_size(n_ctx, res, views):
         off = ws[L.tile_offset:L.tile_offset + (V * T + 1) * 4].view(torch.int32).long()
         cnt = ws[L.tile_count:L.tile_count + V * T * 4].view(torch.int32).long()
         assert int(off[-1]) == R and torch.equal(off[1:] - off[:-1], cnt)
-        q = ws[L.queue:L.queue + R * 48].view(torch.float32).view(R, 12)
-        depth = q[:, 6]
-        ids = q[:, 7].view(torch.int32)
-        pl = ws[L.point_list:L.point_list + R * 4].view(torch.int32)
-        assert torch.equal(ids, pl)
+        ids = ws[L.point_list:L.point_list + R * 4].view(torch.int32)
+        # every listed splat belongs to its view's record array; its depth is the sort key
+        view_of_entry = torch.repeat_interleave(torch.arange(V * T, device=DEV) // T, cnt)
+        recs = ws[L.records:L.records + V * G * 48].view(torch.float32).view(V * G, 12)
+        depth = recs[view_of_entry * G + ids.long(), 2]
+        assert bool((recs[view_of_entry * G + ids.long(), 3].view(torch.int32) & 0xffffff).ne(0).all())      # visible (radius > 0)
         # inside every tile: depth non-decreasing, ties by ascending id  <=>  no descent except at tile boundaries
         key_desc = (depth[1:] < depth[:-1]) | ((depth[1:] == depth[:-1]) & (ids[1:] <= ids[:-1]))
         starts = torch.zeros(R, dtype=torch.bool, device=DEV)
         starts[off[:-1][cnt > 0]] = True
         assert not bool((key_desc & ~starts[1:]).any())
-        # every queued splat really belongs to its view's record array
-        view_of_entry = torch.repeat_interleave(torch.arange(V * T, device=DEV) // T, cnt)
-        recs = ws[L.records:L.records + V * G * 48].view(torch.float32).view(V * G, 12)
-        assert torch.equal(recs[view_of_entry * G + ids.long(), 2], depth)
         assert torch.isfinite(out.color).all() and out.color.min() >= 0
     finally:
         rz.KEEP_DEBUG = False

@@ -386,7 +386,7 @@ def test_single_call_and_two_phase_forward_are_identical():
                 assert float(img.abs().sum()) == 0.0               # nothing rendered yet
         torch.cuda.synchronize()
         results.append((img, dep, opa, radii, status.cpu(), ws[L.final_T:L.final_T + 4 * V * H * W].clone(),
-                        ws[L.n_contrib:L.n_contrib + 4 * V * H * W].clone(), ws[L.queue:L.queue + 48 * int(status[0])].clone()))
+                        ws[L.n_contrib:L.n_contrib + 4 * V * H * W].clone(), ws[L.point_list:L.point_list + 4 * int(status[0])].clone()))
     for a, b in zip(*results):
         assert torch.equal(a, b)
     assert float(results[0][0].abs().sum()) > 0
