@@ -115,7 +115,7 @@ def cpu_baseline(args, scenes):
     from styl3r_amd.decoder import prepare_views
     sc = scenes[0]
     orc = Oracle("f32")
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # cores this process may use
     nv = min(args.cpu_views, args.views)
     views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(args.views, 3), True).numpy()
     cov = sc.covariances.numpy()
@@ -134,8 +134,8 @@ def cpu_baseline(args, scenes):
     dt = time.perf_counter() - t0
     return {"value": round(nv / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
             "sample": f"{nv} of the {args.views} views of scene 0 (G={sc.means.shape[0]}, {H}x{W}), fwd+bwd, "
-                      f"oracle/gsr_oracle.c f32, OpenMP over Gaussians (preprocess, key emission, preprocess-backward) "
-                      f"and tiles (per-tile sort, composite forward / backward)"}
+                      f"oracle/gsr_oracle.c f32, OpenMP: per-Gaussian stages (preprocess, key emission + radix sort, preprocess-backward) on "
+                      f"min(cores, 32) threads, per-tile stages (composite forward / backward) on all cores"}
 
 
 def pmc_record(kernel, headline_workload):

@@ -158,7 +158,7 @@ int gso_sizeof_real(void) { return (int)sizeof(real); }
 /* OpenMP threads of the per-Gaussian stages (preprocess, key emission + radix sort, preprocess backward); the per-tile
  * stages take theirs as an argument.  Every parallel loop writes disjoint outputs: results do not depend on the count. */
 static int g_threads = 1;
-void gso_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+void gso_set_threads(int n) { g_threads = n > 0 ? (n > 32 ? 32 : n) : 1; }   /* these stages are short: wide teams only buy fork / barrier time */
 int gso_sizeof_params(void) { return (int)sizeof(gso_params); }
 
 /* ------------------------------------------------------------------------
@@ -332,7 +332,7 @@ int64_t gso_bin_sort(const gso_params *p, const real *depth, const int32_t *tile
     /* stable LSD radix sort, 8 passes of 8 bits; each thread owns a contiguous chunk: per-(digit, thread) offsets keep the
      * order inside a digit = (thread, position) = the input order, i.e. the pass is stable exactly like the serial one */
     {
-        int nt = g_threads;
+        int nt = g_threads > 16 ? 16 : g_threads;   /* barrier per pass: wide teams only add barrier time to this small stage */
         if ((int64_t)nt > R) nt = (int)R;
         size_t *hist = (size_t *)malloc(sizeof(size_t) * 256 * (size_t)nt);
         for (int pass = 0; pass < 8; ++pass) {
