@@ -7,7 +7,8 @@ checkpoints load unchanged.  Differences that do not change results: q, k, v are
 the fused qkv buffer (no rearrange copies), the 2-D RoPE is applied inside the attention kernel
 (the reference rotates the qkv buffer in place with two extra read/write sweeps), dropout layers with
 p = 0 are omitted (every Styl3R config uses drop = attn_drop = drop_path = 0).
-Linear / LayerNorm / GELU run through torch (hipBLASLt / rocm kernels) in fp32.
+Linear (+ bias / exact GELU / residual epilogues) and LayerNorm run on the hand-written kernels of styl3r_amd.vit_ops for
+device tensors (fp32-accurate bf16x6 by default), on the framework's fp32 ops for CPU tensors.
 """
 from __future__ import annotations
 
@@ -19,8 +20,8 @@ from torch import Tensor, nn
 
 from .vit_ops import LayerNorm, fused_linear, memory_efficient_attention
 
-# Linear layers of the blocks run on the fused fp32-MFMA kernel (bias / exact GELU / residual in the
-# epilogue); set to False to route them through torch.nn.functional.linear (hipBLASLt) instead.
+# Linear layers of the blocks run on the fused kernels (bias / exact GELU / residual in the epilogue); set to False to route
+# them through torch.nn.functional.linear (hipBLASLt) instead (tools/bench_train.py --torch-linear: an A/B switch).
 USE_FUSED_LINEAR = True
 
 

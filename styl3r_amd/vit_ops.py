@@ -1,11 +1,19 @@
-"""Host side of libvit_hip.so (include/vit_ops.h): fused 2-D RoPE and fp32 MFMA
-flash attention for the CroCo/MASt3R ViT blocks.
+"""Host side of libvit_hip.so (include/vit_ops.h): ctypes bindings + autograd functions for the encoder's kernels.
 
 Mirrors the reference operator interfaces:
   * `cuRoPE2D` / `cuRoPE2D_func`   src/model/encoder/backbone/croco/curope/curope2d.py:12-39
-    (in-place on the (B,H,N,D) view, backward = same kernel with -F0)
+    (in-place on the (B,H,N,D) view, backward = same kernel with -F0)                          -> vit_rope2d
   * `memory_efficient_attention(q, k, v, scale=, p=0)` on (B,N,H,64) fp32 tensors, blocks.py:129,195
-No CPU / eager fallback: CPU tensors raise.
+                                                                                              -> vit_attention_fwd / _bwd
+  * `nn.Linear` (+ exact GELU, + residual add) of Mlp / Attention / Block, blocks.py:76-82,100,131,149-152
+    -> `fused_linear`: vit_linear_x6_fwd (fp32-accurate bf16x6, default) or vit_linear_fwd (exact-f32 MFMA), dX on the
+       pre-split transposed weight, dW + db on vit_linear_x6_wgrad (accumulating into all-reduce bucket slices)
+  * `nn.LayerNorm(eps=1e-6)`, blocks.py:144-152,205-222                                        -> `LayerNorm` (vit_layernorm_*)
+  * `nn.Conv2d` 3x3 / 1x1 stride 1 of the DPT heads and VGG, dpt_block.py:79-218,350-419      -> `Conv2dX6` (vit_conv_x6_*)
+  * `F.interpolate(scale_factor=2, bilinear, align_corners=True)`                             -> `upsample2x`
+  * reg_dense_depth + opacity map + UnifiedGaussianAdapter + build_covariance                 -> `gaussian_adapter_hip`
+`CALLS` counts how often each hand-written kernel was taken (the parity tests assert on it).
+No CPU / eager fallback for the kernels above on device tensors: a missing library raises; CPU tensors take the framework ops.
 """
 from __future__ import annotations
 
