@@ -94,6 +94,17 @@ int vit_linear_fwd(const float *x, const float *w, const float *bias, const floa
  */
 size_t vit_split_weight_bytes(int rows, int cols);
 int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
+/*
+ * The same Linear with an LDS-DMA operand ring (csrc/vit_gemm_x6r.hip).  Its weight operand is the BLOCK layout
+ * packed[row / 64][k / 8][piece][row % 64][8] bf16 written by vit_split_weight_block (rows padded to a multiple of 64 with
+ * zeros; vit_split_weight_block_bytes gives the size).  cfg: 1 = 128 x 128 ring, 2 = 256 x 256 ring, 3 = 256 x 256 with one
+ * conversion per workgroup and ping-pong wave pairs; K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
+ * DESIGN.md 9.2, not used by the default path.
+ */
+size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);
+int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
+int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
+                       int M, int N, int K, int act, int cfg, void *stream);
 int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                       int M, int N, int K, int act, void *stream);
 

@@ -1,0 +1,544 @@
+// vit_gemm_x6r.hip -- the bf16x6 Linear (see vit_gemm_x6.hip for the arithmetic) with an LDS-DMA operand ring.
+//
+//     out (M,N) = [residual +] act( x (M,K) . w^T (N,K) + bias )
+//
+// EXPERIMENTAL: exported (vit_linear_x6r_fwd) and parity-tested, not on the default path of styl3r_amd/vit_ops.py.
+// Round 2's answer to "is vit_gemm_x6.hip's register-staged data path what holds it at ~40 % of the matrix peak?":
+// it is not.  Measured on the encoder's qkv Linear (5140 x 3072 x 1024, warm clocks, same run; DESIGN 9.2 has the table):
+//     vit_gemm_x6.hip, 128 x 128 tiles, registers -> split -> ds_write, 3 workgroups / CU        0.190 ms   170 TF
+//     k_linear_x6r, 128 x 128 ring, split at fragment read, 2 workgroups / CU                   0.187 ms   173 TF
+//     k_linear_x6r, 256 x 256 ring, 8 waves in lockstep                                         0.196 ms   165 TF
+//     k_linear_x6c, 256 x 256, split once per workgroup, the two waves of a SIMD in ping-pong   0.168 ms   192 TF
+// with the MFMA pipes 43 % busy in every variant that keeps its waves in lockstep (SQ_VALU_MFMA_BUSY_CYCLES), no LDS bank
+// conflicts, and 27 us of the launch being the 63 MB output store.  256 x 256 tiles quantise badly on everything but the
+// qkv / fc1 shapes (84 tiles for N = 1024), so the default path keeps the 128-wide kernel.
+//
+// What this file does differently:
+//   * both operands reach LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no LDS store instructions;
+//     every DMA instruction moves 1 KiB, each 4-lane group reading 64 contiguous bytes;
+//   * the weight is pre-split in a BLOCK layout, packed[n / 64][k / 8][piece][n % 64][8] bf16 (vit_split_weight_block):
+//     a DMA chunk is 1 KiB of contiguous global memory and lands as one plane of 64 consecutive 16-byte LDS slots, which
+//     is also the conflict-free order for the B fragment reads;
+//   * k_linear_x6r: the activations stay fp32 in LDS and are split into their three bf16 pieces when a wave reads its
+//     fragment (redundantly in the WN waves that share the rows); NST stages form a ring, the DMA for slab s + NST - 1 is
+//     issued when slab s starts and waited for with a COUNTED `s_waitcnt vmcnt(n)`, one raw `s_barrier` per slab;
+//   * k_linear_x6c: every wave converts a 32-row share of the NEXT slab into bf16 planes (each activation is split once
+//     per workgroup), all fragment reads are plane reads, and the two waves that share a SIMD run their LDS phase and
+//     their MFMA phase in opposite order, so one wave's 48 MFMAs cover the other's reads and conversion.
+//
+// LDS images: raw A = BM rows x 64 B, 16-byte slot q of row r at slot r*4 + (q ^ ((r >> 2) & 3)) (the 16 lanes of every
+// ds_read_b128 lane group hit 16 distinct 4-bank slots; the DMA applies the XOR on its SOURCE address because its
+// destination is lane-linear); planes = [k group 2][piece 3][rows][16 B].
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vit_ops.h"
+
+namespace vit {
+extern thread_local hipError_t g_last_hip_error;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace x6r {
+constexpr int BK = 16;
+
+__device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ inline void split2(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
+    f32x2 f = {a, b};
+    const bf16x2 h0 = __builtin_convertvector(f, bf16x2);
+    const f32x2 r1 = f - __builtin_convertvector(h0, f32x2);
+    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    p0 = __builtin_bit_cast(uint32_t, h0); p1 = __builtin_bit_cast(uint32_t, h1); p2 = __builtin_bit_cast(uint32_t, h2);
+}
+
+template <typename V4> __device__ inline void split8(const V4 &lo, const V4 &hi, bf16x8 &f0, bf16x8 &f1, bf16x8 &f2)
+{
+    uint4 q0, q1, q2;
+    split2(lo.x, lo.y, q0.x, q1.x, q2.x);
+    split2(lo.z, lo.w, q0.y, q1.y, q2.y);
+    split2(hi.x, hi.y, q0.z, q1.z, q2.z);
+    split2(hi.z, hi.w, q0.w, q1.w, q2.w);
+    f0 = __builtin_bit_cast(bf16x8, q0); f1 = __builtin_bit_cast(bf16x8, q1); f2 = __builtin_bit_cast(bf16x8, q2);
+}
+
+// same walk as vit_gemm_x6.hip's: XCD x owns a contiguous range of the tile sequence, the sequence walks groups of 8
+// row tiles column by column
+__device__ inline void tile_of_block(int bid, int tiles_m, int tiles_n, int &tm, int &tn)
+{
+    constexpr int GM = 8;
+    const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int pid = xcd * q + min(xcd, r) + local;
+    const int per_group = GM * tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_group = pid - group * per_group;
+    tm = first_m + in_group % gsz;
+    tn = in_group / gsz;
+}
+
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Fragment reads are inline asm: a compiler-visible ds_read behind an LDS-DMA makes hipcc wait for vmcnt(0) -- for the
+// youngest DMA -- before it (it cannot tell the ring's stages apart), which would serialise the ring.  The asm reads
+// return asynchronously; lds_wait<N> waits until at most N of them are outstanding and lists the registers that are valid
+// from then on as in/out operands, so no consumer can be scheduled ahead of it.
+template <int OFF> __device__ inline void lds_read(f32x4 &dst, uint32_t addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> __device__ inline void lds_wait(f32x4 &a, f32x4 &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N) : "memory");
+}
+template <int N> __device__ inline void lds_wait(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e)
+{
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : [n] "n"(N) : "memory");
+}
+template <int N> __device__ inline void lds_wait(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f, f32x4 &g, f32x4 &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : [n] "n"(N) : "memory");
+}
+
+template <int N> __device__ inline void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BM x BN output tile, WM x WN wavefronts of (BM/WM) x (BN/WN) sub-tiles, NST LDS stages
+template <int ACT, int BM, int BN, int WM, int WN, int NST, int OCC>
+__global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *__restrict__ x, const uint4 *__restrict__ wp,
+                                                                   const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                   float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; it has no amdgcn builtins / asm constraints)
+    constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
+    constexpr int A_BYTES = BM * 64, B_BYTES = BN * 96, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_CH = BM / 16, B_CH = 6 * (BN / 64), CH = A_CH + B_CH, CPW = (CH + NW - 1) / NW;   // 1 KiB DMA chunks per stage, per wave
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && RM >= 1 && (RN == 1 || RN == 2), "tile shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KG = K >> 3, NB = (N + 63) >> 6;
+    const int nk = K / BK;
+
+    // this wave's DMA chunks.  MUBUF (`buffer_load_dwordx4 ... lds`) rather than `global_load_lds`: the compiler keeps counted
+    // vmcnt waits for buffer loads, while a pending FLAT-encoded LDS access turns every later wait into vmcnt(0).  Buffer
+    // bases are the tile's first row / first 64-row weight block, so the 32-bit offsets stay far below 4 GiB for any tensor.
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (int64_t)m0 * K), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(wp + (int64_t)(n0 >> 6) * KG * 3 * 64), 0, 0x7fffffff, 0x00020000);
+    int voff[CPW], dst[CPW];      // per-lane byte offset of slab 0 inside the buffer; LDS offset inside a stage (wave-uniform)
+    bool is_a[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = min(wave + i * NW, CH - 1);                     // (a surplus chunk repeats the last one: same bytes, same place)
+        is_a[i] = c < A_CH;
+        if (c < A_CH) {
+            const int row = c * 16 + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+            voff[i] = min(row, M - 1 - m0) * K * 4 + q * 16;          // rows past M: the last row again (never stored)
+            dst[i] = c * 1024;
+        } else {
+            const int cb = c - A_CH, nbl = cb / 6, kg = (cb % 6) / 3, p = cb % 3;
+            const int nb = min(nbl, NB - 1 - (n0 >> 6));
+            voff[i] = ((nb * KG + kg) * 3 + p) * 1024 + lane * 16;
+            dst[i] = A_BYTES + ((kg * 3 + p) * BN + nbl * 64) * 16;
+        }
+    }
+    auto issue = [&](int s, unsigned char *stage) {   // DMA slab min(s, nk-1) (past the end: the last slab again, into a stage nobody reads)
+        const int ks = min(s, nk - 1);
+        const int so_a = ks * (BK * 4), so_b = ks * (2 * 3 * 1024);
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(stage + dst[i]), 16, voff[i], so_a, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lptr_t)(stage + dst[i]), 16, voff[i], so_b, 0, 0);
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x16{0};
+
+    // fragment addresses inside a stage (LDS byte addresses: the fragment reads are inline asm, see lds_read)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    uint32_t a_off[RM][2];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+        const int row = wm * (BM / WM) + 32 * i + col, g = (row >> 2) & 3;
+        a_off[i][0] = lds0 + row * 64 + (((2 * half) ^ g) << 4);
+        a_off[i][1] = lds0 + row * 64 + (((2 * half + 1) ^ g) << 4);
+    }
+    const uint32_t b_off = lds0 + A_BYTES + ((half * 3) * BN + wn * (BN / WN) + col) * 16;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(s, smem + s * ST_BYTES);
+
+    int cur = 0;                                  // stage of slab s
+    for (int s = 0; s < nk; ++s) {
+        const int refill = cur == 0 ? NST - 1 : cur - 1;     // the stage slab s-1 occupied
+        wait_vmcnt<CPW * (NST - 2)>();          // this wave's chunks of slab s have landed (NST-2 younger slabs stay in flight)
+        asm volatile("s_barrier" ::: "memory");  // ... and everybody's; everybody is also done reading slab s-1
+        issue(s + NST - 1, smem + refill * ST_BYTES);
+        const uint32_t so = cur * ST_BYTES;
+        f32x4 fb[RN][3], lo[2], hi[2];
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) lds_read<0>(fb[j][p], b_off + so + (p * BN + 32 * j) * 16);
+        lds_read<0>(lo[0], a_off[0][0] + so);
+        lds_read<0>(hi[0], a_off[0][1] + so);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            if (i + 1 < RM) {
+                lds_read<0>(lo[(i + 1) & 1], a_off[i + 1][0] + so);
+                lds_read<0>(hi[(i + 1) & 1], a_off[i + 1][1] + so);
+            }
+            // everything but the two reads just issued has arrived; the operand list ties the consumers to this wait
+            if (i == 0) {
+                if constexpr (RN == 2) lds_wait<(RM > 1) ? 2 : 0>(fb[0][0], fb[0][1], fb[0][2], fb[1][0], fb[1][1], fb[1][2], lo[0], hi[0]);
+                else lds_wait<(RM > 1) ? 2 : 0>(fb[0][0], fb[0][1], fb[0][2], lo[0], hi[0]);
+            } else if (i + 1 < RM) lds_wait<2>(lo[i & 1], hi[i & 1]);
+            else lds_wait<0>(lo[i & 1], hi[i & 1]);
+            bf16x8 fa0, fa1, fa2;
+            split8(lo[i & 1], hi[i & 1], fa0, fa1, fa2);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {      // smallest partial products first
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b0, c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    wait_vmcnt<0>();   // the surplus DMAs of the last slabs must not outlive the workgroup's LDS allocation
+
+    // acc[i][j]: lane column n = n0 + wn*(BN/WN) + 32 j + col ; register r = row m0 + wm*(BM/WM) + 32 i + (r&3) + 8 (r>>2) + 4 half
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + wn * (BN / WN) + 32 * j + col;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const int64_t o = (int64_t)m * N + n;
+                float t = acc[i][j][r] + bv;
+                if (pre) pre[o] = t;
+                if (ACT == 1) t = gelu_exact(t);
+                if (residual) t += residual[o];
+                out[o] = t;
+            }
+        }
+    }
+#endif
+}
+
+template <int OFF> __device__ inline void lds_write(uint32_t addr, const bf16x8 &v)
+{
+    asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int N> __device__ inline void lds_wait(f32x4 &a, f32x4 &b, f32x4 &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c) : [n] "n"(N) : "memory");
+}
+template <int N> __device__ inline void lds_wait(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d, f32x4 &e, f32x4 &f, f32x4 &g, f32x4 &h, f32x4 &i)
+{
+    asm volatile("s_waitcnt lgkmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i) : [n] "n"(N) : "memory");
+}
+
+__device__ inline void lds_wait_all(f32x4 (&b)[2][3], f32x4 (&a)[4][3])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(a[0][0]), "+v"(a[0][1]),
+                   "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[3][0]),
+                   "+v"(a[3][1]), "+v"(a[3][2])
+                 :
+                 : "memory");
+}
+
+// Variant that splits every activation ONCE per workgroup: the fp32 slab arrives by DMA (raw image), each wave converts its
+// 32-row share into the three bf16 planes of a second image one slab ahead of the MFMAs, and all fragment reads are plane
+// reads (A like B).  Per wave and slab: 2 + 3*(RM+RN) 16-byte LDS reads, 3 writes, one split8 -- instead of RM split8's.
+// LDS: raw A x2, B x2, converted A x2; every DMA is issued one whole slab before its consumer, so the top-of-slab wait is
+// a plain vmcnt(0) with nothing young in flight.
+template <int ACT, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__restrict__ x, const uint4 *__restrict__ wp,
+                                                                 const float *__restrict__ bias, const float *__restrict__ residual,
+                                                                 float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
+    constexpr int RAW_BYTES = BM * 64, B_BYTES = BN * 96, AC_BYTES = BM * 96;
+    constexpr int RAW0 = 0, B0 = 2 * RAW_BYTES, AC0 = B0 + 2 * B_BYTES, LDS_BYTES = AC0 + 2 * AC_BYTES;
+    constexpr int A_CH = BM / 16, B_CH = 6 * (BN / 64), CH = A_CH + B_CH, CPW = (CH + NW - 1) / NW;
+    static_assert(BM == 32 * NW, "every wave converts 32 rows of the slab");
+    static_assert(RN == 2 && RM == 4, "tile shape");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int KG = K >> 3, NB = (N + 63) >> 6;
+    const int nk = K / BK;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (int64_t)m0 * K), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(wp + (int64_t)(n0 >> 6) * KG * 3 * 64), 0, 0x7fffffff, 0x00020000);
+    int voff[CPW], dst[CPW];
+    bool is_a[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = min(wave + i * NW, CH - 1);
+        is_a[i] = c < A_CH;
+        if (c < A_CH) {
+            const int row = c * 16 + (lane >> 2), q = (lane & 3) ^ ((row >> 2) & 3);
+            voff[i] = min(row, M - 1 - m0) * K * 4 + q * 16;
+            dst[i] = c * 1024;
+        } else {
+            const int cb = c - A_CH, nbl = cb / 6, kg = (cb % 6) / 3, p = cb % 3;
+            const int nb = min(nbl, NB - 1 - (n0 >> 6));
+            voff[i] = ((nb * KG + kg) * 3 + p) * 1024 + lane * 16;
+            dst[i] = ((kg * 3 + p) * BN + nbl * 64) * 16;
+        }
+    }
+    // raw A slab sa -> raw[sa & 1], B slab sb -> B[sb & 1] (past the end: the last slab again, never consumed)
+    auto issue = [&](int sa, int sb) {
+        const int so_a = min(sa, nk - 1) * (BK * 4), so_b = min(sb, nk - 1) * (2 * 3 * 1024);
+        unsigned char *ra = smem + RAW0 + (sa & 1) * RAW_BYTES, *rb = smem + B0 + (sb & 1) * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(ra + dst[i]), 16, voff[i], so_a, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lptr_t)(rb + dst[i]), 16, voff[i], so_b, 0, 0);
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x16{0};
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    // converter: lane -> (row 32 wave + col, k group half) of the raw image; its three pieces go to the planes
+    const int crow = 32 * wave + col, cg = (crow >> 2) & 3;
+    const uint32_t c_rd0 = lds0 + RAW0 + crow * 64 + (((2 * half) ^ cg) << 4), c_rd1 = lds0 + RAW0 + crow * 64 + (((2 * half + 1) ^ cg) << 4);
+    const uint32_t c_wr = lds0 + AC0 + ((half * 3) * BM + crow) * 16;
+    // fragments: planes [k group][piece][row][16 B]
+    const uint32_t a_rd = lds0 + AC0 + ((half * 3) * BM + wm * (BM / WM) + col) * 16;
+    const uint32_t b_rd = lds0 + B0 + ((half * 3) * BN + wn * (BN / WN) + col) * 16;
+
+    auto convert = [&](int s_, f32x4 &lo, f32x4 &hi) {   // (lo, hi already waited for) -> planes of Ac[s_ & 1]
+        bf16x8 f0, f1, f2;
+        split8(lo, hi, f0, f1, f2);
+        const uint32_t w = c_wr + (s_ & 1) * AC_BYTES;
+        lds_write<0>(w, f0); lds_write<BM * 16>(w, f1); lds_write<2 * BM * 16>(w, f2);
+    };
+
+    // prologue: A(0), B(0), A(1) in flight; convert A(0)
+    issue(0, 0);
+    issue(1, 0);                                 // (B(0) twice: same bytes, same place -- keeps issue() uniform)
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    {
+        f32x4 lo, hi;
+        lds_read<0>(lo, c_rd0); lds_read<0>(hi, c_rd1);
+        lds_wait<0>(lo, hi);
+        convert(0, lo, hi);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    f32x4 fb[RN][3], fa[RM][3];
+    // R(s): this wave's share of the conversion of slab s+1, and ALL its fragments of slab s into registers
+    auto load_phase = [&](int s) {
+        const uint32_t ao = a_rd + (s & 1) * AC_BYTES, bo = b_rd + (s & 1) * B_BYTES, ro = ((s + 1) & 1) * RAW_BYTES;
+        f32x4 clo, chi;
+        lds_read<0>(clo, c_rd0 + ro); lds_read<0>(chi, c_rd1 + ro);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            lds_read<0>(fb[j][0], bo + j * 512); lds_read<BN * 16>(fb[j][1], bo + j * 512); lds_read<2 * BN * 16>(fb[j][2], bo + j * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lds_read<0>(fa[i][0], ao + i * 512); lds_read<BM * 16>(fa[i][1], ao + i * 512); lds_read<2 * BM * 16>(fa[i][2], ao + i * 512);
+        }
+        lds_wait<12>(clo, chi);                   // 14 reads outstanding (the counter holds 15): the two oldest have arrived
+        convert(s + 1, clo, chi);
+#pragma unroll
+        for (int i = 2; i < RM; ++i) {
+            lds_read<0>(fa[i][0], ao + i * 512); lds_read<BM * 16>(fa[i][1], ao + i * 512); lds_read<2 * BM * 16>(fa[i][2], ao + i * 512);
+        }
+        lds_wait_all(fb, fa);
+    };
+    auto mfma_phase = [&]() {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]), a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        }
+    };
+
+    // The two waves that share a SIMD (w and w + 4) belong to the two row halves of the tile.  The first half runs
+    // load -> MFMA inside a slab interval, the second half MFMA (of the previous slab, from registers) -> load: one wave's
+    // matrix phase covers the other's LDS / conversion phase instead of both idling the matrix pipe at the same time.
+    if (wave < NW / 2) {
+        for (int s = 0; s < nk; ++s) {
+            wait_vmcnt<0>();                          // issued a whole slab ago: raw A(s+1), B(s)
+            asm volatile("s_barrier" ::: "memory");   // everybody's DMAs and conversions of the previous slab are visible; its reads are done
+            issue(s + 2, s + 1);
+            load_phase(s);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_phase();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        for (int s = 0; s < nk; ++s) {
+            wait_vmcnt<0>();
+            asm volatile("s_barrier" ::: "memory");
+            issue(s + 2, s + 1);
+            if (s > 0) mfma_phase();
+            __builtin_amdgcn_sched_barrier(0);
+            load_phase(s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_phase();
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + wn * (BN / WN) + 32 * j + col;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= M) continue;
+                const int64_t o = (int64_t)m * N + n;
+                float t = acc[i][j][r] + bv;
+                if (pre) pre[o] = t;
+                if (ACT == 1) t = gelu_exact(t);
+                if (residual) t += residual[o];
+                out[o] = t;
+            }
+        }
+    }
+#endif
+}
+
+// w (R, C) row-major fp32 -> block layout packed[r / 64][c / 8][piece][r % 64][8] bf16, rows padded with zeros to a
+// multiple of 64.  transpose = 1 packs w^T (output row = column of w, k = row of w).
+__global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w, uint4 *__restrict__ packed, int rows, int cols,
+                                                     int transpose)
+{
+    // output rows R_ = transpose ? cols : rows, contraction length K_ = transpose ? rows : cols
+    const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols, KG = K_ >> 3;
+    __shared__ float s[64][65];                       // [output row][k]: 64 rows x 64 k (8 k groups)
+    const int rb = blockIdx.y, k0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int r, k;
+        if (transpose) { k = i >> 6; r = i & 63; } else { r = i >> 6; k = i & 63; }      // coalesced along the source's fast axis
+        const int R = rb * 64 + r, Kx = k0 + k;
+        float v = 0.f;
+        if (R < R_ && Kx < K_) v = transpose ? w[(int64_t)Kx * cols + R] : w[(int64_t)R * cols + Kx];
+        s[r][k] = v;
+    }
+    __syncthreads();
+    // thread -> (k group of the 64-wide slice, output row): consecutive threads = consecutive rows of one plane
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+        const int kg = i >> 6, r = i & 63;
+        if (k0 + kg * 8 >= K_) continue;
+        const float4 lo = make_float4(s[r][kg * 8 + 0], s[r][kg * 8 + 1], s[r][kg * 8 + 2], s[r][kg * 8 + 3]);
+        const float4 hi = make_float4(s[r][kg * 8 + 4], s[r][kg * 8 + 5], s[r][kg * 8 + 6], s[r][kg * 8 + 7]);
+        bf16x8 f0, f1, f2;
+        split8(lo, hi, f0, f1, f2);
+        uint4 *o = packed + (((int64_t)rb * KG + (k0 >> 3) + kg) * 3) * 64 + r;
+        o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); o[128] = __builtin_bit_cast(uint4, f2);
+    }
+}
+}  // namespace x6r
+
+int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream)
+{
+    if (!w || !packed || rows <= 0 || cols <= 0) return VIT_EINVAL;
+    const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols;
+    if (K_ % 8 != 0) return VIT_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(x6r::k_split_block, dim3((K_ + 63) / 64, (R_ + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed),
+                       rows, cols, transpose);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+// cfg: 1 = ring kernel, 128 x 128 tiles, 3 stages, two workgroups per CU; 2 = ring kernel, 256 x 256 tiles (8 waves);
+// 3 = convert-once ping-pong kernel, 256 x 256 tiles.  (tools/probes/gemm_lab.py sweeps them against vit_linear_x6_fwd.)
+int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
+                   int K, int act, int cfg, hipStream_t stream)
+{
+    if (!x || !wp || !out) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || cfg < 1 || cfg > 3) return VIT_EINVAL;
+    const uint4 *w4 = static_cast<const uint4 *>(wp);
+    (void)hipGetLastError();
+#define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
+    if (cfg == 1) {
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+    } else if (cfg == 2) {
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
+        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
+    } else {
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
+    }
+#undef X6R_ARGS
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+}  // namespace vit

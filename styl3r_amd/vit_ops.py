@@ -30,9 +30,9 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_linear_x6_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -99,6 +99,12 @@ def load() -> C.CDLL:
     lib.vit_split_weight_bytes.restype = C.c_size_t
     lib.vit_split_weight.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight.restype = C.c_int
+    lib.vit_split_weight_block_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vit_split_weight_block_bytes.restype = C.c_size_t
+    lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_split_weight_block.restype = C.c_int
+    lib.vit_linear_x6r_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_x6r_fwd.restype = C.c_int
     lib.vit_linear_x6_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_fwd.restype = C.c_int
     lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -298,6 +304,33 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
 LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")
 
 _SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
+
+
+def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
+    """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
+    multiple of 64 with zeros).  Not cached: the ring kernels are experimental and off the default path."""
+    lib = load()
+    N, K = weight.shape
+    w = weight.detach().contiguous().float()
+    packed = torch.empty(lib.vit_split_weight_block_bytes(N, K, 1 if transposed else 0), dtype=torch.uint8, device=weight.device)
+    _check(lib.vit_split_weight_block(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
+           "vit_split_weight_block")
+    return packed
+
+
+def linear_x6r(x: Tensor, packed_block: Tensor, N: int, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+               gelu: bool = False, cfg: int = 3) -> Tensor:
+    """out = [residual +] act(x . W^T + bias) on the LDS-DMA ring kernels (vit_linear_x6r_fwd; forward only, experimental).
+    `packed_block` = split_weight_block(W) (or of W^T's transposed packing for a dX product), N = its output width."""
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K).contiguous().float()
+    M = x2.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    res = residual.reshape(M, N).contiguous().float() if residual is not None else None
+    _check(load().vit_linear_x6r_fwd(x2.data_ptr(), packed_block.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     res.data_ptr() if res is not None else None, out.data_ptr(), None, M, N, K, 1 if gelu else 0,
+                                     cfg, _stream(x.device)), "vit_linear_x6r_fwd")
+    return out.reshape(*x.shape[:-1], N)
 
 
 def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:

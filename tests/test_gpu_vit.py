@@ -230,6 +230,41 @@ def test_bf16x6_linear_matches_fp64_like_the_f32_mfma_path(M, N, K, gelu, monkey
         assert errs["bf16x6"][k] <= 3.0 * errs["f32"][k] + 2e-7, errs
 
 
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K,gelu,res", [(1028, 3072, 1024, False, False), (600, 200, 48, True, False), (2000, 1024, 2048, False, True), (77, 40, 16, False, True)])
+def test_ring_dma_linear_kernels_equal_the_default_bf16x6_kernel(cfg, M, N, K, gelu, res):
+    """csrc/vit_gemm_x6r.hip (LDS-DMA ring, block-layout weight, inline-asm fragment reads with counted waits, ping-pong wave
+    pairs): same six partial products in the same order as vit_linear_x6_fwd, so the outputs agree to the last bit -- any race
+    between a DMA, a conversion and a fragment read shows up as a wrong tile; ragged M / N (row clamp, zero-padded weight
+    block), one- and many-slab K; repeated to catch an intermittent race.  (Shapes chosen so that the default path does not
+    take its split-K branch, whose atomics reorder the sum.)"""
+    from styl3r_amd import vit_ops
+    g = torch.Generator(DEV).manual_seed(M + 3 * N + cfg)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    r = torch.randn(M, N, device=DEV, generator=g) if res else None
+    vit_ops.LINEAR_MODE, keep = "bf16x6", vit_ops.LINEAR_MODE
+    try:
+        want = vit_ops.fused_linear(x, w, b, gelu=gelu, residual=r) if r is not None else vit_ops.fused_linear(x, w, b, gelu=gelu)
+    finally:
+        vit_ops.LINEAR_MODE = keep
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = torch.nn.functional.gelu(ref) if gelu else ref
+    ref = ref + r.double() if r is not None else ref
+    blk = vit_ops.split_weight_block(w)
+    for rep in range(5):
+        got = vit_ops.linear_x6r(x, blk, N, bias=b, residual=r, gelu=gelu, cfg=cfg)
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 4e-6
+        assert torch.equal(got, want), (rep, float((got - want).abs().max()))
+    # dX product through the transposed block packing: dX = dY . W
+    gy = torch.randn(M, N, device=DEV, generator=g)
+    if N % 16 == 0:
+        dx = vit_ops.linear_x6r(gy, vit_ops.split_weight_block(w, transposed=True), K, cfg=cfg)
+        dref = gy.double() @ w.double()
+        assert float((dx.double() - dref).abs().max() / dref.abs().max()) <= 4e-6
+
+
 def test_split_cache_never_serves_a_dead_tensors_entry():
     """a new weight that reuses a freed one's Python id / device address (version 0 again) must be split afresh"""
     from styl3r_amd.vit_ops import split_weight
