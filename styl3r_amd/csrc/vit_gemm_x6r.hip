@@ -3,15 +3,17 @@
 //     out (M,N) = [residual +] act( x (M,K) . w^T (N,K) + bias )
 //
 // EXPERIMENTAL: exported (vit_linear_x6r_fwd) and parity-tested, not on the default path of styl3r_amd/vit_ops.py.
-// Round 2's answer to "is vit_gemm_x6.hip's register-staged data path what holds it at ~40 % of the matrix peak?":
-// it is not.  Measured on the encoder's qkv Linear (5140 x 3072 x 1024, warm clocks, same run; DESIGN 9.2 has the table):
-//     vit_gemm_x6.hip, 128 x 128 tiles, registers -> split -> ds_write, 3 workgroups / CU        0.190 ms   170 TF
-//     k_linear_x6r, 128 x 128 ring, split at fragment read, 2 workgroups / CU                   0.187 ms   173 TF
-//     k_linear_x6r, 256 x 256 ring, 8 waves in lockstep                                         0.196 ms   165 TF
-//     k_linear_x6c, 256 x 256, split once per workgroup, the two waves of a SIMD in ping-pong   0.168 ms   192 TF
-// with the MFMA pipes 43 % busy in every variant that keeps its waves in lockstep (SQ_VALU_MFMA_BUSY_CYCLES), no LDS bank
-// conflicts, and 27 us of the launch being the 63 MB output store.  256 x 256 tiles quantise badly on everything but the
-// qkv / fc1 shapes (84 tiles for N = 1024), so the default path keeps the 128-wide kernel.
+// Round 2's answer to "is vit_gemm_x6.hip's register-staged data path what holds it at ~40 % of the matrix peak?"
+// Measured on the encoder's qkv Linear (5140 x 3072 x 1024, random operands, warm clocks, one run; profiles/r02s_gemm_lab.jsonl,
+// DESIGN 9.2 has every shape):
+//     vit_gemm_x6.hip, 128 x 128 tiles, registers -> split -> ds_write, 3 workgroups / CU          170 TF
+//     k_linear_x6r, 128 x 128 ring, split at fragment read, 2 workgroups / CU            (cfg 1)   177 TF
+//     k_linear_x6r, 256 x 256 ring, 8 waves in lockstep                                  (cfg 2)   185 TF
+//     k_linear_x6c, 256 x 256, split once per workgroup, wave pairs in ping-pong          (cfg 3)   206 TF   (280 TF on zero-filled operands)
+// The data path alone is worth +4 %; what moves the number is the ping-pong schedule: 3 460 cycles per 16-wide slab against
+// the 3 072 its 2 x 48 MFMAs per SIMD need (lockstep: 5 000).  At that point the kernel is limited by the power budget, not by
+// cycles: the same binary on zero-filled operands runs the same cycle counts at 2.3 GHz instead of 1.65 GHz.  256 x 256 tiles
+// quantise badly on everything but the qkv / fc1 shapes (84 tiles for N = 1024), so the default path keeps the 128-wide kernel.
 //
 // What this file does differently:
 //   * both operands reach LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no LDS store instructions;
@@ -288,7 +290,7 @@ __device__ inline void lds_wait_all(f32x4 (&b)[2][3], f32x4 (&a)[4][3])
 // reads (A like B).  Per wave and slab: 2 + 3*(RM+RN) 16-byte LDS reads, 3 writes, one split8 -- instead of RM split8's.
 // LDS: raw A x2, B x2, converted A x2; every DMA is issued one whole slab before its consumer, so the top-of-slab wait is
 // a plain vmcnt(0) with nothing young in flight.
-template <int ACT, int BM, int BN, int WM, int WN>
+template <int ACT, int BM, int BN, int WM, int WN, bool PROF = false>
 __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
                                                                  float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
     constexpr int RAW_BYTES = BM * 64, B_BYTES = BN * 96, AC_BYTES = BM * 96;
-    constexpr int RAW0 = 0, B0 = 2 * RAW_BYTES, AC0 = B0 + 2 * B_BYTES, LDS_BYTES = AC0 + 2 * AC_BYTES;
+    constexpr int RAW0 = 0, B0 = 3 * RAW_BYTES, AC0 = B0 + 2 * B_BYTES, LDS_BYTES = AC0 + 2 * AC_BYTES;   // raw ring of 3
     constexpr int A_CH = BM / 16, B_CH = 6 * (BN / 64), CH = A_CH + B_CH, CPW = (CH + NW - 1) / NW;
     static_assert(BM == 32 * NW, "every wave converts 32 rows of the slab");
     static_assert(RN == 2 && RM == 4, "tile shape");
@@ -334,9 +336,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         }
     }
     // raw A slab sa -> raw[sa & 1], B slab sb -> B[sb & 1] (past the end: the last slab again, never consumed)
-    auto issue = [&](int sa, int sb) {
+    auto issue = [&](int ring, int sa, int sb) {   // raw A slab sa -> raw[ring], B slab sb -> B[sb & 1]
         const int so_a = min(sa, nk - 1) * (BK * 4), so_b = min(sb, nk - 1) * (2 * 3 * 1024);
-        unsigned char *ra = smem + RAW0 + (sa & 1) * RAW_BYTES, *rb = smem + B0 + (sb & 1) * B_BYTES;
+        unsigned char *ra = smem + RAW0 + ring * RAW_BYTES, *rb = smem + B0 + (sb & 1) * B_BYTES;
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             if (is_a[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(ra + dst[i]), 16, voff[i], so_a, 0, 0);
@@ -366,84 +368,130 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         lds_write<0>(w, f0); lds_write<BM * 16>(w, f1); lds_write<2 * BM * 16>(w, f2);
     };
 
-    // prologue: A(0), B(0), A(1) in flight; convert A(0)
-    issue(0, 0);
-    issue(1, 0);                                 // (B(0) twice: same bytes, same place -- keeps issue() uniform)
+    // prologue: A(0), A(1), A(2), B(0) land; everybody converts its share of slab 0
+    issue(0, 0, 0);
+    issue(1, 1, 0);                              // (B(0) again: same bytes, same place -- keeps issue() uniform)
+    issue(2, 2, 0);
     wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
+    f32x4 fb[RN][3], fa[RM][3], clo, chi;
     {
         f32x4 lo, hi;
         lds_read<0>(lo, c_rd0); lds_read<0>(hi, c_rd1);
+        lds_read<0>(clo, c_rd0 + RAW_BYTES); lds_read<0>(chi, c_rd1 + RAW_BYTES);     // (second wave group: its share of slab 1)
         lds_wait<0>(lo, hi);
+        lds_wait<0>(clo, chi);
         convert(0, lo, hi);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    f32x4 fb[RN][3], fa[RM][3];
-    // R(s): this wave's share of the conversion of slab s+1, and ALL its fragments of slab s into registers
-    auto load_phase = [&](int s) {
-        const uint32_t ao = a_rd + (s & 1) * AC_BYTES, bo = b_rd + (s & 1) * B_BYTES, ro = ((s + 1) & 1) * RAW_BYTES;
-        f32x4 clo, chi;
-        lds_read<0>(clo, c_rd0 + ro); lds_read<0>(chi, c_rd1 + ro);
+    long long tw = 0, ti = 0, tl = 0, tc = 0, tp = PROF ? clock64() : 0;
+#define X6C_T(acc_) do { if (PROF) { const long long t_ = clock64(); acc_ += t_ - tp; tp = t_; } } while (0)
+    // all of this wave's fragments of slab s into registers (+ for the first wave group: its raw share of slab s+1)
+    auto load_phase = [&](int s, int raw_ring) {
+        const uint32_t ao = a_rd + (s & 1) * AC_BYTES, bo = b_rd + (s & 1) * B_BYTES;
+        lds_read<0>(clo, c_rd0 + raw_ring * RAW_BYTES); lds_read<0>(chi, c_rd1 + raw_ring * RAW_BYTES);
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             lds_read<0>(fb[j][0], bo + j * 512); lds_read<BN * 16>(fb[j][1], bo + j * 512); lds_read<2 * BN * 16>(fb[j][2], bo + j * 512);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            lds_read<0>(fa[i][0], ao + i * 512); lds_read<BM * 16>(fa[i][1], ao + i * 512); lds_read<2 * BM * 16>(fa[i][2], ao + i * 512);
-        }
-        lds_wait<12>(clo, chi);                   // 14 reads outstanding (the counter holds 15): the two oldest have arrived
-        convert(s + 1, clo, chi);
-#pragma unroll
-        for (int i = 2; i < RM; ++i) {
+        for (int i = 0; i < RM; ++i) {
             lds_read<0>(fa[i][0], ao + i * 512); lds_read<BM * 16>(fa[i][1], ao + i * 512); lds_read<2 * BM * 16>(fa[i][2], ao + i * 512);
         }
         lds_wait_all(fb, fa);
+        lds_wait<0>(clo, chi);
     };
-    auto mfma_phase = [&]() {
+    // 48 MFMAs on the fragments in registers, with the conversion of (clo, chi) -> Ac[s_conv & 1] riding in their issue gaps:
+    // a wave's own VALU work between its MFMAs is free (up to ~5 slots per 32-cycle MFMA), the same work issued by the
+    // SIMD's other wave while this one streams MFMAs gets about one slot per MFMA (measured: 44 instructions = 1 600 cycles)
+    auto mfma_phase = [&](int s_conv, bool do_mfma) {
+        uint4 q0, q1, q2;
+        uint32_t *p0 = reinterpret_cast<uint32_t *>(&q0), *p1 = reinterpret_cast<uint32_t *>(&q1), *p2 = reinterpret_cast<uint32_t *>(&q2);
+        if (do_mfma) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]), a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
+            for (int i = 0; i < RM; ++i) {
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]), a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
-                f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
-                acc[i][j] = c;
+                for (int j = 0; j < RN; ++j) {
+                    const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+                    acc[i][j] = c;
+                    const int blk = i * RN + j;
+                    if (blk >= 4) {               // one quarter of the split rides in this block's six MFMA gaps
+                        const float c0 = blk == 4 ? clo.x : blk == 5 ? clo.z : blk == 6 ? chi.x : chi.z, c1 = blk == 4 ? clo.y : blk == 5 ? clo.w : blk == 6 ? chi.y : chi.w;
+                        split2(c0, c1, p0[blk - 4], p1[blk - 4], p2[blk - 4]);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+        } else {
+            split2(clo.x, clo.y, p0[0], p1[0], p2[0]); split2(clo.z, clo.w, p0[1], p1[1], p2[1]);
+            split2(chi.x, chi.y, p0[2], p1[2], p2[2]); split2(chi.z, chi.w, p0[3], p1[3], p2[3]);
         }
+        const uint32_t w = c_wr + (s_conv & 1) * AC_BYTES;
+        lds_write<0>(w, __builtin_bit_cast(bf16x8, q0)); lds_write<BM * 16>(w, __builtin_bit_cast(bf16x8, q1));
+        lds_write<2 * BM * 16>(w, __builtin_bit_cast(bf16x8, q2));
     };
 
     // The two waves that share a SIMD (w and w + 4) belong to the two row halves of the tile.  The first half runs
     // load -> MFMA inside a slab interval, the second half MFMA (of the previous slab, from registers) -> load: one wave's
-    // matrix phase covers the other's LDS / conversion phase instead of both idling the matrix pipe at the same time.
+    // matrix phase covers the other's LDS phase instead of both idling the matrix pipe at the same time.
+    // ring position of raw slab s (s % 3), kept incrementally
+    int r0 = 0;
     if (wave < NW / 2) {
         for (int s = 0; s < nk; ++s) {
-            wait_vmcnt<0>();                          // issued a whole slab ago: raw A(s+1), B(s)
-            asm volatile("s_barrier" ::: "memory");   // everybody's DMAs and conversions of the previous slab are visible; its reads are done
-            issue(s + 2, s + 1);
-            load_phase(s);
+            const int r1 = r0 == 2 ? 0 : r0 + 1;
+            wait_vmcnt<0>();                          // issued a whole slab ago
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // conversions written; everybody's DMAs visible; previous reads done
+            X6C_T(tw);
+            issue(r0, s + 3, s + 1);
+            X6C_T(ti);
+            load_phase(s, r1);                        // fragments of slab s + this wave's raw share of slab s+1
             __builtin_amdgcn_sched_barrier(0);
-            mfma_phase();
+            X6C_T(tl);
+            mfma_phase(s + 1, true);                  // ... converted under the MFMAs of slab s
             __builtin_amdgcn_sched_barrier(0);
+            X6C_T(tc);
+            r0 = r1;
         }
     } else {
         for (int s = 0; s < nk; ++s) {
+            const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
             wait_vmcnt<0>();
-            asm volatile("s_barrier" ::: "memory");
-            issue(s + 2, s + 1);
-            if (s > 0) mfma_phase();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            X6C_T(tw);
+            __builtin_amdgcn_s_setprio(2);            // this group's MFMAs first; the other group is in its LDS phase
+            if (s > 0) mfma_phase(s + 1, true); else mfma_phase(s + 1, false);   // MFMAs of slab s-1 (registers); converts its share of slab s+1
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            load_phase(s);
+            X6C_T(tc);
+            issue(r0, s + 3, s + 1);                  // (half a slab after the first group's chunks: still most of a slab ahead of the wait)
+            X6C_T(ti);
+            load_phase(s, r2);                        // fragments of slab s + its raw share of slab s+2 (landed a slab ago)
             __builtin_amdgcn_sched_barrier(0);
+            X6C_T(tl);
+            r0 = r1;
         }
-        mfma_phase();
+        mfma_phase(nk + 1, true);                 // MFMAs of the last slab (its conversion lands in a stage nobody reads any more)
+    }
+#undef X6C_T
+    if (PROF) {
+        if (blockIdx.x == 8 && lane == 0) {
+            pre[wave * 4 + 0] = (float)tw / nk; pre[wave * 4 + 1] = (float)ti / nk; pre[wave * 4 + 2] = (float)tl / nk; pre[wave * 4 + 3] = (float)tc / nk;
+        }
+        pre = nullptr;
     }
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -522,7 +570,7 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
                    int K, int act, int cfg, hipStream_t stream)
 {
     if (!x || !wp || !out) return VIT_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || cfg < 1 || cfg > 3) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || cfg < 1 || cfg > 4) return VIT_EINVAL;
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
@@ -532,6 +580,8 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     } else if (cfg == 2) {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
+    } else if (cfg == 4) {
+        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512));
     } else {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bf16x6 Linear: the LDS-DMA ring kernel (vit_linear_x6r_fwd, every tile configuration) against the register-staged kernel
 (vit_linear_x6_fwd) -- error vs float64 and time per shape.  Prints one JSON line per (shape, kernel)."""
-import ctypes as C, json, sys
+import ctypes as C, json, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
@@ -27,7 +27,6 @@ shapes = dict(enc_qkv=(5140, 3072, 1024), enc_fc1=(5140, 4096, 1024), enc_fc2=(5
               dec_qkv=(5120, 2304, 768), dec_fc1=(5120, 3072, 768), dec_fc2=(5120, 768, 3072), dec_proj=(5120, 768, 768), odd=(1000, 200, 48))
 if len(sys.argv) > 2:
     shapes = {k: (shapes[k] if k in shapes else tuple(int(v) for v in k.split("x"))) for k in sys.argv[2].split(",")}
-import os
 ACT = int(os.environ.get("ACT", "0")); USE_RES = int(os.environ.get("RES", "1")); USE_PRE = int(os.environ.get("PRE", "0"))
 torch.manual_seed(0)
 _w = torch.randn(4096, 4096, device=dev)
@@ -35,6 +34,7 @@ for _ in range(200): _w @ _w          # clocks up before the first timing
 torch.cuda.synchronize()
 for name, (M, N, K) in shapes.items():
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; b = torch.randn(N, device=dev)
+    if int(os.environ.get("ZERO", "0")): x.zero_(); w.zero_()      # DVFS check: same instruction stream, no switching activity in the matrix pipes
     res = torch.randn(M, N, device=dev)
     ref = (x.double() @ w.double().t() + b.double())
     if ACT: ref = torch.nn.functional.gelu(ref)
@@ -61,4 +61,6 @@ for name, (M, N, K) in shapes.items():
             print(json.dumps(dict(shape=name, kernel=f"x6r cfg {cfg}", rc=rc, err=vit_ops.load().vit_last_error().decode()))); continue
         err = float((out.double() - ref).abs().max()) / scale
         ms = timeit(f)
+        if cfg == 4 and pre is not None:
+            print("phase cycles per slab (wave: barrier-wait, dma issue, lds phase, mfma phase):", [[round(v) for v in row] for row in pre.flatten()[:32].view(8, 4).tolist()])
         print(json.dumps(dict(shape=name, kernel=f"x6r cfg {cfg}", err=err, ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1))), flush=True)
