@@ -98,7 +98,8 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
  * The same Linear with an LDS-DMA operand ring (csrc/vit_gemm_x6r.hip).  Its weight operand is the BLOCK layout
  * packed[row / 64][k / 8][piece][row % 64][8] bf16 written by vit_split_weight_block (rows padded to a multiple of 64 with
  * zeros; vit_split_weight_block_bytes gives the size).  cfg: 1 = 128 x 128 ring, 2 = 256 x 256 ring, 3 = 256 x 256 with one
- * conversion per workgroup and ping-pong wave pairs; K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
+ * conversion per workgroup and ping-pong wave pairs, 32 + S = the same with an S-way K split (S = 2..8, fp32 atomics into the
+ * zeroed output, no activation / pre); K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
  * DESIGN.md 9.2, not used by the default path.
  */
 size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);

@@ -313,7 +313,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int KG = K >> 3, NB = (N + 63) >> 6;
-    const int nk = K / BK;
+    // gridDim.y > 1: this workgroup contracts slabs [k_lo, k_lo + nk) of the K / 16 and adds its partial tile into the zeroed
+    // `out` with fp32 atomics (bias / residual enter through split 0; no activation): N <= 1024 gives 84 tiles of 256 x 256 for
+    // 256 CUs, 84 x 3 fills them
+    const int nk_all = K / BK, S_ = gridDim.y, sp_ = blockIdx.y;
+    const int k_lo = sp_ * (nk_all / S_) + min(sp_, nk_all % S_), nk = nk_all / S_ + (sp_ < nk_all % S_ ? 1 : 0);
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (int64_t)m0 * K), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b =
@@ -337,7 +341,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     }
     // raw A slab sa -> raw[sa & 1], B slab sb -> B[sb & 1] (past the end: the last slab again, never consumed)
     auto issue = [&](int ring, int sa, int sb) {   // raw A slab sa -> raw[ring], B slab sb -> B[sb & 1]
-        const int so_a = min(sa, nk - 1) * (BK * 4), so_b = min(sb, nk - 1) * (2 * 3 * 1024);
+        const int so_a = (k_lo + min(sa, nk - 1)) * (BK * 4), so_b = (k_lo + min(sb, nk - 1)) * (2 * 3 * 1024);
         unsigned char *ra = smem + RAW0 + ring * RAW_BYTES, *rb = smem + B0 + (sb & 1) * B_BYTES;
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
@@ -500,7 +504,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     for (int j = 0; j < RN; ++j) {
         const int n = n0 + wn * (BN / WN) + 32 * j + col;
         if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const bool first = sp_ == 0;
+        const float bv = (bias && first) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
 #pragma unroll
@@ -509,6 +514,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
                 float t = acc[i][j][r] + bv;
+                if (S_ > 1) {
+                    if (residual && first) t += residual[o];
+                    atomicAdd(out + o, t);
+                    continue;
+                }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
@@ -570,7 +580,7 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
                    int K, int act, int cfg, hipStream_t stream)
 {
     if (!x || !wp || !out) return VIT_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || cfg < 1 || cfg > 4) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
@@ -582,6 +592,12 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
     } else if (cfg == 4) {
         hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512));
+    } else if (cfg >= 34) {
+        const int S = cfg - 32;
+        if (act || pre || K / x6r::BK < S) return VIT_EINVAL;
+        if (hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), dim3(((M + 255) / 256) * ((N + 255) / 256), S), dim3(512), 0, stream, x, w4, bias,
+                           residual, out, pre, M, N, K);
     } else {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
