@@ -289,7 +289,31 @@ def train_leg(args, rank, world, dev, dist):
            "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
     if not cpu:
         out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+        if not args.train_tiny:
+            out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
     return out
+
+
+def linear_roofline(dev, M):
+    """MFMA roofline of the step's dominant GEMM-shaped kernel, measured live: the encoder's qkv Linear (M tokens x 3072 x 1024) on
+    the bf16x6 kernel the step runs (six bf16 MFMAs per fp32 product: the nominal peak-equivalent is 2.5 PF / 6)."""
+    import torch
+    from styl3r_amd import vit_ops
+    N, K = 3072, 1024
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; bias = torch.randn(N, device=dev)
+    with torch.no_grad():
+        for _ in range(10):
+            vit_ops.fused_linear(x, w, bias)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            vit_ops.fused_linear(x, w, bias)
+        e1.record(); torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / 50
+    tf = 2.0 * M * N * K / ms / 1e9
+    return {"kernel": "vit::x6::k_linear_x6 (encoder qkv Linear)", "shape_MNK": [M, N, K], "ms": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s (fp32-accurate)",
+            "bound": "mfma", "peak": round(2500.0 / 6, 1), "frac": round(tf / (2500.0 / 6), 3), "mfma_TFLOPs_bf16": round(6 * tf, 1),
+            "note": "power-limited on random operands: DESIGN.md 9.2"}
 
 
 # ------------------------------------------------------------------ dry run (CPU launch-path test)
