@@ -291,6 +291,18 @@ def train_leg(args, rank, world, dev, dist):
         out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
         if not args.train_tiny:
             out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
+            # the same step with three partial products per GEMM launch instead of six (opt-in VIT_LINEAR_MODE=bf16x3: Gaussians within
+            # 1e-4 of the reference, ~3.5e-6 per GEMM) -- reported beside the headline mode, never instead of it
+            keep = vit_ops.LINEAR_MODE
+            try:
+                vit_ops.LINEAR_MODE = "bf16x3"
+                step(batch)
+                dt3 = dist_utils.timed_steps(lambda: step(batch), 2, sync, dist, dev)
+                out["bf16x3"] = {"ms_per_step": round(1e3 * dt3 / 2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, 2, world, dt3), 3),
+                                 "unit": "views/s", "steps": 2, "note": "opt-in arithmetic mode, not the headline"}
+            finally:
+                vit_ops.LINEAR_MODE = keep
+                vit_ops._x6()
     return out
 
 

@@ -93,6 +93,14 @@ int vit_linear_fwd(const float *x, const float *w, const float *bias, const floa
  * The contraction length must be a multiple of 16.
  */
 size_t vit_split_weight_bytes(int rows, int cols);
+/*
+ * Partial products per launch of every bf16x6 kernel below (Linear, weight gradient, convolutions): 6 = fp32 round-off accuracy
+ * (default); 3 = "bf16x3", a0 b0 + a0 b1 + a1 b0 only: ~3.5e-6 of the output scale per GEMM (two orders tighter than the TF32 the
+ * reference enables, croco.py:13) for half the MFMA work.  Process-wide, read when a kernel is launched.  Returns VIT_EINVAL for
+ * any other n.
+ */
+int vit_x6_set_products(int n);
+int vit_x6_products(void);
 int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
 /*
  * The same Linear with an LDS-DMA operand ring (csrc/vit_gemm_x6r.hip).  Its weight operand is the BLOCK layout

@@ -30,6 +30,8 @@ int adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_co
                 float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app, hipStream_t s);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
                     hipStream_t stream);
+int x6_set_products(int n);
+int x6_products();
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                    int K, int act, int cfg, hipStream_t stream);
@@ -80,6 +82,9 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
 {
     return vit::linear_x6_fwd(x, w_packed, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
+
+VIT_EXPORT int vit_x6_set_products(int n) { return vit::x6_set_products(n); }
+VIT_EXPORT int vit_x6_products(void) { return vit::x6_products(); }
 
 VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose)
 {

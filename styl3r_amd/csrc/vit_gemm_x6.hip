@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/vit_ops.h"
 
 namespace vit {
@@ -86,7 +88,7 @@ __device__ inline void split8(const float4 &lo, const float4 &hi, uint4 &q0, uin
 // SPLITK: gridDim.y workgroups share one output tile, each contracting its own range of K slabs and adding its partial
 // sums into a pre-zeroed `out` with fp32 atomics (bias / residual enter through split 0; no activation).  Used when the
 // tile count alone cannot fill the chip: the 257..514-row GEMMs of batch-1 inference give 48-160 tiles for 256 CUs.
-template <int ACT, int TN, bool SPLITK>
+template <int ACT, int TN, bool SPLITK, int NPROD>
 __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                       const float *__restrict__ bias, const float *__restrict__ residual,
                                                       float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
@@ -166,9 +168,11 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
@@ -242,6 +246,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
 // the register -> LDS step: a thread's eight m-values of one column are exactly one 8-wide k group of the operand.  The
 // output is small (N x K) and the contraction long (M = 4 000..5 000), so gridDim.y workgroups split M and add their
 // partial tiles with fp32 atomics into the zeroed dW; workgroups of the first K-tile also accumulate db.
+template <int NPROD>
 __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ x,
                                                      float *__restrict__ dw, float *__restrict__ dbias, int M, int N, int K,
                                                      int accumulate)
@@ -315,9 +320,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                }
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
@@ -378,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
 // pixel on the lane, so every accumulator register stores a coalesced run of one output channel.
 // Epilogue: + bias, + residual (the skip connection of a ResidualConvUnit), or -- `gate` -- the ReLU mask of the
 // backward pass; RELU_IN applies the unit's ReLU while the activations are staged (no separate ReLU pass / tensor).
-template <int KS, bool RELU_IN>
+template <int KS, bool RELU_IN, int NPROD>
 __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in, const uint4 *__restrict__ wp,
                                                     const float *__restrict__ bias, const float *__restrict__ residual,
                                                     float *__restrict__ out, int B, int Ci, int Co, int H, int W, int gate)
@@ -464,9 +471,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                }
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
@@ -527,7 +536,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
 // split the pixels and accumulate with fp32 atomics into the zeroed dw (and db from the row sums of dy).
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-byte load with 4-byte alignment (tap shift +-1)
 
-template <int KS, bool RELU_IN>
+template <int KS, bool RELU_IN, int NPROD>
 __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ in,
                                                           float *__restrict__ dw, float *__restrict__ dbias, int B, int Ci,
                                                           int Co, int H, int W)
@@ -620,9 +629,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
+                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                }
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
                 cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
@@ -707,6 +718,18 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
 }
 }  // namespace x6
 
+// Partial products per bf16x6 kernel launch: 6 (default, fp32 round-off accuracy) or 3 ("bf16x3": a0 b0 + a0 b1 + a1 b0, operands
+// good to 2^-18 -- ~3.5e-6 of the output scale per GEMM, two orders tighter than the TF32 the reference enables, croco.py:13).
+// Process-wide and read at launch time, so a step never mixes modes unless the caller changes it mid-step.
+static std::atomic<int> g_x6_products{6};
+int x6_set_products(int n)
+{
+    if (n != 3 && n != 6) return VIT_EINVAL;
+    g_x6_products.store(n, std::memory_order_relaxed);
+    return VIT_OK;
+}
+int x6_products() { return g_x6_products.load(std::memory_order_relaxed); }
+
 // number of contraction splits for the weight-gradient kernels (2 resident workgroups per CU): one full round of 512
 // workgroups when the tiles alone are fewer, otherwise whole multiples are left to the tile count; >= min_slabs per split
 static int split_count(int tiles, int nslab, int min_slabs)
@@ -751,6 +774,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     const bool narrow = tm * ((N + 127) / 128) < 640;
     const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
     const uint4 *w4 = static_cast<const uint4 *>(wp);
+    const bool three = x6_products() == 3;
     (void)hipGetLastError();
     // split-K when the tiles cannot fill the 256 CUs x 3 resident workgroups: S = 2 / 4 / 8 ranges of >= 8 slabs each
     int S = 1;
@@ -760,10 +784,16 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     }
     if (S > 1) {
         if (hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-        if (narrow) hipLaunchKernelGGL((x6::k_linear_x6<0, 1, true>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);
-        else hipLaunchKernelGGL((x6::k_linear_x6<0, 2, true>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);
+#define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
+        if (three) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
+        else { if (narrow) VIT_LAUNCH_X6S(1, 6); else VIT_LAUNCH_X6S(2, 6); }
+#undef VIT_LAUNCH_X6S
     } else {
-#define VIT_LAUNCH_X6(ACT, TN) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
+#define VIT_LAUNCH_X6(ACT, TN)                                                                                                                          \
+    do {                                                                                                                                                \
+        if (three) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 3>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K); \
+        else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);      \
+    } while (0)
         if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
         else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
 #undef VIT_LAUNCH_X6
@@ -788,7 +818,8 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
         if (S > 1 && hipMemsetAsync(dw, 0, ((size_t)N * K + (joined ? N : 0)) * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
         if (dbias && !(S > 1 && joined) && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     }
-    hipLaunchKernelGGL(x6::k_wgrad_x6, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
+    if (x6_products() == 3) hipLaunchKernelGGL(x6::k_wgrad_x6<3>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
+    else hipLaunchKernelGGL(x6::k_wgrad_x6<6>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
@@ -804,13 +835,18 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     const int64_t tiles = (int64_t)((Co + x6::BM - 1) / x6::BM) * ((NP + 127) / 128);
     if (tiles > 0x7fffffff) return VIT_EINVAL;
     const uint4 *w4 = static_cast<const uint4 *>(wp);
+    const bool three = x6_products() == 3;
     (void)hipGetLastError();
     // few output tiles: split the K slabs so that tiles x S fills the 512 resident workgroups, >= 8 slabs per split
     int S = 1;
     const int nslab = ksize * ksize * Ci / x6::BK;
     if (tiles < 256) { S = (int)(512 / tiles); while (S > 1 && nslab / S < 8) --S; if (S < 1) S = 1; if (S > 16) S = 16; }
     if (S > 1 && hipMemsetAsync(out, 0, (size_t)NP * Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-#define VIT_LAUNCH_C6(KS, RL) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate)
+#define VIT_LAUNCH_C6(KS, RL)                                                                                                                                   \
+    do {                                                                                                                                                        \
+        if (three) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 3>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate); \
+        else hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 6>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate);      \
+    } while (0)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
     else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
 #undef VIT_LAUNCH_C6
@@ -827,10 +863,15 @@ int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int
     const int tiles = ((Co + x6::BM - 1) / x6::BM) * ((R + 127) / 128);
     const int nslab = B * (H * W / x6::BK);
     int S = split_count(tiles, nslab, 32);
+    const bool three = x6_products() == 3;
     (void)hipGetLastError();
     if (hipMemsetAsync(dw, 0, (size_t)Co * R * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-#define VIT_LAUNCH_G6(KS, RL) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W)
+#define VIT_LAUNCH_G6(KS, RL)                                                                                                                          \
+    do {                                                                                                                                               \
+        if (three) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 3>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W);      \
+        else hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 6>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W);            \
+    } while (0)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_G6(3, true); else VIT_LAUNCH_G6(3, false); }
     else { if (relu_in) VIT_LAUNCH_G6(1, true); else VIT_LAUNCH_G6(1, false); }
 #undef VIT_LAUNCH_G6

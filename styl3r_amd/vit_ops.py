@@ -32,7 +32,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -99,6 +99,10 @@ def load() -> C.CDLL:
     lib.vit_split_weight_bytes.restype = C.c_size_t
     lib.vit_split_weight.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight.restype = C.c_int
+    lib.vit_x6_set_products.argtypes = [C.c_int]
+    lib.vit_x6_set_products.restype = C.c_int
+    lib.vit_x6_products.argtypes = []
+    lib.vit_x6_products.restype = C.c_int
     lib.vit_split_weight_block_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.vit_split_weight_block_bytes.restype = C.c_size_t
     lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -301,7 +305,21 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
 #            with fp32 accumulation (417 TF peak-equivalent); forward and input-gradient GEMMs.  Default: its measured
 #            error against fp64 is equal to or below the f32 path's on every shape tested (split error 2^-27, dropped
 #            cross terms 3 * 2^-26 relative), at 1.5-1.7x the throughput
-LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")
+LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")      # "bf16x6" (default) | "bf16x3" | "f32"
+
+
+def _x6() -> bool:
+    """True when the bf16 split-arithmetic kernels are selected; keeps the library's products-per-launch (6 / 3) in step with
+    LINEAR_MODE (a module global that tests and benchmarks flip at run time)."""
+    if LINEAR_MODE == "f32":
+        return False
+    if LINEAR_MODE not in ("bf16x6", "bf16x3"):
+        raise ValueError(f"VIT_LINEAR_MODE = {LINEAR_MODE!r}: expected bf16x6, bf16x3 or f32")
+    want = 3 if LINEAR_MODE == "bf16x3" else 6
+    lib = load()
+    if lib.vit_x6_products() != want:
+        _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
+    return True
 
 _SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
 
@@ -479,7 +497,7 @@ class Conv2dX6(nn.Conv2d):
 
     def _x6_ok(self, x: Tensor) -> bool:
         k = self.kernel_size[0]
-        return (LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        return (_x6() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
                 and self.kernel_size in ((1, 1), (3, 3)) and self.stride == (1, 1) and self.padding == (k // 2, k // 2)
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
                 and self.in_channels % 16 == 0 and self.out_channels >= _CONV_X6_MIN_ROWS
@@ -603,7 +621,7 @@ class _FusedLinear(torch.autograd.Function):
         pre = torch.empty_like(out) if need_pre else None
         res2 = residual.reshape(-1, N).contiguous().float() if residual is not None else None
         b = bias.contiguous().float() if bias is not None else None
-        x6 = LINEAR_MODE == "bf16x6"
+        x6 = _x6()
         w = weight.contiguous().float()
         args = (b.data_ptr() if b is not None else None, res2.data_ptr() if res2 is not None else None, out.data_ptr(),
                 pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
@@ -683,7 +701,7 @@ class _FusedLinear(torch.autograd.Function):
 def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
                  gelu: bool = False) -> Tensor:
     """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd)."""
-    if not torch.is_grad_enabled() and LINEAR_MODE == "bf16x6" and x.is_cuda and x.dtype == torch.float32:
+    if not torch.is_grad_enabled() and _x6() and x.is_cuda and x.dtype == torch.float32:
         # serving path: no autograd node, no saved tensors, straight to the kernel
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])

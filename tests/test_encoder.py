@@ -75,6 +75,29 @@ def _build_noposplat():
     return EncoderNoPoSplatMulti(EncoderNoPoSplatCfg(gaussian_adapter=GaussianAdapterCfg(0.5, 15.0, 1)), trunk_params=TINY).eval()
 
 
+@pytest.mark.gpu
+def test_encoder_forward_in_bf16x3_mode_stays_within_the_1e_4_bar(monkeypatch):
+    """VIT_LINEAR_MODE=bf16x3 (three partial products per GEMM launch): the Gaussians still match the reference fixture to the
+    north_star bar of 1e-4; what the mode gives up is gradient noise deep in the network (observed 5e-3 on the stylizer's projk
+    weight against 1e-4 .. 6e-4 in bf16x6 mode -- the same order as the reference's own fp32 run on the mid-size fixture), which is
+    why it is opt-in."""
+    from styl3r_amd import vit_ops
+    from tests.gpu_utils import assert_close_rel
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x3")
+    dev, tag = "cuda:0", "sh1"
+    m = deterministic_init_(_build(1)).to(dev)
+    T = lambda k: torch.tensor(G[f"{tag}_{k}"], device=dev)
+    with torch.no_grad():
+        gs = m(dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style")), global_step=0)
+    assert vit_ops.load().vit_x6_products() == 3
+    assert_close_rel(gs.means.cpu().numpy(), G[f"{tag}_means"], 1e-4, "means")
+    assert_close_rel(gs.covariances.cpu().numpy(), G[f"{tag}_cov"], 1e-4, "covariances")
+    assert_close_rel(gs.harmonics.cpu().numpy(), G[f"{tag}_sh"], 1e-4, "harmonics")
+    assert_close_rel(gs.opacities.cpu().numpy(), G[f"{tag}_opac"], 1e-4, "opacities")
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
+    assert vit_ops._x6() and vit_ops.load().vit_x6_products() == 6
+
+
 def test_noposplat_variant_keys_match_reference():
     m = _build_noposplat()
     assert sorted(m.state_dict().keys()) == list(G["np_keys"])

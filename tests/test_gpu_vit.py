@@ -230,6 +230,52 @@ def test_bf16x6_linear_matches_fp64_like_the_f32_mfma_path(M, N, K, gelu, monkey
         assert errs["bf16x6"][k] <= 3.0 * errs["f32"][k] + 2e-7, errs
 
 
+def test_bf16x3_mode_is_two_orders_tighter_than_tf32_on_every_split_arithmetic_kernel(monkeypatch):
+    """VIT_LINEAR_MODE=bf16x3 (three partial products per launch instead of six: include/vit_ops.h vit_x6_set_products): Linear
+    forward / dX / dW / db and the 3x3 convolution forward / dX / dW against float64.  Bars: 2e-5 of the output scale (measured
+    3.3e-6 .. 3.7e-6 per GEMM); TF32, which the reference enables for these products (croco.py:13), is ~3e-4.  The mode must not
+    leak: afterwards the default mode gives the six-product result again."""
+    from styl3r_amd import vit_ops
+    g = torch.Generator(DEV).manual_seed(5)
+    M, N, K = 1028, 768, 1024
+    x0 = torch.randn(M, K, device=DEV, generator=g); w0 = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b0 = torch.randn(N, device=DEV, generator=g); gy = torch.randn(M, N, device=DEV, generator=g)
+    xd, wd, bd = x0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    (torch.nn.functional.linear(xd, wd, bd) * gy.double()).sum().backward()
+    ref = torch.nn.functional.linear(xd, wd, bd).detach()
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    errs = {}
+    for mode in ("bf16x3", "bf16x6"):
+        monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+        x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True); b = b0.clone().requires_grad_(True)
+        y = vit_ops.fused_linear(x, w, b)
+        (y * gy).sum().backward()
+        errs[mode] = (rel(y.detach(), ref), rel(x.grad, xd.grad), rel(w.grad, wd.grad), rel(b.grad, bd.grad))
+        assert vit_ops.load().vit_x6_products() == (3 if mode == "bf16x3" else 6)
+    print("Linear (fwd, dX, dW, db) max-norm error vs fp64:", errs)
+    assert max(errs["bf16x3"]) <= 2e-5 and max(errs["bf16x6"]) <= 4e-6
+    assert errs["bf16x3"][0] > errs["bf16x6"][0]                      # the mode really changed the arithmetic
+    # convolution (the DPT heads' 3x3, large enough for the implicit-GEMM kernels)
+    B, Ci, Co, H, W = 4, 128, 128, 64, 64
+    cx0 = torch.randn(B, Ci, H, W, device=DEV, generator=g); conv = vit_ops.Conv2dX6(Ci, Co, 3, padding=1).to(DEV)
+    cg = torch.randn(B, Co, H, W, device=DEV, generator=g)
+    cxd = cx0.double().requires_grad_(True); cwd = conv.weight.detach().double().requires_grad_(True)
+    cref = torch.nn.functional.conv2d(cxd, cwd, conv.bias.detach().double(), padding=1)
+    (cref * cg.double()).sum().backward()
+    cerrs = {}
+    for mode in ("bf16x3", "bf16x6"):
+        monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+        conv.zero_grad()
+        cx = cx0.clone().requires_grad_(True)
+        before = vit_ops.CALLS["conv_x6_fwd"]
+        y = conv(cx)
+        assert vit_ops.CALLS["conv_x6_fwd"] == before + 1
+        (y * cg).sum().backward()
+        cerrs[mode] = (rel(y.detach(), cref.detach()), rel(cx.grad, cxd.grad), rel(conv.weight.grad, cwd.grad))
+    print("conv 3x3 (fwd, dX, dW) max-norm error vs fp64:", cerrs)
+    assert max(cerrs["bf16x3"]) <= 2e-5 and max(cerrs["bf16x6"]) <= 4e-6
+
+
 @pytest.mark.parametrize("cfg", [1, 2, 3])
 @pytest.mark.parametrize("M,N,K,gelu,res", [(1028, 3072, 1024, False, False), (600, 200, 48, True, False), (2000, 1024, 2048, False, True), (77, 40, 16, False, True)])
 def test_ring_dma_linear_kernels_equal_the_default_bf16x6_kernel(cfg, M, N, K, gelu, res):

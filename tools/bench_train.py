@@ -20,11 +20,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
+ap.add_argument("--linear-mode", choices=["bf16x6", "bf16x3", "f32"], default=None, help="arithmetic of the Linear / convolution kernels (default: VIT_LINEAR_MODE or bf16x6)")
 ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                 help="c3: NVS-pretrain, 2 ctx / 4 tgt views, MSE, everything trains.  c4: style stage, 4 ctx / 6 tgt views, "
                      "VGG style loss + identity pass (two encoder/decoder passes), backbone frozen (random-init VGG: no weights here).  "
                      "c5: stress shapes, 4 ctx views 512x512 -> 1 048 576 Gaussians/scene, sh_degree 4, 4 tgt views 512x512, MSE, all train")
 args = ap.parse_args()
+if args.linear_mode:
+    from styl3r_amd import vit_ops as _vo
+    _vo.LINEAR_MODE = args.linear_mode
 if args.torch_linear:
     from styl3r_amd import vit as _vit
     _vit.USE_FUSED_LINEAR = False
