@@ -63,6 +63,14 @@ typedef struct VitAttnArgs {
 
 int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,
                       void *stream);
+/*
+ * Arithmetic of vit_attention_fwd's two contractions: 1 (default) = bf16x6 split arithmetic on the bf16 MFMA
+ * (csrc/vit_attention_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernel's error against float64 -- and
+ * 1.15 - 1.4x faster), 0 = exact-f32 MFMA.  q / k strides that are not multiples of 4 floats always take the f32 kernel.
+ * Process-wide, read at launch time.  The backward (vit_attention_bwd) is exact-f32 in both modes.
+ */
+int vit_attention_set_arith(int mode);
+int vit_attention_arith(void);
 
 /*
  * Backward of vit_attention_fwd.  q/k/v as in the forward (same strides / RoPE arguments); out, dout,

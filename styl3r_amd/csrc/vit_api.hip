@@ -30,6 +30,8 @@ int adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_co
                 float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app, hipStream_t s);
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
                     hipStream_t stream);
+int attention_set_arith(int mode);
+int attention_arith();
 int x6_set_products(int n);
 int x6_products();
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
@@ -83,6 +85,8 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
     return vit::linear_x6_fwd(x, w_packed, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
 
+VIT_EXPORT int vit_attention_set_arith(int mode) { return vit::attention_set_arith(mode); }
+VIT_EXPORT int vit_attention_arith(void) { return vit::attention_arith(); }
 VIT_EXPORT int vit_x6_set_products(int n) { return vit::x6_set_products(n); }
 VIT_EXPORT int vit_x6_products(void) { return vit::x6_products(); }
 

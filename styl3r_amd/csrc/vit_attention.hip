@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/vit_ops.h"
 
 namespace vit {
@@ -214,6 +216,19 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
 }
 
 int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
+hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, dim3 grid,
+                                   hipStream_t stream);
+
+// 0: both contractions on the exact-f32 MFMA (this file); 1 (default): bf16x6 split arithmetic on the bf16 MFMA (vit_attention_x6.hip).
+// Process-wide like vit_x6_set_products, read at launch time.
+static std::atomic<int> g_attn_arith{1};
+int attention_set_arith(int mode)
+{
+    if (mode != 0 && mode != 1) return VIT_EINVAL;
+    g_attn_arith.store(mode, std::memory_order_relaxed);
+    return VIT_OK;
+}
+int attention_arith() { return g_attn_arith.load(std::memory_order_relaxed); }
 int attention_fwd_tail(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, int rows,
                        hipStream_t stream);
 
@@ -231,9 +246,15 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     const int tail_rows = attention_tail_rows(a.Nq, a.Nk, a.H * a.B);
     const dim3 grid((a.Nq - tail_rows + QB - 1) / QB, a.H, a.B);
     (void)hipGetLastError();
-    if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
-    else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
-    hipError_t e = hipGetLastError();
+    // the split-arithmetic kernel loads q / k rows as float4: strides in multiples of 4 floats, 16-byte aligned bases
+    const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb) & 3) && !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15);
+    hipError_t e;
+    if (attention_arith() == 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, stream);
+    else {
+        if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     if (tail_rows) return attention_fwd_tail(a, q, k, v, out, lse, tail_rows, stream);
     return VIT_OK;

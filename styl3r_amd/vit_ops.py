@@ -30,8 +30,8 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
-EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
+EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
            "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
@@ -99,6 +99,10 @@ def load() -> C.CDLL:
     lib.vit_split_weight_bytes.restype = C.c_size_t
     lib.vit_split_weight.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight.restype = C.c_int
+    lib.vit_attention_set_arith.argtypes = [C.c_int]
+    lib.vit_attention_set_arith.restype = C.c_int
+    lib.vit_attention_arith.argtypes = []
+    lib.vit_attention_arith.restype = C.c_int
     lib.vit_x6_set_products.argtypes = [C.c_int]
     lib.vit_x6_set_products.restype = C.c_int
     lib.vit_x6_products.argtypes = []
@@ -249,10 +253,23 @@ def _attn_args(q, k, v, out, scale, rope):
     return a, keep
 
 
+ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # forward contractions: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "f32" (exact-f32 MFMA)
+
+
+def _sync_attention_arith() -> None:
+    if ATTENTION_ARITH not in ("f32", "bf16x6"):
+        raise ValueError(f"VIT_ATTENTION = {ATTENTION_ARITH!r}: expected f32 or bf16x6")
+    want = 1 if ATTENTION_ARITH == "bf16x6" else 0
+    lib = load()
+    if lib.vit_attention_arith() != want:
+        _check(lib.vit_attention_set_arith(want), "vit_attention_set_arith")
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, qpos, kpos, base, max_pos):
         _need_gpu(q, "attention")
+        _sync_attention_arith()
         B, Nq, H, D = q.shape
         out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)

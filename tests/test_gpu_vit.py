@@ -49,8 +49,17 @@ def test_rope_kernel_matches_reference_golden_and_is_inplace_on_views():
     assert torch.equal(qkv[:, :, 1:], before[:, :, 1:])   # k, v untouched
 
 
+@pytest.fixture(params=["bf16x6", "f32"])
+def attention_arith(request, monkeypatch):
+    """both forward kernels: the bf16x6 split-arithmetic one (csrc/vit_attention_x6.hip, the default) and the exact-f32 MFMA one"""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", request.param)
+    yield request.param
+    assert vit_ops.load().vit_attention_arith() == (1 if request.param == "bf16x6" else 0)     # the launch really took that kernel
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1), (11, 16, 257, 257), (11, 16, 260, 129), (1, 1, 1025, 1025)])
-def test_attention_forward_vs_oracle(B, H, Nq, Nk):
+def test_attention_forward_vs_oracle(B, H, Nq, Nk, attention_arith):
     from styl3r_amd.vit_ops import memory_efficient_attention
     g = torch.Generator(DEV).manual_seed(Nq * 7 + Nk)
     q = torch.randn(B, Nq, H, 64, device=DEV, generator=g)
@@ -61,7 +70,7 @@ def test_attention_forward_vs_oracle(B, H, Nq, Nk):
     assert_close_rel(out.cpu().numpy(), ref, 1e-5, "attention fwd")
 
 
-def test_attention_forward_fused_rope_on_qkv_views():
+def test_attention_forward_fused_rope_on_qkv_views(attention_arith):
     from styl3r_amd.vit_ops import memory_efficient_attention
     B, N, H = 2, 257, 4
     g = torch.Generator(DEV).manual_seed(3)
