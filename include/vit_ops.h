@@ -64,10 +64,10 @@ typedef struct VitAttnArgs {
 int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,
                       void *stream);
 /*
- * Arithmetic of vit_attention_fwd's two contractions: 1 (default) = bf16x6 split arithmetic on the bf16 MFMA
- * (csrc/vit_attention_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernel's error against float64 -- and
- * 1.15 - 1.4x faster), 0 = exact-f32 MFMA.  q / k strides that are not multiples of 4 floats always take the f32 kernel.
- * Process-wide, read at launch time.  The backward (vit_attention_bwd) is exact-f32 in both modes.
+ * Arithmetic of the contractions of vit_attention_fwd and vit_attention_bwd: 1 (default) = bf16x6 split arithmetic on the bf16
+ * MFMA (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernels'
+ * error against float64 -- forward 1.3 - 1.6x, backward 1.3 - 1.55x faster), 0 = exact-f32 MFMA.  Strides that are not multiples
+ * of 4 floats (or bases that are not 16-byte aligned) always take the f32 kernels.  Process-wide, read at launch time.
  */
 int vit_attention_set_arith(int mode);
 int vit_attention_arith(void);

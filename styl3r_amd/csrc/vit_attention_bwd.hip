@@ -279,6 +279,9 @@ __global__ void __launch_bounds__(256, 3) k_attn_bwd_q(VitAttnArgs a, const floa
 }
 
 int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
+int attention_arith();
+hipError_t launch_attention_bwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *dout, const float *lse,
+                                   const float *delta, float *dq, float *dk, float *dv, dim3 gkv, dim3 gq, hipStream_t stream);
 int attention_bwd_tails(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *lse, const float *dout,
                         const float *delta, float *dq, float *dk, float *dv, int q_rows, int k_rows, hipStream_t stream);
 
@@ -296,14 +299,22 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     // almost empty workgroup per (batch, head) would open a second round on the chip (+63 % measured)
     const int q_tail = attention_tail_rows(a.Nq, a.Nk, a.H * a.B), k_tail = attention_tail_rows(a.Nk, a.Nq, a.H * a.B);
     const dim3 gkv((a.Nk - k_tail + 127) / 128, a.H, a.B), gq((a.Nq - q_tail + 127) / 128, a.H, a.B);
-    if (rope) {
-        hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
-        hipLaunchKernelGGL(k_attn_bwd_q<true>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+    // the split-arithmetic kernels (vit_attention_bwd_x6.hip) load rows as float4: strides in multiples of 4 floats, 16-byte aligned bases
+    const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb | a.v_sn | a.v_sh | a.v_sb) & 3) &&
+                       !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15);
+    hipError_t e;
+    if (attention_arith() == 1 && x6_ok) {
+        e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, stream);
     } else {
-        hipLaunchKernelGGL(k_attn_bwd_kv<false>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
-        hipLaunchKernelGGL(k_attn_bwd_q<false>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+        if (rope) {
+            hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
+            hipLaunchKernelGGL(k_attn_bwd_q<true>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+        } else {
+            hipLaunchKernelGGL(k_attn_bwd_kv<false>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
+            hipLaunchKernelGGL(k_attn_bwd_q<false>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+        }
+        e = hipGetLastError();
     }
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     if (q_tail || k_tail) return attention_bwd_tails(a, q, k, v, lse, dout, delta_ws, dq, dk, dv, q_tail, k_tail, stream);
     return VIT_OK;

@@ -30,7 +30,7 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
            "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
@@ -253,7 +253,7 @@ def _attn_args(q, k, v, out, scale, rope):
     return a, keep
 
 
-ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # forward contractions: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "f32" (exact-f32 MFMA)
+ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # attention contractions, forward and backward: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "f32" (exact-f32 MFMA)
 
 
 def _sync_attention_arith() -> None:
@@ -288,6 +288,7 @@ class _Attention(torch.autograd.Function):
         lib = load()
         if not hasattr(lib, "vit_attention_bwd"):
             raise RuntimeError("vit_attention_bwd is not built into libvit_hip.so")
+        _sync_attention_arith()
         g = g.contiguous()
         dq = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)

@@ -51,7 +51,8 @@ def test_rope_kernel_matches_reference_golden_and_is_inplace_on_views():
 
 @pytest.fixture(params=["bf16x6", "f32"])
 def attention_arith(request, monkeypatch):
-    """both forward kernels: the bf16x6 split-arithmetic one (csrc/vit_attention_x6.hip, the default) and the exact-f32 MFMA one"""
+    """both kernel families, forward and backward: bf16x6 split arithmetic (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; the
+    default) and exact-f32 MFMA (csrc/vit_attention.hip, vit_attention_bwd.hip)"""
     from styl3r_amd import vit_ops
     monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", request.param)
     yield request.param
@@ -87,7 +88,7 @@ def test_attention_forward_fused_rope_on_qkv_views(attention_arith):
 
 @pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, False), (1, 2, 130, 771, True), (1, 1, 5, 1, False), (2, 2, 33, 160, True),
                                              (11, 16, 257, 257, True), (11, 16, 259, 514, True), (1, 2, 256, 130, True)])   # 11 x 16 heads: the tail-row kernels kick in (they need > 512 workgroups)
-def test_attention_backward_vs_oracle(B, H, Nq, Nk, rope):
+def test_attention_backward_vs_oracle(B, H, Nq, Nk, rope, attention_arith):
     from styl3r_amd.vit_ops import memory_efficient_attention
     g = torch.Generator(DEV).manual_seed(Nq * 3 + Nk)
     q = torch.randn(B, Nq, H, 64, device=DEV, generator=g, requires_grad=True)

@@ -28,7 +28,7 @@ for name, (B, H, Nq, Nk, rope) in dict(enc_self=(20, 16, 257, 257, True), dec_cr
     kpos = pos[:Nk].expand(B, Nk, 2).contiguous() if rope else None
     kw = dict(qpos=qpos, kpos=kpos, max_pos=64) if rope else {}
     if rope:
-        def rot(x, p):        # float64 2-D RoPE: (d, d+16) of [0,32) by y, of [32,64) by x; table = the fp32 table the kernels read
+        def rot(x, p):               # float64 2-D RoPE: (d, d+16) of [0,32) by y, of [32,64) by x; table = the fp32 table the kernels read
             cos, sin = vit_ops.rope_tables(64, 65, 100.0, x.device)
             x = x.double(); o = x.clone()
             for base, ax in ((0, 0), (32, 1)):
@@ -47,4 +47,21 @@ for name, (B, H, Nq, Nk, rope) in dict(enc_self=(20, 16, 257, 257, True), dec_cr
             out = vit_ops.memory_efficient_attention(q, k, v, 0.125, **kw)
             err = float((out.double() - ref).abs().max() / ref.abs().max())
             ms = timeit(lambda: vit_ops.memory_efficient_attention(q, k, v, 0.125, **kw))
-        print(json.dumps(dict(shape=name, arith=arith, err=err, ms=round(ms, 4), TF=round(4 * B * H * Nq * Nk * 64 / ms / 1e9, 1))), flush=True)
+        # backward: gradients of sum(out * w) against float64 autograd of the same expression
+        if arith == "f32": gw = torch.randn_like(out)          # one cotangent per shape: the float64 gradients below are reused by the second kernel
+        q_, k_, v_ = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        o = vit_ops.memory_efficient_attention(q_, k_, v_, 0.125, **kw)
+        (o * gw).sum().backward()
+        if arith == "f32":
+            qd_, kd_, vd_ = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+            qr, kr = (rot(qd_, qpos), rot(kd_, kpos)) if rope else (qd_, kd_)
+            s_ = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * 0.125
+            (torch.einsum("bhqk,bkhd->bqhd", s_.softmax(-1), vd_) * gw.double()).sum().backward()
+            gref = (qd_.grad, kd_.grad, vd_.grad)
+        gerr = [float((a_.grad.double() - r_).abs().max() / r_.abs().max()) for a_, r_ in zip((q_, k_, v_), gref)]
+        def fb():
+            o = vit_ops.memory_efficient_attention(q_, k_, v_, 0.125, **kw)
+            torch.autograd.grad(o, (q_, k_, v_), gw)
+        msb = timeit(fb, iters=50) - ms
+        print(json.dumps(dict(shape=name, arith=arith, err=err, ms=round(ms, 4), TF=round(4 * B * H * Nq * Nk * 64 / ms / 1e9, 1), bwd_ms=round(msb, 4),
+                              grad_err=["%.1e" % e for e in gerr])), flush=True)
