@@ -5,9 +5,11 @@ Mirrors the reference operator interfaces:
     (in-place on the (B,H,N,D) view, backward = same kernel with -F0)                          -> vit_rope2d
   * `memory_efficient_attention(q, k, v, scale=, p=0)` on (B,N,H,64) fp32 tensors, blocks.py:129,195
                                                                                               -> vit_attention_fwd / _bwd
+    (bf16x6 split arithmetic on the bf16 MFMA by default, VIT_ATTENTION=f32: exact-f32 MFMA; fused RoPE in both)
   * `nn.Linear` (+ exact GELU, + residual add) of Mlp / Attention / Block, blocks.py:76-82,100,131,149-152
     -> `fused_linear`: vit_linear_x6_fwd (fp32-accurate bf16x6, default) or vit_linear_fwd (exact-f32 MFMA), dX on the
-       pre-split transposed weight, dW + db on vit_linear_x6_wgrad (accumulating into all-reduce bucket slices)
+       pre-split transposed weight, dW + db on vit_linear_x6_wgrad (accumulating into all-reduce bucket slices);
+       VIT_LINEAR_MODE=bf16x3: three instead of six partial products per launch (opt-in, ~4e-6 per GEMM)
   * `nn.LayerNorm(eps=1e-6)`, blocks.py:144-152,205-222                                        -> `LayerNorm` (vit_layernorm_*)
   * `nn.Conv2d` 3x3 / 1x1 stride 1 of the DPT heads and VGG, dpt_block.py:79-218,350-419      -> `Conv2dX6` (vit_conv_x6_*)
   * `F.interpolate(scale_factor=2, bilinear, align_corners=True)`                             -> `upsample2x`
