@@ -183,6 +183,14 @@ int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W
 int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream);
 
 /*
+ * ReLU followed by Dropout(p) of the 'gs_params' DPT heads (dpt_block.py:332-340) in one pass: y = keep ? max(x, 0) / (1 - p) : 0
+ * (y may alias x), keep drawn from Philox-4x32-10 keyed by (seed, element index / 4) -- no mask tensor; the backward reads y only:
+ * dx = y > 0 ? g / (1 - p) : 0 (dx may alias g).  n = number of floats, a multiple of 4; 0 <= p < 1.
+ */
+int vit_relu_dropout_fwd(const float *x, float *y, int64_t n, float p, uint64_t seed, void *stream);
+int vit_relu_dropout_bwd(const float *y, const float *g, float *dx, int64_t n, float p, void *stream);
+
+/*
  * Head tails + Gaussian adapter in one pass: reg_dense_depth(mode='exp') (postprocess.py:22-60),
  * sigmoid + map_pdf_to_opacity (encoder_noposplat_multi_token_style.py:115-128,205-209), UnifiedGaussianAdapter.forward
  * (gaussian_adapter.py:122-153) and build_covariance / quaternion_to_matrix (gaussians.py:8-44), from the DPT heads' NCHW

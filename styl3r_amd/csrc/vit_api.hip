@@ -19,6 +19,8 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
 int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
                   int relu_in, hipStream_t stream);
 int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hipStream_t stream);
+int relu_dropout_fwd(const float *x, float *y, int64_t n, float p, uint64_t seed, hipStream_t stream);
+int relu_dropout_bwd(const float *y, const float *g, float *dx, int64_t n, float p, hipStream_t stream);
 size_t layernorm_scratch_bytes(int M, int C);
 int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd, int M, int C,
                   float eps, hipStream_t stream);
@@ -143,6 +145,16 @@ VIT_EXPORT int vit_layernorm_bwd(const float *dy, const float *x, const float *m
 {
     return vit::layernorm_bwd(dy, x, mean, rstd, gamma, dskip, dx, dgamma, dbeta, static_cast<float *>(scratch), M, C, accumulate,
                               static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_relu_dropout_fwd(const float *x, float *y, int64_t n, float p, uint64_t seed, void *stream)
+{
+    return vit::relu_dropout_fwd(x, y, n, p, seed, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_relu_dropout_bwd(const float *y, const float *g, float *dx, int64_t n, float p, void *stream)
+{
+    return vit::relu_dropout_bwd(y, g, dx, n, p, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream)

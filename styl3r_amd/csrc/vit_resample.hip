@@ -122,4 +122,71 @@ int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hi
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
 }
+// ---- ReLU -> Dropout of the 'gs_params' DPT heads (dpt_block.py:332-340: ReLU(True), Dropout(0.1)) on their 256^2 x 256-channel
+// tensors (1.3 GB at 20 views) as ONE pass each way.  Forward: y = keep(i) ? max(x, 0) / (1 - p) : 0 with keep drawn by a
+// counter-based generator (Philox-4x32-10 keyed by (seed, element index / 4): no mask tensor is written); y > 0 exactly where
+// the gradient passes, so the backward needs y only: dx = y > 0 ? g / (1 - p) : 0.  The framework runs clamp + fused_dropout
+// forward and masked_scale + threshold_backward backward, two 2.7 GB passes each way plus the mask.
+__device__ inline uint4 philox4x32_10(uint4 ctr, uint2 key)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u; key.y += 0xBB67AE85u;
+    }
+    return ctr;
+}
+
+__global__ void __launch_bounds__(256) k_relu_dropout_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t n4, uint32_t thresh,
+                                                          float scale, uint64_t seed)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        float4 o;                                  // keep with probability 1 - p: a uniform 32-bit draw below thresh = (1 - p) 2^32
+        o.x = (r.x < thresh && v.x > 0.f) ? v.x * scale : 0.f;
+        o.y = (r.y < thresh && v.y > 0.f) ? v.y * scale : 0.f;
+        o.z = (r.z < thresh && v.z > 0.f) ? v.z * scale : 0.f;
+        o.w = (r.w < thresh && v.w > 0.f) ? v.w * scale : 0.f;
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_relu_dropout_bwd(const float *__restrict__ y, const float *__restrict__ g, float *__restrict__ dx,
+                                                          int64_t n4, float scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4 *>(y)[i], d = reinterpret_cast<const float4 *>(g)[i];
+        reinterpret_cast<float4 *>(dx)[i] = make_float4(a.x > 0.f ? d.x * scale : 0.f, a.y > 0.f ? d.y * scale : 0.f,
+                                                         a.z > 0.f ? d.z * scale : 0.f, a.w > 0.f ? d.w * scale : 0.f);
+    }
+}
+
+int relu_dropout_fwd(const float *x, float *y, int64_t n, float p, uint64_t seed, hipStream_t stream)
+{
+    if (!x || !y || n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f)) return VIT_EINVAL;
+    const double keep = 1.0 - (double)p;
+    const uint32_t thresh = keep >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(keep * 4294967296.0);
+    (void)hipGetLastError();
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(k_relu_dropout_fwd, dim3((unsigned)((n4 + 255) / 256 < 256 * 64 ? (n4 + 255) / 256 : 256 * 64)), dim3(256), 0, stream, x, y, n4, thresh,
+                       (float)(1.0 / keep), seed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int relu_dropout_bwd(const float *y, const float *g, float *dx, int64_t n, float p, hipStream_t stream)
+{
+    if (!y || !g || !dx || n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f)) return VIT_EINVAL;
+    (void)hipGetLastError();
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL(k_relu_dropout_bwd, dim3((unsigned)((n4 + 255) / 256 < 256 * 64 ? (n4 + 255) / 256 : 256 * 64)), dim3(256), 0, stream, y, g, dx, n4,
+                       (float)(1.0 / (1.0 - (double)p)));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
 }  // namespace vit

@@ -30,7 +30,7 @@ from torch import Tensor, nn
 
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
-from .vit_ops import Conv2dX6, upsample2x
+from .vit_ops import Conv2dX6, relu_dropout, upsample2x
 
 inf = float("inf")
 
@@ -398,7 +398,12 @@ class DPTAdapter(nn.Module):
             p1 = upsample2x(p1) + self.input_merger(imgs.contiguous())
         elif self.kind == "sh":
             p1 = upsample2x(p1)
-        return _PackGrad.apply(self.head(p1))
+        if self.kind == "pts3d":
+            return _PackGrad.apply(self.head(p1))
+        # 'gs_params' head: conv 3x3, ReLU(True) -> Dropout(0.1) in one pass each way (vit_ops.relu_dropout), conv 1x1; the modules stay in
+        # `self.head` for the state_dict keys (head.0 / head.4)
+        h = relu_dropout(self.head[0](p1), self.head[3].p, self.training)
+        return _PackGrad.apply(self.head[4](h))
 
 
 def reg_dense_depth_exp(xyz: Tensor) -> Tensor:

@@ -34,7 +34,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -125,6 +125,10 @@ def load() -> C.CDLL:
     lib.vit_conv_x6_fwd.restype = C.c_int
     lib.vit_conv_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_conv_x6_wgrad.restype = C.c_int
+    lib.vit_relu_dropout_fwd.argtypes = [vp, vp, C.c_int64, C.c_float, C.c_uint64, vp]
+    lib.vit_relu_dropout_fwd.restype = C.c_int
+    lib.vit_relu_dropout_bwd.argtypes = [vp, vp, vp, C.c_int64, C.c_float, vp]
+    lib.vit_relu_dropout_bwd.restype = C.c_int
     lib.vit_upsample2x_fwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
     lib.vit_upsample2x_fwd.restype = C.c_int
     lib.vit_upsample2x_bwd.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp]
@@ -561,6 +565,35 @@ def upsample2x(x: Tensor) -> Tensor:
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0:
         return _Upsample2x.apply(x)
     return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+
+
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _need_gpu(x, "relu_dropout")
+        ctx.mark_dirty(x)                        # in place, like the reference's ReLU(True): the convolution before it does not keep its output
+        _check(load().vit_relu_dropout_fwd(x.data_ptr(), x.data_ptr(), x.numel(), float(p), int(seed), _stream(x.device)), "vit_relu_dropout_fwd")
+        ctx.save_for_backward(x)
+        ctx.p = float(p)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(y)
+        _check(load().vit_relu_dropout_bwd(y.data_ptr(), g.data_ptr(), dx.data_ptr(), y.numel(), ctx.p, _stream(g.device)), "vit_relu_dropout_bwd")
+        return dx, None, None
+
+
+def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
+    """Dropout(p)(ReLU(x)) of the 'gs_params' DPT heads (dpt_block.py:332-340).  Training on a device fp32 tensor: one HIP pass each
+    way, in place, no mask tensor (vit_relu_dropout_fwd / _bwd; the keep decisions come from Philox keyed by a seed drawn from torch's
+    default CPU generator, so `torch.manual_seed` makes a run repeatable); otherwise the framework ops."""
+    if training and p > 0.0 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and not x.is_leaf:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return _ReluDropout.apply(x, p, seed)
+    return torch.nn.functional.dropout(torch.relu_(x) if not x.is_leaf else torch.relu(x), p, training)
 
 
 class _GaussianAdapterHip(torch.autograd.Function):

@@ -324,6 +324,41 @@ def test_ring_dma_linear_kernels_equal_the_default_bf16x6_kernel(cfg, M, N, K, g
         assert float((dx.double() - dref).abs().max() / dref.abs().max()) <= 4e-6
 
 
+def test_relu_dropout_kernel_is_relu_then_an_unbiased_dropout_and_its_backward_gates_by_the_output():
+    """vit_relu_dropout_fwd / _bwd (the 'gs_params' heads' ReLU(True) -> Dropout(0.1), dpt_block.py:332-340): every output is 0 or
+    max(x, 0) / (1 - p); the kept fraction of the positive inputs is 1 - p within 4 sigma and independent of the position; the same
+    seed repeats the mask, another seed does not; backward: g / (1 - p) exactly where the output is positive; eval mode / p = 0 is
+    plain ReLU."""
+    from styl3r_amd import vit_ops
+    torch.manual_seed(11)
+    x0 = torch.randn(3, 32, 64, 64, device=DEV)
+    p = 0.1
+    conv = lambda t: t * 1.0                                   # (a non-leaf, like the convolution output the heads hand over)
+    torch.manual_seed(5); x = conv(x0.clone().requires_grad_(True)); y = vit_ops.relu_dropout(x, p, True)
+    pos = x0 > 0
+    kept = y > 0
+    assert not bool((kept & ~pos).any())
+    assert torch.equal(y[kept], (x0[kept] / (1 - p)).float()) or float((y[kept] - x0[kept] / (1 - p)).abs().max()) <= 1e-6 * float(x0.abs().max())
+    n = int(pos.sum()); frac = float(kept.sum()) / n
+    assert abs(frac - (1 - p)) <= 4 * (p * (1 - p) / n) ** 0.5, frac
+    halves = [float((kept & pos)[..., :32].sum()) / float(pos[..., :32].sum()), float((kept & pos)[..., 32:].sum()) / float(pos[..., 32:].sum())]
+    assert abs(halves[0] - halves[1]) <= 0.01
+    torch.manual_seed(5); y2 = vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
+    assert torch.equal(y, y2)
+    y3 = vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
+    assert not torch.equal(y3 > 0, kept)
+    # backward
+    leaf = x0.clone().requires_grad_(True)
+    torch.manual_seed(5); out = vit_ops.relu_dropout(conv(leaf), p, True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    assert torch.equal(leaf.grad, torch.where(out.detach() > 0, g / (1 - p), torch.zeros_like(g)).float()) or \
+        float((leaf.grad - torch.where(out.detach() > 0, g / (1 - p), torch.zeros_like(g))).abs().max()) <= 1e-6 * float(g.abs().max())
+    # eval / p = 0
+    assert torch.equal(vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, False), torch.relu(x0))
+    assert torch.equal(vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), 0.0, True), torch.relu(x0))
+
+
 def test_split_cache_never_serves_a_dead_tensors_entry():
     """a new weight that reuses a freed one's Python id / device address (version 0 again) must be split afresh"""
     from styl3r_amd.vit_ops import split_weight
