@@ -27,6 +27,40 @@ import torch
 from torch import nn
 
 
+def broadcast_module_state(module: nn.Module, dist, src: int = 0, chunk_bytes: int = 64 << 20) -> int:
+    """Every rank starts from rank `src`'s parameters and buffers -- what torch DDP does when it wraps a module
+    (`_sync_module_states`; the reference gets it from Lightning's DDP strategy, src/main_style.py:104-108, whose per-rank seed only
+    differs for the data).  Tensors are packed per dtype into flat chunks of <= chunk_bytes, one broadcast each (a handful of large
+    collectives instead of ~1 000 small ones).  Returns the number of bytes sent; a no-op without a process group / at world size 1."""
+    if dist is None or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    groups: dict = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    sent = 0
+    for (dtype, dev), ts in groups.items():
+        chunk, nbytes = [], 0
+        def flush():
+            nonlocal chunk, nbytes, sent
+            if not chunk:
+                return
+            flat = torch.cat([t.reshape(-1) for t in chunk])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in chunk:
+                t.copy_(flat[off:off + t.numel()].view_as(t)); off += t.numel()
+            sent += flat.numel() * flat.element_size()
+            chunk, nbytes = [], 0
+        for t in ts:
+            nb = t.numel() * t.element_size()
+            if chunk and nbytes + nb > chunk_bytes:
+                flush()
+            chunk.append(t); nbytes += nb
+        flush()
+    return sent
+
+
 class BucketedGradReducer:
     def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20, inplace_grads: bool = True):
         self.dist = dist

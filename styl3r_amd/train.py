@@ -9,7 +9,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from .ddp import BucketedGradReducer
+from .ddp import BucketedGradReducer, broadcast_module_state
 from .losses import mse_loss
 
 
@@ -70,6 +70,8 @@ class TrainStep:
                  warm_up_steps: Optional[int] = None, max_steps: int = 100_000):
         self.encoder, self.decoder, self.clip = encoder, decoder, clip
         self.losses, self.identity_loss = (list(losses) if losses is not None else None), identity_loss
+        # identical replicas before anything else looks at the parameters (DDP semantics: rank 0's state wins)
+        self.synced_bytes = broadcast_module_state(encoder, dist)
         new, pre, self.frozen_names = select_trainable(encoder)
         self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier)
         self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None

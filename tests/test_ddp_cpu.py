@@ -58,6 +58,49 @@ def test_bucketed_reducer_two_ranks(tmp_path):
         assert sum(d["buckets"]) == 4 * (16 * 64 + 64 + 64 * 64 + 64 + 64 * 8 + 8 + 5)
 
 
+SYNC_WORKER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, %r)
+    import torch
+    from torch import nn
+    from styl3r_amd import dist_utils
+    from styl3r_amd.ddp import broadcast_module_state
+    rank, _, world = dist_utils.env_world()
+    dist = dist_utils.init_distributed("gloo")
+    torch.manual_seed(1000 + rank)                         # DIFFERENT replicas, as after a per-rank seed
+    model = nn.Sequential(nn.Linear(16, 300), nn.BatchNorm1d(300), nn.Linear(300, 7))
+    model[1].running_mean.fill_(float(rank)); model[1].num_batches_tracked.fill_(5 + rank)   # buffers too, incl. an int64 one
+    before = float(model[0].weight.sum())
+    sent = broadcast_module_state(model, dist, src=0, chunk_bytes=4096)       # several chunks
+    flat = torch.cat([t.double().reshape(-1) for t in list(model.parameters()) + list(model.buffers())])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    print(json.dumps(dict(rank=rank, same=same, changed=(float(model[0].weight.sum()) != before), sent=sent,
+                          tracked=int(model[1].num_batches_tracked))), flush=True)
+    dist.barrier(); dist.destroy_process_group()
+""") % str(ROOT)
+
+
+def test_initial_parameter_broadcast_makes_the_replicas_identical(tmp_path):
+    """DDP's module-state sync (rank 0 wins, parameters and buffers of every dtype) -- TrainStep does it before building the optimizer"""
+    script = tmp_path / "s.py"; script.write_text(SYNC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29546", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    assert all(d["same"] for d in outs), outs
+    assert [d["changed"] for d in sorted(outs, key=lambda d: d["rank"])] == [False, True]       # rank 0 keeps its state, rank 1 adopts it
+    assert all(d["tracked"] == 5 for d in outs) and outs[0]["sent"] == outs[1]["sent"] > 0
+    from styl3r_amd.ddp import broadcast_module_state
+    import torch
+    assert broadcast_module_state(torch.nn.Linear(2, 2), None) == 0                          # single process: nothing to do
+
+
 def test_reducer_single_process_is_identity():
     import torch
     from torch import nn
