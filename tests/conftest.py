@@ -29,3 +29,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _arithmetic_modes_do_not_leak():
+    """libvit_hip.so keeps two process-wide settings (products per split-arithmetic launch, attention arithmetic) that the Python
+    side syncs from module globals when an op runs; tests that call the C ABI directly must not inherit another test's mode."""
+    yield
+    vo = sys.modules.get("styl3r_amd.vit_ops")
+    if vo is not None and getattr(vo, "_lib", None) is not None:
+        vo._lib.vit_x6_set_products(6)
+        vo._lib.vit_attention_set_arith(1 if os.environ.get("VIT_ATTENTION", "bf16x6") == "bf16x6" else 0)
