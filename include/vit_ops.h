@@ -114,14 +114,23 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
  * The same Linear with an LDS-DMA operand ring (csrc/vit_gemm_x6r.hip).  Its weight operand is the BLOCK layout
  * packed[row / 64][k / 8][piece][row % 64][8] bf16 written by vit_split_weight_block (rows padded to a multiple of 64 with
  * zeros; vit_split_weight_block_bytes gives the size).  cfg: 1 = 128 x 128 ring, 2 = 256 x 256 ring, 3 = 256 x 256 with one
- * conversion per workgroup and ping-pong wave pairs, 32 + S = the same with an S-way K split (S = 2..8, fp32 atomics into the
- * zeroed output, no activation / pre); K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
+ * conversion per workgroup and ping-pong wave pairs, K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
  * DESIGN.md 9.2, not used by the default path.
  */
 size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);
 int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
 int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                        int M, int N, int K, int act, int cfg, void *stream);
+/*
+ * The ping-pong kernel (cfg 3 above: 256 x 256 tiles, one workgroup per CU) with an S-way split of K whose partial tiles meet in a
+ * caller-owned workspace (vit_linear_x6c_workspace_bytes; plain stores, one ticket per tile, the last arriver reduces and runs the
+ * full epilogue, activation and `pre` included).  vit_linear_x6c_choose_splits returns the S that fills the chip's 256 CUs best for
+ * a shape, or 0 when 256 x 256 tiles do not fit it (keep vit_linear_x6_fwd then).  Same weight layout as vit_linear_x6r_fwd.
+ */
+size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits);
+int vit_linear_x6c_choose_splits(int M, int N, int K);
+int vit_linear_x6c_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
+                       int M, int N, int K, int act, int splits, void *workspace, size_t workspace_bytes, void *stream);
 int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                       int M, int N, int K, int act, void *stream);
 

@@ -34,6 +34,10 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
                     hipStream_t stream);
 int attention_set_arith(int mode);
 int attention_arith();
+size_t x6c_workspace_bytes(int M, int N, int splits);
+int x6c_choose_splits(int M, int N, int K);
+int linear_x6c_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K,
+                   int act, int splits, void *workspace, size_t workspace_bytes, hipStream_t stream);
 int x6_set_products(int n);
 int x6_products();
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
@@ -101,6 +105,16 @@ VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose
 VIT_EXPORT int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
 {
     return vit::split_weight_block(w, packed, rows, cols, transpose, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits) { return vit::x6c_workspace_bytes(M, N, splits); }
+VIT_EXPORT int vit_linear_x6c_choose_splits(int M, int N, int K) { return vit::x6c_choose_splits(M, N, K); }
+
+VIT_EXPORT int vit_linear_x6c_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
+                                  int M, int N, int K, int act, int splits, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return vit::linear_x6c_fwd(x, w_packed, bias, residual, out, pre, M, N, K, act, splits, workspace, workspace_bytes,
+                               static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out,

@@ -13,7 +13,8 @@
 // The data path alone is worth +4 %; what moves the number is the ping-pong schedule: 3 460 cycles per 16-wide slab against
 // the 3 072 its 2 x 48 MFMAs per SIMD need (lockstep: 5 000).  At that point the kernel is limited by the power budget, not by
 // cycles: the same binary on zero-filled operands runs the same cycle counts at 2.3 GHz instead of 1.65 GHz.  256 x 256 tiles
-// quantise badly on everything but the qkv / fc1 shapes (84 tiles for N = 1024), so the default path keeps the 128-wide kernel.
+// quantise badly on everything but the qkv / fc1 shapes (84 tiles for N = 1024) and a K split (vit_linear_x6c_fwd: partial tiles
+// through a workspace, last arriver reduces) only pays for K >= 3072, so the default path keeps the 128-wide kernel.
 //
 // What this file does differently:
 //   * both operands reach LDS by DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no LDS store instructions;
@@ -293,7 +294,8 @@ __device__ inline void lds_wait_all(f32x4 (&b)[2][3], f32x4 (&a)[4][3])
 template <int ACT, int BM, int BN, int WM, int WN, bool PROF = false>
 __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                 float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+                                                                 float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
+                                                                 float4 *__restrict__ slabs, int *__restrict__ tickets)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
@@ -313,9 +315,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int KG = K >> 3, NB = (N + 63) >> 6;
-    // gridDim.y > 1: this workgroup contracts slabs [k_lo, k_lo + nk) of the K / 16 and adds its partial tile into the zeroed
-    // `out` with fp32 atomics (bias / residual enter through split 0; no activation): N <= 1024 gives 84 tiles of 256 x 256 for
-    // 256 CUs, 84 x 3 fills them
+    // gridDim.y > 1: this workgroup contracts slabs [k_lo, k_lo + nk) of the K / 16 (N <= 1024 gives 84 tiles of 256 x 256 for 256
+    // CUs, 84 x 3 fills them).  The S partial tiles of an output tile meet through `slabs` (register layout, 1 KiB per store
+    // instruction) and a ticket counter: whoever draws the last ticket adds the other S - 1 slabs to its own accumulators and
+    // runs the normal epilogue -- plain stores and loads, one release / acquire pair per tile, no atomics on the output.
     const int nk_all = K / BK, S_ = gridDim.y, sp_ = blockIdx.y;
     const int k_lo = sp_ * (nk_all / S_) + min(sp_, nk_all % S_), nk = nk_all / S_ + (sp_ < nk_all % S_ ? 1 : 0);
 
@@ -500,12 +503,53 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+    if (S_ > 1) {
+        const int tile_id = tm * tiles_n + tn;
+        constexpr int PER_WAVE = RM * RN * 4;                 // float4 stores per lane
+        auto slab_of = [&](int split) { return slabs + (((size_t)tile_id * S_ + split) * NW + wave) * (PER_WAVE * 64) + lane; };
+        float4 *mine = slab_of(sp_);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    mine[((i * RN + j) * 4 + q4) * 64] = make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // (also: every wave is done with the LDS images)
+        int *flag = reinterpret_cast<int *>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag != S_ - 1) return;                            // not the last arriver of this tile
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            tickets[tile_id] = 0;                               // ready for the next launch (the host zeroes it before the first)
+        }
+        __syncthreads();
+        for (int t = 0; t < S_; ++t) {
+            if (t == sp_) continue;
+            const float4 *other = slab_of(t);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 v = other[((i * RN + j) * 4 + q4) * 64];
+                        acc[i][j][4 * q4] += v.x; acc[i][j][4 * q4 + 1] += v.y; acc[i][j][4 * q4 + 2] += v.z; acc[i][j][4 * q4 + 3] += v.w;
+                    }
+        }
+    }
+
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int n = n0 + wn * (BN / WN) + 32 * j + col;
         if (n >= N) continue;
-        const bool first = sp_ == 0;
-        const float bv = (bias && first) ? bias[n] : 0.f;
+        const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
 #pragma unroll
@@ -514,11 +558,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
                 float t = acc[i][j][r] + bv;
-                if (S_ > 1) {
-                    if (residual && first) t += residual[o];
-                    atomicAdd(out + o, t);
-                    continue;
-                }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
@@ -591,18 +630,56 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
     } else if (cfg == 4) {
-        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512));
+        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     } else if (cfg >= 34) {
-        const int S = cfg - 32;
-        if (act || pre || K / x6r::BK < S) return VIT_EINVAL;
-        if (hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), dim3(((M + 255) / 256) * ((N + 255) / 256), S), dim3(512), 0, stream, x, w4, bias,
-                           residual, out, pre, M, N, K);
+        return VIT_EINVAL;            // K splits need a workspace: vit_linear_x6c_fwd
     } else {
-        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
-        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512));
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     }
 #undef X6R_ARGS
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+// The ping-pong kernel with an S-way K split whose partial tiles meet in `workspace` (x6c_workspace_bytes): S = 1 needs none.
+size_t x6c_workspace_bytes(int M, int N, int splits)
+{
+    const size_t tiles = (size_t)((M + 255) / 256) * ((N + 255) / 256);
+    return splits <= 1 ? 0 : tiles * splits * 256 * 256 * sizeof(float) + tiles * sizeof(int);
+}
+
+// Number of K splits that fills the 256 CUs best with 256 x 256 tiles (one workgroup per CU), or 0 when no split count gets
+// within 20 % of whole rounds -- the caller then keeps the 128-wide kernel.  At least 16 slabs per split.
+int x6c_choose_splits(int M, int N, int K)
+{
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / x6r::BK;
+    int best = 0;
+    float best_score = 0.8f;
+    for (int S = 1; S <= 8; ++S) {
+        if (S > 1 && nk / S < 16) break;
+        const int wg = tiles * S, rounds = (wg + 255) / 256;
+        const float score = (float)wg / (float)(rounds * 256) - 0.02f * (float)(S - 1);
+        if (score > best_score) { best_score = score; best = S; }
+    }
+    return best;
+}
+
+int linear_x6c_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K,
+                   int act, int splits, void *workspace, size_t workspace_bytes, hipStream_t stream)
+{
+    if (!x || !wp || !out) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || splits < 1 || splits > 8 || K / x6r::BK < splits) return VIT_EINVAL;
+    if (splits > 1 && (!workspace || workspace_bytes < x6c_workspace_bytes(M, N, splits))) return VIT_EINVAL;
+    const uint4 *w4 = static_cast<const uint4 *>(wp);
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    float4 *slabs = static_cast<float4 *>(workspace);
+    int *tickets = splits > 1 ? reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + (size_t)tiles * splits * 256 * 256 * sizeof(float)) : nullptr;
+    (void)hipGetLastError();
+    if (splits > 1 && hipMemsetAsync(tickets, 0, (size_t)tiles * sizeof(int), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets);
+    else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

@@ -313,9 +313,20 @@ def test_ring_dma_linear_kernels_equal_the_default_bf16x6_kernel(cfg, M, N, K, g
         got = vit_ops.linear_x6r(x, blk, N, bias=b, residual=r, gelu=gelu, cfg=cfg)
         assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 4e-6
         assert torch.equal(got, want), (rep, float((got - want).abs().max()))
-    if cfg == 3 and not gelu and K >= 48:            # the same kernel with a 3-way K split (fp32 atomics: sum order differs)
-        got = vit_ops.linear_x6r(x, blk, N, bias=b, residual=r, cfg=32 + 3)
-        assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 4e-6
+    if cfg == 3 and K >= 48:      # the ping-pong kernel with a 3-way K split: partial tiles through a workspace, last arriver reduces + epilogue
+        import ctypes as C
+        lib = vit_ops.load()
+        nb = lib.vit_linear_x6c_workspace_bytes(M, N, 3)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        got3 = torch.empty(M, N, device=DEV); pre3 = torch.empty(M, N, device=DEV)
+        for rep in range(5):
+            rc = lib.vit_linear_x6c_fwd(x.data_ptr(), blk.data_ptr(), b.data_ptr(), r.data_ptr() if r is not None else None, got3.data_ptr(),
+                                        pre3.data_ptr(), M, N, K, 1 if gelu else 0, 3, ws.data_ptr(), nb, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            assert float((got3.double() - ref).abs().max() / ref.abs().max()) <= 4e-6, rep
+        lin = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        assert float((pre3.double() - lin).abs().max() / lin.abs().max()) <= 4e-6           # the pre-activation store of the reducer
+        assert lib.vit_linear_x6c_choose_splits(5140, 1024, 4096) == 3 and lib.vit_linear_x6c_choose_splits(514, 1024, 1024) == 0
     # dX product through the transposed block packing: dX = dY . W
     gy = torch.randn(M, N, device=DEV, generator=g)
     if N % 16 == 0:

@@ -52,6 +52,21 @@ for name, (M, N, K) in shapes.items():
     err = float((out.double() - ref).abs().max()) / scale
     ms = timeit(f_old)
     print(json.dumps(dict(shape=name, kernel="x6", err=err, ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1))), flush=True)
+    S = lib.vit_linear_x6c_choose_splits(M, N, K)
+    if S > 0:
+        wsb = lib.vit_linear_x6c_workspace_bytes(M, N, S)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        out.zero_()
+        fa = lambda: lib.vit_linear_x6c_fwd(x.data_ptr(), blk.data_ptr(), b.data_ptr(), rp, out.data_ptr(), pp, M, N, K, ACT, S, ws.data_ptr(), wsb, st)
+        assert fa() == 0
+        torch.cuda.synchronize()
+        errs = []
+        for _ in range(5):
+            fa(); errs.append(float((out.double() - ref).abs().max()) / scale)
+        ms = timeit(fa)
+        print(json.dumps(dict(shape=name, kernel=f"x6c auto (S={S})", err=max(errs), ms=round(ms, 4), TF=round(2 * M * N * K / ms / 1e9, 1))), flush=True)
+    else:
+        print(json.dumps(dict(shape=name, kernel="x6c auto (S=0: default kernel kept)")), flush=True)
     for cfg in cfgs:
         out.zero_()
         f = lambda: lib.vit_linear_x6r_fwd(x.data_ptr(), blk.data_ptr(), b.data_ptr(), rp, out.data_ptr(), pp, M, N, K, ACT, cfg, st)
