@@ -188,23 +188,23 @@ def raster_leg(args, rank, world, dev, dist):
         loss.backward()
         return loss
 
-    # clocks first: a fresh, idle MI355X runs its first few hundred milliseconds 10-35 % slow (measured: 16.5 k instead of 22.1 k
-    # views/s with only the W warm-up steps in front of a 0.4 s timed region), so the device is kept busy for --prewarm-seconds with
-    # the same step before the W warm-up steps and the K timed ones; none of it is inside the timed region
-    t_end = time.perf_counter() + max(args.prewarm_seconds, 0.0)
-    while time.perf_counter() < t_end:
-        for _ in range(25):
-            step()
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    prof = _lib.StageProfile(args.steps + 1)
-    rz.PROFILE = prof
-    # the host is never more than one step ahead of the device (the forward reads its 32-byte status back), so a collector
-    # pause inside the timed region is device idle time: collect now, not then
+    # Everything that idles the device (profile buffers, a collector pass) happens BEFORE the clocks are brought up; from then on the
+    # device is kept busy without a pause: pre-warm (a fresh, idle MI355X runs its first ~0.1 s at less than half speed and a short timed
+    # region right behind a pause still sees the ramp: 21.2 k instead of 21.9 k views/s at --steps 20), the W warm-up steps, the K timed
+    # ones.  The host is never more than one step ahead of the device (the forward reads its 32-byte status back), so a collector pause
+    # inside the timed region would be device idle time: the collector stays off until the region is over.
     import gc
+    prof = _lib.StageProfile(args.steps + 1)
     gc.collect(); gc.disable()
     try:
+        t_end = time.perf_counter() + max(args.prewarm_seconds, 0.0)
+        while time.perf_counter() < t_end:
+            for _ in range(25):
+                step()
+            torch.cuda.synchronize(dev)
+        for _ in range(args.warmup):
+            step()
+        rz.PROFILE = prof
         dt = dist_utils.timed_steps(step, args.steps, lambda: torch.cuda.synchronize(dev), dist, dev)
     finally:
         gc.enable()
