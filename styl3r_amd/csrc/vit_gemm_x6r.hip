@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
     }
 #undef X6C_T
     if (PROF) {
-        if (blockIdx.x == 8 && lane == 0) {
+        if (pre && blockIdx.x == min(8, (int)gridDim.x - 1) && lane == 0) {      // cfg 4: `pre` receives 8 x 4 per-phase cycle counts of one workgroup
             pre[wave * 4 + 0] = (float)tw / nk; pre[wave * 4 + 1] = (float)ti / nk; pre[wave * 4 + 2] = (float)tl / nk; pre[wave * 4 + 3] = (float)tc / nk;
         }
         pre = nullptr;
@@ -629,7 +629,8 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     } else if (cfg == 2) {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
-    } else if (cfg == 4) {
+    } else if (cfg == 4) {      // phase-timing instantiation (tools/probes/gemm_lab.py): needs `pre` with room for 32 floats
+        if (!pre || (size_t)M * N < 32) return VIT_EINVAL;
         hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     } else if (cfg >= 34) {
         return VIT_EINVAL;            // K splits need a workspace: vit_linear_x6c_fwd
