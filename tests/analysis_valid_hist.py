@@ -1,4 +1,5 @@
-"""CPU statistic (no GPU): for the headline scene, the distribution of the number of pixels of a 16x16 tile that pass the
+"""Analysis script, not a test (kept under tests/ because it drives the oracle, which only tests / smoke / the bench's CPU leg may use).
+CPU statistic (no GPU): for the headline scene, the distribution of the number of pixels of a 16x16 tile that pass the
 alpha >= 1/255 test per (tile, Gaussian) pair -- what the wave reduction of the composite backward is amortised over."""
 import sys; sys.path.insert(0, ".")
 import numpy as np, torch
