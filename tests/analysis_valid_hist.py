@@ -39,3 +39,29 @@ for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 64), (65,
     print(f"  valid px {lo:3d}..{hi:3d}: {m.mean() * 100:5.1f} % of contributing pairs, {nz[m].sum() / nz.sum() * 100:5.1f} % of the useful evaluations")
 print("quadrants touched per contributing pair:", ((qcnt > 0).sum(1)[cnt > 0]).mean())
 print("cumulative: pairs with <= k valid px:", {k: round(float((nz <= k).mean()), 3) for k in (1, 2, 3, 4, 6, 8, 12, 16)})
+
+# ---- what a finer evaluation granularity would buy (round-3 estimate) --------------------------------------------------------
+# Today a wave evaluates a pair once per touched 8x8 quadrant (64 lanes = 64 pixels).  Alternative: the two half-waves run as two
+# independent 32-pixel machines -- lanes 0..31 own rows 0..3 of every quadrant, lanes 32..63 rows 4..7 -- each walking the list at
+# its own pace over the 8x4 half-quadrants a splat touches; a 64-entry batch then costs max(top items, bottom items) passes.
+hq = np.zeros((R, 8), bool)                      # [pair][quadrant * 2 + half]
+for a in range(0, R, 1 << 16):
+    e = slice(a, min(R, a + (1 << 16)))
+    dx = x[e, None, None] - (torch.tensor(ox[e])[:, None, None] + px[None, None, :])
+    dy = y[e, None, None] - (torch.tensor(oy[e])[:, None, None] + px[None, :, None])
+    power = -0.5 * (A[e, None, None] * dx * dx + Cc[e, None, None] * dy * dy) - B[e, None, None] * dx * dy
+    alpha = torch.clamp(op[e, None, None] * torch.exp(power), max=0.99)
+    ok = (power <= 0) & (alpha >= 1 / 255)
+    # (pair, qy, half, 4 rows, qx, 8 cols) -> any over rows / cols
+    h = ok.view(-1, 2, 2, 4, 2, 8).any(dim=5).any(dim=3)          # (pair, qy, half, qx)
+    hq[e] = h.permute(0, 1, 3, 2).reshape(-1, 8).numpy()
+quad_passes = (qcnt > 0).sum()
+starts = st.ranges[:, 0].astype(np.int64); ends = st.ranges[:, 1].astype(np.int64)
+two_stream = 0
+for s0, e0 in zip(starts, ends):
+    for b0 in range(s0, e0, 64):
+        blk = hq[b0:min(b0 + 64, e0)]
+        top = blk[:, 0::2].sum(); bot = blk[:, 1::2].sum()
+        two_stream += max(top, bot)
+print(f"evaluation passes over view 1: per 8x8 quadrant (today, exact-valid masks) {quad_passes}; two independent half-waves over 8x4 "
+      f"half-quadrants, per 64-entry batch {two_stream}  ->  {two_stream / quad_passes:.2f} x the passes, each over 32 instead of 64 pixels")
