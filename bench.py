@@ -245,6 +245,14 @@ def raster_leg(args, rank, world, dev, dist):
                 "alg_bytes_per_launch": dk["alg_bytes"], "avg_launch_ms": dk["avg_ms"],
                 "ns_per_pair_per_simd": round(dk["avg_ms"] * 1e6 * 1024 / max(R, 1), 2),
                 "pairs_R": R, "R_eff": R_eff, "stages": stages}
+    # the pass north_star's ">= 0.5 x HBM roofline" names is the alpha-composite FORWARD: reported beside the dominant kernel's block
+    cf = stages.get("composite_fwd")
+    pf = pmc_record("composite_fwd", headline)
+    roofline_cf = None if cf is None else {
+        "kernel": "k_composite_fwd", "bound": "hbm", "achieved": cf["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(cf["GBps"] / HBM_PEAK_GBS, 4), "traffic": pf["traffic"], "limited_by": "valu-issue", "valu": pf["valu"],
+        "alg_bytes_per_launch": cf["alg_bytes"], "avg_launch_ms": cf["avg_ms"], "target_frac": 0.5,
+        "note": "SURVEY 8d byte model (44 B per staged entry + 28 B per pixel); the kernel is VALU-issue-bound, DESIGN.md section 6"}
     res = {
         "metric": "256x256 stylized views/sec (fwd+bwd) @ ~65k Gaussians",
         "value": round(dist_utils.aggregate_throughput(V, args.steps, world, dt), 2), "unit": "views/s", "n_gpus": world,
@@ -252,9 +260,11 @@ def raster_leg(args, rank, world, dev, dist):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
                                f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x {args.grid}x{args.grid}), sh_degree="
-                               f"{args.sh_degree}, make_scale_invariant, all views in one batched launch",
+                               f"{args.sh_degree}, make_scale_invariant, all views in one batched launch; outputs the decoder discards are not computed "
+                               f"(decoder_splatting_cuda.py:37-68 drops radii / opacity / n_touched, MSE sends no depth gradient: the composite kernels run "
+                               f"their n_touched-free / depth-gradient-free instantiations -- the consumed results are identical)",
                    "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
-        "roofline": roofline,
+        "roofline": roofline, "roofline_composite_fwd": roofline_cf,
     }
     del g, cams, target, dec
     torch.cuda.empty_cache()
@@ -278,7 +288,9 @@ def train_leg(args, rank, world, dev, dist):
                 pos_embed="RoPE100", img_size=(512, 512)) if args.train_tiny else None
     enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=False), trunk_params=tiny).to(dev)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
-    step = TrainStep(enc, dec, dist=dist)
+    # a one-rank group (torch.distributed.run --nproc-per-node 1) still issues every collective: the RCCL path runs on one GPU
+    forced = dist is not None and world == 1
+    step = TrainStep(enc, dec, dist=dist, force_collective=forced)
     b, v_ctx, v_tgt, H = args.train_scenes, 2, 4, (32 if args.train_tiny else 256)
     g = torch.Generator(dev).manual_seed(1234 + rank)
     sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
@@ -298,9 +310,10 @@ def train_leg(args, rank, world, dev, dist):
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.train_steps, world, dt), 3), "unit": "views/s",
            "ms_per_step": round(1e3 * dt / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
            "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
-           "params": sum(p.numel() for p in enc.parameters()), "grad_bytes_all_reduced_per_step": grad_bytes if world > 1 else 0,
+           "params": sum(p.numel() for p in enc.parameters()), "grad_bytes_all_reduced_per_step": grad_bytes if step.reducer.collective else 0,
            "grad_bytes": grad_bytes, "buckets": len(step.reducer.buckets), "bucket_MiB": 64,
-           "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward" if world > 1 else "none (1 rank)"),
+           "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward"
+                          + (" (ONE-rank group: collectives issued, identity result)" if forced else "") if step.reducer.collective else "none (1 rank, no process group)"),
            "linear_arithmetic": vit_ops.LINEAR_MODE, "dtype": "f32", "data": "synthetic, random-init weights",
            "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
     if not cpu:
@@ -386,7 +399,9 @@ def main():
         assert local_rank < torch.cuda.device_count(), f"rank {rank}: local rank {local_rank} but {torch.cuda.device_count()} GPUs visible"
         torch.cuda.set_device(local_rank)
         dev, backend = torch.device("cuda", local_rank), "nccl"   # "nccl" is RCCL on ROCm
-    dist = dist_utils.init_distributed(backend, dev if backend == "nccl" else None)
+    # under torch.distributed.run a one-rank launch still forms its (one-rank) RCCL group, so `--gpus 1` exercises the collective path
+    dist = dist_utils.init_distributed(backend, dev if backend == "nccl" else None,
+                                       single_rank_group=dist_utils.launched_by_torchrun() and not args.dry_cpu)
 
     if args.dry_cpu:
         res, scenes = dry_leg(args, rank, world, dist), None

@@ -67,7 +67,7 @@ int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, cons
  * Arithmetic of the contractions of vit_attention_fwd and vit_attention_bwd: 1 (default) = bf16x6 split arithmetic on the bf16
  * MFMA (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernels'
  * error against float64 -- forward 1.3 - 1.6x, backward 1.3 - 1.55x faster), 0 = exact-f32 MFMA.  Strides that are not multiples
- * of 4 floats (or bases that are not 16-byte aligned) always take the f32 kernels.  Process-wide, read at launch time.
+ * of 4 floats (or bases that are not 16-byte aligned) always take the f32 kernels.  Per calling thread (thread_local), read at launch time on that thread.
  */
 int vit_attention_set_arith(int mode);
 int vit_attention_arith(void);
@@ -104,7 +104,7 @@ size_t vit_split_weight_bytes(int rows, int cols);
 /*
  * Partial products per launch of every bf16x6 kernel below (Linear, weight gradient, convolutions): 6 = fp32 round-off accuracy
  * (default); 3 = "bf16x3", a0 b0 + a0 b1 + a1 b0 only: ~3.5e-6 of the output scale per GEMM (two orders tighter than the TF32 the
- * reference enables, croco.py:13) for half the MFMA work.  Process-wide, read when a kernel is launched.  Returns VIT_EINVAL for
+ * reference enables, croco.py:13) for half the MFMA work.  Per calling thread (thread_local), read when that thread launches a kernel.  Returns VIT_EINVAL for
  * any other n.
  */
 int vit_x6_set_products(int n);

@@ -1,8 +1,11 @@
 // gsr_backward.hip -- backward pipeline of the gfx950 rasterizer.
 //
 //   K6 composite_bwd    same tiling as the forward (one wavefront per tile, 4 pixels per
-//                       lane); the per-tile queues are walked back-to-front from the
-//                       tile's deepest contributor; each splat's ten partial gradients are
+//                       lane); the tile's sorted id list is walked back-to-front from the
+//                       tile's deepest contributor, 64 entries at a time: each lane gathers ONE
+//                       entry's 48-byte record (and the quadrant mask the forward left in
+//                       `quad_mask`) into a wave-private LDS slot, then the wave evaluates the
+//                       batch from LDS broadcasts; each splat's ten partial gradients are
 //                       summed across the 64 lanes in registers (permlane swaps + DPP row
 //                       sums, no LDS) and leave the wave as ONE atomic per (tile, splat,
 //                       component).                                           (upstream R7)
@@ -24,11 +27,8 @@ enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_
 // ten-value wave reduction per splat (wave_reduce10) and ten lanes issue the tile's single
 // atomic per component.  No LDS atomics, no workgroup barriers.
 // DEPTH = false: no dL/ddepth was passed (Styl3R trains on colour only): the depth terms drop out of the evaluation
-#ifndef GSR_K6_MIN_WAVES
-#define GSR_K6_MIN_WAVES 1
-#endif
 template <bool DEPTH>
-__global__ void __launch_bounds__(64, GSR_K6_MIN_WAVES) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
+__global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      const float *__restrict__ dL_dimage,
                                                      const float *__restrict__ dL_ddepth)
 {

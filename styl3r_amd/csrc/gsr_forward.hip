@@ -404,7 +404,7 @@ constexpr uint32_t SORT_LDS_KEYS = 4096;  // at most 32 KiB of (dynamic) LDS per
 //      inside a bucket is arbitrary and does not matter);
 //   4. every key's final position = bucket start + number of keys of its bucket that compare smaller on the full 64-bit
 //      (depth, id) key -- buckets hold n / 256 keys on average, so this is a short loop over LDS words that neighbouring
-//      lanes read at the same address (broadcast); the sorted id and the queue record go straight to global memory;
+//      lanes read at the same address (broadcast); the sorted id goes straight to global memory (`point_list`);
 //   5. a bucket with more than RANK_MAX keys (depth clustered into a sliver of the tile's range: a near outlier in front
 //      of a far plane, or all depths equal) is sorted by the bitonic network instead, in place, by the whole workgroup.
 // O(n) + O(n * bucket size) instead of O(n log^2 n); no stability requirement anywhere because positions come from

@@ -220,15 +220,16 @@ hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const f
                                    hipStream_t stream);
 
 // 0: both contractions on the exact-f32 MFMA (this file); 1 (default): bf16x6 split arithmetic on the bf16 MFMA (vit_attention_x6.hip).
-// Process-wide like vit_x6_set_products, read at launch time.
-static std::atomic<int> g_attn_arith{1};
+// Per HOST THREAD (thread_local, like vit_x6_set_products): a thread's set + launch pair cannot be interleaved with another
+// thread's choice; read at launch time on the launching thread.
+static thread_local int g_attn_arith = 1;
 int attention_set_arith(int mode)
 {
     if (mode != 0 && mode != 1) return VIT_EINVAL;
-    g_attn_arith.store(mode, std::memory_order_relaxed);
+    g_attn_arith = mode;
     return VIT_OK;
 }
-int attention_arith() { return g_attn_arith.load(std::memory_order_relaxed); }
+int attention_arith() { return g_attn_arith; }
 int attention_fwd_tail(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, int rows,
                        hipStream_t stream);
 

@@ -19,10 +19,7 @@ namespace vit {
 extern thread_local hipError_t g_last_hip_error;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef VIT_BK
-#define VIT_BK 16
-#endif
-constexpr int BM = 128, BK = VIT_BK, LDT = 132;   // LDT: padded row length of the k-major tiles (BN = 64 * TN)
+constexpr int BM = 128, BK = 16, LDT = 132;   // LDT: padded row length of the k-major tiles (BN = 64 * TN)
 
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

@@ -48,10 +48,7 @@ __device__ inline int swz(int row, int slot) { return slot ^ ((row >> 3) & 1); }
 // 24x / 2.7x of a row-major walk (the B panels do not fit the 4 MB L2 and were re-streamed over the fabric).
 __device__ inline void tile_of_block(int bid, int tiles_m, int tiles_n, int &tm, int &tn)
 {
-#ifndef X6_GM
-#define X6_GM 8
-#endif
-    constexpr int GM = X6_GM;
+    constexpr int GM = 8;
     const int ntiles = tiles_m * tiles_n, q = ntiles >> 3, r = ntiles & 7;
     const int xcd = bid & 7, local = bid >> 3;
     const int pid = xcd * q + min(xcd, r) + local;
@@ -720,15 +717,16 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
 
 // Partial products per bf16x6 kernel launch: 6 (default, fp32 round-off accuracy) or 3 ("bf16x3": a0 b0 + a0 b1 + a1 b0, operands
 // good to 2^-18 -- ~3.5e-6 of the output scale per GEMM, two orders tighter than the TF32 the reference enables, croco.py:13).
-// Process-wide and read at launch time, so a step never mixes modes unless the caller changes it mid-step.
-static std::atomic<int> g_x6_products{6};
+// Per HOST THREAD (thread_local) and read at launch time on the launching thread: a thread's set + launch pair cannot be
+// interleaved with another thread's choice (a serving thread in bf16x3 beside a training thread in bf16x6).
+static thread_local int g_x6_products = 6;
 int x6_set_products(int n)
 {
     if (n != 3 && n != 6) return VIT_EINVAL;
-    g_x6_products.store(n, std::memory_order_relaxed);
+    g_x6_products = n;
     return VIT_OK;
 }
-int x6_products() { return g_x6_products.load(std::memory_order_relaxed); }
+int x6_products() { return g_x6_products; }
 
 // number of contraction splits for the weight-gradient kernels (2 resident workgroups per CU): one full round of 512
 // workgroups when the tiles alone are fewer, otherwise whole multiples are left to the tile count; >= min_slabs per split

@@ -12,11 +12,14 @@ all-reduced on RCCL's own stream while the backward keeps running.  xGMI is a po
 large buckets (default 64 MiB) keep every link busy and amortise the launch latency of the collective.
 Parameters that never receive a gradient on ANY rank (mask_token; head2 when v == 1) keep `grad = None` after
 `finish()`, as under the reference's `find_unused_parameters=True`: AdamW then skips them (no weight decay, no moment
-update).  The used / unused map is exchanged once (first step, one small MAX all-reduce) and cached -- the graph is static;
-it is re-exchanged if the local arrival set ever changes.
+update).  With more than one rank the used / unused map is exchanged EVERY step -- one small int32 MAX all-reduce issued
+asynchronously behind the buckets, unconditionally and identically on every rank (a collective must never be gated on
+rank-local state: a rank whose arrival set changed alone would enter it alone and hang or pair with another rank's next bucket);
+a single rank recomputes its map only when its own arrival set changes.
 
-Contract: exactly ONE backward between `prepare()` and `finish()`, and the same gradient-arrival order on every rank
-(identical replicas of a static graph).  A second backward after a bucket was launched would race with the collective and
+Contract: exactly ONE backward between `prepare()` and `finish()`.  Buckets are launched strictly in index order (a complete
+bucket waits for its predecessors; whatever is left goes out in `finish()`), so the collective sequence is the same on every rank
+whatever the local gradient-arrival order or set.  A second backward after a bucket was launched would race with the collective and
 is refused with a RuntimeError.
 """
 from __future__ import annotations
@@ -27,12 +30,13 @@ import torch
 from torch import nn
 
 
-def broadcast_module_state(module: nn.Module, dist, src: int = 0, chunk_bytes: int = 64 << 20) -> int:
+def broadcast_module_state(module: nn.Module, dist, src: int = 0, chunk_bytes: int = 64 << 20, force_collective: bool = False) -> int:
     """Every rank starts from rank `src`'s parameters and buffers -- what torch DDP does when it wraps a module
     (`_sync_module_states`; the reference gets it from Lightning's DDP strategy, src/main_style.py:104-108, whose per-rank seed only
     differs for the data).  Tensors are packed per dtype into flat chunks of <= chunk_bytes, one broadcast each (a handful of large
-    collectives instead of ~1 000 small ones).  Returns the number of bytes sent; a no-op without a process group / at world size 1."""
-    if dist is None or dist.get_world_size() == 1:
+    collectives instead of ~1 000 small ones).  Returns the number of bytes sent; a no-op without a process group / at world size 1
+    (unless `force_collective`: a one-rank group still issues every collective -- the hardware smoke test of this code path)."""
+    if dist is None or (dist.get_world_size() == 1 and not force_collective):
         return 0
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     groups: dict = {}
@@ -62,10 +66,14 @@ def broadcast_module_state(module: nn.Module, dist, src: int = 0, chunk_bytes: i
 
 
 class BucketedGradReducer:
-    def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20, inplace_grads: bool = True):
+    def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20, inplace_grads: bool = True,
+                 force_collective: bool = False):
         self.dist = dist
         self.inplace_grads = inplace_grads
         self.world = dist.get_world_size() if dist is not None else 1
+        # `force_collective`: issue every collective even in a one-rank group (sum over one rank = identity), so that the stream
+        # ordering between the in-place bucket writers, the pack copy and RCCL's stream is exercised on a single GPU
+        self.collective = dist is not None and (self.world > 1 or force_collective)
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))
         self.buckets: List[dict] = []
@@ -82,6 +90,7 @@ class BucketedGradReducer:
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._arrived: set = set()
         self._arrived_key = None        # the local arrival set the cached map was computed for
+        self._next = 0                  # index of the next bucket to launch
         self._unused: List[nn.Parameter] = []
         self._hooks = []
         for bi, b in enumerate(self.buckets):
@@ -108,8 +117,10 @@ class BucketedGradReducer:
                                    "retain_graph re-runs through the reducer)")
             self._arrived.add(self._index[id(p)])
             b["pending"] -= 1
-            if b["pending"] == 0:
-                self._launch(b)
+            # buckets are launched strictly in index order, so that every rank issues the same collective sequence even
+            # when a gradient arrives in a different order (or not at all) on some rank
+            while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+                self._launch(self.buckets[self._next]); self._next += 1
         return hook
 
     def _launch(self, b):
@@ -120,7 +131,7 @@ class BucketedGradReducer:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
         for p, v in zip(b["params"], b["views"]):
             p.grad = v
-        if self.dist is not None and self.world > 1:
+        if self.collective:
             self._handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def prepare(self):
@@ -128,6 +139,7 @@ class BucketedGradReducer:
         self._handles.clear()
         self._armed = True
         self._arrived = set()
+        self._next = 0
         torch._foreach_zero_([b["flat"] for b in self.buckets])
         for b in self.buckets:
             b["pending"], b["launched"] = len(b["params"]), False
@@ -142,6 +154,13 @@ class BucketedGradReducer:
         for b in self.buckets:
             if not b["launched"]:
                 self._launch(b)
+        # the used / unused exchange: unconditional and symmetric (same collective sequence on every rank, every step)
+        used = None
+        if self.collective:
+            used = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device if self.params else "cpu")
+            if self._arrived:
+                used[torch.tensor(sorted(self._arrived), device=used.device)] = 1
+            self._handles.append(self.dist.all_reduce(used, op=self.dist.ReduceOp.MAX, async_op=True))
         for h in self._handles:
             h.wait()
         self._handles.clear()
@@ -152,16 +171,14 @@ class BucketedGradReducer:
         if self.world > 1:
             torch._foreach_mul_([b["flat"] for b in self.buckets], 1.0 / self.world)
         # parameters no rank produced a gradient for: grad = None (the optimizer skips them), as DDP(find_unused_parameters)
-        key = frozenset(self._arrived)
-        if key != self._arrived_key:
-            used = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device if self.params else "cpu")
-            if self._arrived:
-                used[torch.tensor(sorted(self._arrived), device=used.device)] = 1
-            if self.dist is not None and self.world > 1:
-                self.dist.all_reduce(used, op=self.dist.ReduceOp.MAX)
-            flags = used.cpu().tolist()            # one host sync, on the first step only (static graph)
+        if used is not None:
+            flags = used.cpu().tolist()            # 4 B per parameter; the optimizer step that follows needs the host anyway
             self._unused = [p for p, u in zip(self.params, flags) if not u]
-            self._arrived_key = key
+        else:
+            key = frozenset(self._arrived)         # one rank: nothing to exchange, the map changes only with the local set
+            if key != self._arrived_key:
+                self._unused = [p for i, p in enumerate(self.params) if i not in key]
+                self._arrived_key = key
         for p in self._unused:
             p.grad = None
 

@@ -18,10 +18,16 @@ def env_world() -> tuple:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_distributed(backend: str, device: Optional[torch.device] = None):
-    """Returns the torch.distributed module if WORLD_SIZE > 1 (process group initialised), else None."""
+def launched_by_torchrun() -> bool:
+    """True inside a `python -m torch.distributed.run` worker (it exports the rendezvous of the group it expects us to join)."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+
+
+def init_distributed(backend: str, device: Optional[torch.device] = None, single_rank_group: bool = False):
+    """Returns the torch.distributed module if WORLD_SIZE > 1 (process group initialised), else None.  `single_rank_group`: also
+    initialise a ONE-rank group (a `torch.distributed.run --nproc-per-node 1` launch: the RCCL path then runs on one GPU)."""
     rank, _, world = env_world()
-    if world <= 1:
+    if world <= 1 and not single_rank_group:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

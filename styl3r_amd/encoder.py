@@ -13,8 +13,8 @@ Own restatement (same parameter names, so reference checkpoints load unchanged) 
                                     src/model/encoder/encoder_noposplat_token_style.py:69-295
   * `get_encoder`                   src/model/encoder/__init__.py:20-25
 Everything heavy runs on hand-written gfx950 kernels, all fp32-accurate like the reference (heads under
-autocast(enabled=False), encoder_noposplat_multi_token_style.py:150): transformer blocks on styl3r_amd.vit (f32-MFMA flash
-attention with fused RoPE, bf16x6 Linear layers with bias / GELU / residual epilogues, HIP LayerNorm), the DPT heads' 3x3 /
+autocast(enabled=False), encoder_noposplat_multi_token_style.py:150): transformer blocks on styl3r_amd.vit (flash attention with
+fused RoPE in bf16x6 split arithmetic on the bf16 MFMA -- exact-f32-MFMA kernels behind VIT_ATTENTION=f32 -- bf16x6 Linear layers with bias / GELU / residual epilogues, HIP LayerNorm), the DPT heads' 3x3 /
 1x1 stride-1 convolutions and x2 resampling on vit_conv_x6_* / vit_upsample2x_*, the head tails + Gaussian adapter on
 vit_adapter_*.  Only the small-resolution / strided / transposed / 7x7 convolutions stay on MIOpen.
 """

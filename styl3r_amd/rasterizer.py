@@ -25,10 +25,29 @@ from . import _lib
 _CAP_HINT: dict = {}
 # longest per-tile list seen per problem shape (x1.25): picks the LDS budget of the per-tile sort
 _MAX_TILE_HINT: dict = {}
-# per (device, stream, host thread): (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward.
-# Keyed that way because two forwards on different streams or threads of one device would otherwise race on the buffer
-# (and read each other's pair count / overflow flag).
-_STATUS_HOST: dict = {}
+# (pinned int32[GSR_STATUS_WORDS], event) for the status read-back of the forward, per host thread (threading.local: the
+# buffers die with the thread and a recycled thread id can never pick up another thread's buffer) and per (device, stream)
+# inside it, as a small LRU -- two forwards on different streams or threads of one device must not share a buffer (they would
+# read each other's pair count / overflow flag), and short-lived side streams must not pin host memory for the life of the
+# process.
+_STATUS_LOCAL = threading.local()
+_STATUS_LRU_MAX = 8
+
+
+def _status_host(dev):
+    from collections import OrderedDict
+    cache = getattr(_STATUS_LOCAL, "cache", None)
+    if cache is None:
+        cache = _STATUS_LOCAL.cache = OrderedDict()
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    host = cache.get(key)
+    if host is None:
+        host = cache[key] = (torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        while len(cache) > _STATUS_LRU_MAX:
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
+    return host
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
 KEEP_DEBUG = False
 LAST_DEBUG: dict = {}
@@ -114,12 +133,7 @@ class _Rasterize(torch.autograd.Function):
             dims.flags = flags
             _lib.check(rc, "gsr_forward")
 
-        hkey = (dev.index, torch.cuda.current_stream(dev).cuda_stream, threading.get_ident())
-        host = _STATUS_HOST.get(hkey)
-        if host is None:
-            host = _STATUS_HOST[hkey] = (torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, pin_memory=True),
-                                         torch.cuda.Event())
-        st, ev = host
+        st, ev = _status_host(dev)
         while True:
             L = _lib.workspace_layout(dims, cap)
             ws = torch.empty(L.total, dtype=torch.uint8, device=dev)

@@ -67,17 +67,18 @@ class TrainStep:
     def __init__(self, encoder: nn.Module, decoder: nn.Module, lr: float = 2e-4, dist=None, bucket_bytes: int = 64 << 20,
                  clip: Optional[float] = 0.5, losses: Optional[Sequence[nn.Module]] = None,
                  identity_loss: Optional[nn.Module] = None, backbone_lr_multiplier: float = 0.1,
-                 warm_up_steps: Optional[int] = None, max_steps: int = 100_000):
+                 warm_up_steps: Optional[int] = None, max_steps: int = 100_000, force_collective: bool = False):
         self.encoder, self.decoder, self.clip = encoder, decoder, clip
         self.losses, self.identity_loss = (list(losses) if losses is not None else None), identity_loss
         # identical replicas before anything else looks at the parameters (DDP semantics: rank 0's state wins)
-        self.synced_bytes = broadcast_module_state(encoder, dist)
+        self.synced_bytes = broadcast_module_state(encoder, dist, force_collective=force_collective)
         new, pre, self.frozen_names = select_trainable(encoder)
         self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier)
         self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
         # bucket order = reverse registration order of the trainable parameters (autograd readiness)
         trainable = {id(p) for p in list(new) + list(pre)}
-        self.reducer = BucketedGradReducer([p for p in encoder.parameters() if id(p) in trainable], dist, bucket_bytes)
+        self.reducer = BucketedGradReducer([p for p in encoder.parameters() if id(p) in trainable], dist, bucket_bytes,
+                                           force_collective=force_collective)
         self.global_step = 0
 
     def _render(self, ctx, style, tgt):

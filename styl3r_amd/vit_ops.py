@@ -592,12 +592,28 @@ class _ReluDropout(torch.autograd.Function):
         return dx, None, None
 
 
+_DROPOUT_GEN: dict = {}
+
+
+def _dropout_generator() -> torch.Generator:
+    """one generator per (base seed, rank): re-created when torch.manual_seed changes the base seed"""
+    key = (torch.initial_seed(), int(os.environ.get("RANK", "0")))
+    g = _DROPOUT_GEN.get("gen")
+    if g is None or _DROPOUT_GEN.get("key") != key:
+        g = torch.Generator()
+        g.manual_seed((key[0] * 1_000_003 + 7919 * key[1] + 0x5DEECE66D) % (2 ** 63))
+        _DROPOUT_GEN["gen"], _DROPOUT_GEN["key"] = g, key
+    return g
+
+
 def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
     """Dropout(p)(ReLU(x)) of the 'gs_params' DPT heads (dpt_block.py:332-340).  Training on a device fp32 tensor: one HIP pass each
-    way, in place, no mask tensor (vit_relu_dropout_fwd / _bwd; the keep decisions come from Philox keyed by a seed drawn from torch's
-    default CPU generator, so `torch.manual_seed` makes a run repeatable); otherwise the framework ops."""
+    way, in place, no mask tensor (vit_relu_dropout_fwd / _bwd; the keep decisions come from Philox keyed by a seed drawn from a DEDICATED
+    generator -- seeded from (torch.initial_seed(), RANK) at first use, so `torch.manual_seed` before the first step makes a run
+    repeatable, ranks draw different masks as under the reference's `seed + global_rank` (src/main_style.py:118), and the default CPU
+    generator -- data sampling, shuffles -- is never consumed); otherwise the framework ops."""
     if training and p > 0.0 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and not x.is_leaf:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=_dropout_generator()).item())
         return _ReluDropout.apply(x, p, seed)
     return torch.nn.functional.dropout(torch.relu_(x) if not x.is_leaf else torch.relu(x), p, training)
 

@@ -89,3 +89,92 @@ def deterministic_vgg_(module):
                 val = 0.05 * torch.randn(t.shape, generator=g)
             t.copy_(val.to(t.device, t.dtype))
     return module
+
+
+# ---- end-to-end (encoder -> decoder -> MSE) fixtures: tests/golden/make_e2e_fixtures.py and tests/test_e2e_parity.py ----------------
+# Target statistics (mean, std per output channel) of the five 1x1 output convolutions after re-centring: xyz of the point heads
+# (depth expm1(|xyz|) ~ 2..4, inside a tan(fov/2) = 0.58 frustum), (opacity logit, 3 log-scales, 4 quaternion) of the gs heads,
+# SH DC of the appearance head.
+E2E_HEAD_TARGETS = {
+    "downstream_head1": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
+    "downstream_head2": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
+    "gaussian_param_head": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
+    "gaussian_param_head2": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
+    "gaussian_appearance_head": ([0.0, 0.0, 0.0], [1.2, 1.2, 1.2]),
+}
+
+
+def e2e_cameras(b=1):
+    """Two target cameras per scene in the frame of context view 0 (the encoder is pose-free): the identity and a 4-degree
+    turn about y with a small translation; RE10K-like normalised intrinsics; near 0.5 so that make_scale_invariant rescales by 2."""
+    import math
+    a = math.radians(4.0)
+    c2w1 = torch.tensor([[math.cos(a), 0, math.sin(a), 0.25], [0, 1, 0, -0.08], [-math.sin(a), 0, math.cos(a), -0.15], [0, 0, 0, 1.0]])
+    ext = torch.stack([torch.eye(4), c2w1])[None].repeat(b, 1, 1, 1)
+    K = torch.tensor([[0.86, 0, 0.5], [0, 0.86, 0.5], [0, 0, 1.0]])
+    K2 = torch.tensor([[0.90, 0, 0.49], [0, 0.88, 0.51], [0, 0, 1.0]])
+    intr = torch.stack([K, K2])[None].repeat(b, 1, 1, 1)
+    return dict(extrinsics=ext, intrinsics=intr, near=torch.full((b, 2), 0.5), far=torch.full((b, 2), 100.0))
+
+
+def closed_form_image(shape):
+    """smooth target image in [0.1, 0.9] as a closed form of (view, channel, y, x): identical on the generator and the test side"""
+    b, v, c, H, W = shape
+    y = torch.arange(H, dtype=torch.float64)[:, None]
+    x = torch.arange(W, dtype=torch.float64)[None, :]
+    out = torch.empty(shape, dtype=torch.float64)
+    for i in range(b):
+        for j in range(v):
+            for k in range(c):
+                out[i, j, k] = 0.5 + 0.4 * torch.cos(0.045 * x * (1 + 0.3 * k) + 0.031 * y * (1 + 0.5 * j) + 0.9 * k + 0.4 * i)
+    return out.float()
+
+
+def e2e_fragile_mask(st, H, W, eps_alpha=5e-3, tie_rel=5e-6, term_rel=0.02, w_min=2e-5):
+    """Pixels of an oracle render (oracle.gsr_oracle.FwdState) whose value is discontinuity-adjacent when the INPUT Gaussians move
+    by what an fp32 evaluation of the encoder moves them (1e-6 .. 1e-5 relative): (i) a contributor whose alpha is within eps_alpha of the
+    1/255 cut, (ii) two consecutive visible contributors whose depths differ by less than tie_rel (their order may swap), (iii) the
+    termination test T < 1e-4 decided within term_rel -- each only where the flip could move the pixel by more than w_min.
+    Used by the fixture generator only; the mask is stored with the fixture."""
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    frag = np.zeros((H, W), bool)
+    thr = 1.0 / 255.0
+    xy = st.xy.astype(np.float64); co = st.conic_opacity.astype(np.float64); depth = st.depth.astype(np.float64)
+    for tile in range(gx * gy):
+        s, e = int(st.ranges[tile][0]), int(st.ranges[tile][1])
+        if e <= s:
+            continue
+        ids = st.point_list[s:e]
+        tx, ty = tile % gx, tile // gx
+        xs = np.arange(tx * 16, min(tx * 16 + 16, W)); ys = np.arange(ty * 16, min(ty * 16 + 16, H))
+        px, py = np.meshgrid(xs, ys)
+        px = px.reshape(-1).astype(np.float64); py = py.reshape(-1).astype(np.float64)
+        dx = xy[ids, 0][:, None] - px[None]; dy = xy[ids, 1][:, None] - py[None]
+        A, B, C, op = (co[ids, k][:, None] for k in range(4))
+        power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+        alpha = np.minimum(0.99, op * np.exp(np.minimum(power, 0.0)))
+        valid = (power <= 0) & (alpha >= thr)
+        om = np.where(valid, 1.0 - alpha, 1.0)
+        T_after = np.cumprod(om, 0)
+        T_before = T_after / om
+        stop = valid & (T_after < 1e-4)
+        dead = np.cumsum(stop, 0) > 0                              # the terminating entry and everything behind it
+        live = ~dead
+        near_thr = (power <= 0) & (np.abs(alpha - thr) < eps_alpha * thr) & live & (T_before * thr > w_min)
+        first_stop = stop & (np.cumsum(stop, 0) == 1)
+        near_term = (valid & live & (np.abs(T_after - 1e-4) < term_rel * 1e-4)) | (first_stop & (np.abs(T_after - 1e-4) < term_rel * 1e-4))
+        contrib = valid & live
+        n = len(ids)
+        d = depth[ids][:, None]
+        idx = np.where(contrib, np.arange(n)[:, None], -1)
+        prev = np.maximum.accumulate(idx, 0)
+        prev = np.vstack([np.full((1, prev.shape[1]), -1), prev[:-1]])
+        has_prev = prev >= 0
+        pc = np.clip(prev, 0, None)
+        d_prev = np.take_along_axis(np.broadcast_to(d, alpha.shape), pc, 0)
+        a_prev = np.take_along_axis(alpha, pc, 0)
+        T_prev = np.take_along_axis(T_before, pc, 0)
+        tie = contrib & has_prev & ((d - d_prev) < tie_rel * d) & (T_prev * a_prev * alpha > w_min)
+        bad = (near_thr | near_term | tie).any(0)
+        frag[py.astype(int), px.astype(int)] |= bad
+    return frag

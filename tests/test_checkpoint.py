@@ -73,6 +73,33 @@ def test_noposplat_state_dict_splits_gs_head_into_structure_and_appearance():
     assert torch.equal(enc.gaussian_appearance_head.dpt.head[0].weight, sd["encoder.gaussian_param_head.dpt.head.0.weight"])
 
 
+def test_noposplat_state_dict_seeds_the_two_view_encoders_structure_and_appearance_heads():
+    """EncoderNoPoSplatTokenStyle has `gaussian_structure_head` / `gaussian_appearance_head` instead of
+    gaussian_param_head{,2}; the reference seeds exactly these two from NoPoSplat's gaussian_param_head: rows [:-3 d_sh] of
+    dpt.head.4 -> structure head (src/main_style.py:144-146), rows [-3 d_sh:] -> appearance head (:148-150)."""
+    from styl3r_amd.encoder import EncoderNoPoSplatTokenStyle
+    enc = EncoderNoPoSplatTokenStyle(EncoderNoPoSplatTokenStyleCfg(name="noposplat_token_style"), trunk_params=TINY)
+    d3 = 3 * enc.gaussian_adapter.d_sh
+    g = torch.Generator().manual_seed(3)
+    # a NoPoSplat checkpoint: backbone + downstream heads + ONE gs head family whose head.4 has raw_gs_dim rows
+    sd = {"encoder." + k: torch.randn(v.shape, generator=g) for k, v in enc.state_dict().items() if k.startswith(("backbone.", "downstream_head1."))}
+    rows = enc.gaussian_structure_head.dpt.head[4].weight.shape[0]
+    for k, v in enc.gaussian_structure_head.state_dict().items():
+        shape = (rows + d3, *v.shape[1:]) if k.startswith("dpt.head.4.") else v.shape
+        sd["encoder.gaussian_param_head." + k] = torch.randn(shape, generator=g)
+    before_sb = enc.structure_builder.state_dict()
+    before_sb = {k: v.clone() for k, v in before_sb.items()}
+    missing, unexpected = ck.load_pretrained_encoder(enc, {"state_dict": sd})
+    assert all(u.startswith("gaussian_param_head.") for u in unexpected)            # this encoder has no module of that name
+    w4 = sd["encoder.gaussian_param_head.dpt.head.4.weight"]; b4 = sd["encoder.gaussian_param_head.dpt.head.4.bias"]
+    assert torch.equal(enc.gaussian_structure_head.dpt.head[4].weight, w4[:-d3]) and torch.equal(enc.gaussian_structure_head.dpt.head[4].bias, b4[:-d3])
+    assert torch.equal(enc.gaussian_appearance_head.dpt.head[4].weight, w4[-d3:]) and torch.equal(enc.gaussian_appearance_head.dpt.head[4].bias, b4[-d3:])
+    for mod in (enc.gaussian_structure_head, enc.gaussian_appearance_head):          # the shared trunk of both heads is seeded too
+        assert torch.equal(mod.dpt.head[0].weight, sd["encoder.gaussian_param_head.dpt.head.0.weight"])
+        assert torch.equal(mod.dpt.scratch.refinenet1.out_conv.weight, sd["encoder.gaussian_param_head.dpt.scratch.refinenet1.out_conv.weight"])
+    assert all(torch.equal(v, enc.structure_builder.state_dict()[k]) for k, v in before_sb.items())     # untouched, as in the reference
+
+
 def test_checkpoint_filter_matches_the_reference_function():
     """`convert_mast3r_state_dict` against outputs of the reference's own `checkpoint_filter_fn` (weight_modify.py:144-197) on a
     synthetic MASt3R 'model' dict with 8 x 8 patches (-> `resample_patch_embed`), a 4-channel mean head (confidence dropped)

@@ -158,3 +158,49 @@ def test_unused_parameter_keeps_grad_none_and_adamw_skips_it():
         assert dead.grad is None and m.weight.grad is not None
         opt.step()
     assert torch.equal(dead.detach(), torch.ones(5))       # no weight decay applied to a parameter without gradient
+
+
+CHANGING_WORKER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, %r)
+    import torch
+    from torch import nn
+    from styl3r_amd import dist_utils
+    from styl3r_amd.ddp import BucketedGradReducer
+    rank, _, world = dist_utils.env_world()
+    dist = dist_utils.init_distributed("gloo")
+    torch.manual_seed(0)
+    trunk, branch = nn.Linear(8, 8), nn.Linear(8, 8)       # `branch` only gets a gradient where the batch takes it
+    params = list(trunk.parameters()) + list(branch.parameters())
+    red = BucketedGradReducer(params, dist, bucket_bytes=64)
+    x = torch.ones(4, 8)
+    seen = []
+    # step 0: no rank uses the branch; step 1: ONLY rank 1 does (its local arrival set changes, rank 0's does not);
+    # step 2: nobody again.  The r02 reducer entered its map all-reduce on rank 1 alone at step 1 (ADVICE r2: hang / mispaired collective)
+    for step in range(3):
+        red.prepare()
+        y = trunk(x)
+        if step == 1 and rank == 1:
+            y = y + branch(x)
+        y.sum().backward()
+        red.finish()
+        seen.append(branch.weight.grad is not None)
+        if step == 1:
+            want = torch.full((8, 8), 4.0) / world           # rank 1's gradient (sum over 4 rows of ones), averaged over the ranks
+            ok = bool(torch.allclose(branch.weight.grad, want))
+    print(json.dumps(dict(rank=rank, seen=seen, ok=ok)), flush=True)
+    dist.barrier(); dist.destroy_process_group()
+""") % str(ROOT)
+
+
+def test_used_map_exchange_is_symmetric_when_one_ranks_arrival_set_changes(tmp_path):
+    """a collective must not be gated on rank-local state"""
+    script = tmp_path / "c.py"; script.write_text(CHANGING_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29548", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        d = json.loads(o.strip().splitlines()[-1])
+        assert d["seen"] == [False, True, False] and d["ok"], d       # used on ANY rank -> a gradient on EVERY rank, that step only

@@ -283,6 +283,81 @@ def test_full_size_workload_parity():
     _check_forward(sc.means.numpy() * s, cov6, sc.opacities.numpy(), cam, shs=sc.harmonics.numpy().transpose(0, 2, 1))
 
 
+def _scene_view_cam(sc, views, i):
+    row = views[i]; s = np.float32(row[56])
+    cov = sc.covariances.numpy()
+    cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1) * (s * s)
+    H, W = sc.image_shape
+    cam = dict(H=H, W=W, tanfovx=row[51], tanfovy=row[52], view=row[0:16].reshape(4, 4), proj=row[16:32].reshape(4, 4),
+               proj_raw=row[32:48].reshape(4, 4), campos=row[48:51])
+    return s, cov6, cam
+
+
+def test_full_size_workload_backward_parity_single_view():
+    """the BACKWARD at the headline size (G = 65 536, 256 x 256; lists of ~630 entries, multi-batch
+    back-to-front walk) against the f32 and f64 oracles, every gradient, depth gradient included (k_composite_bwd<true>)."""
+    from styl3r_amd.decoder import prepare_views
+    from styl3r_amd.scenes import make_scene
+    sc = make_scene(n_ctx=1, grid_hw=(256, 256), n_views=2, image_hw=(256, 256), sh_degree=0, seed=1234)
+    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(2, 3), True).numpy()
+    s, cov6, cam = _scene_view_cam(sc, views, 1)
+    _check_backward(sc.means.numpy() * s, cov6, sc.opacities.numpy(), cam, shs=sc.harmonics.numpy().transpose(0, 2, 1), seed=5)
+
+
+def test_c4_size_view_backward_parity():
+    """one view of the C4 workload: 4 context views x 256^2 = 262 144 Gaussians (lists of ~2 250, up to ~4 700 entries: beyond the
+    tile sort's LDS budget), forward integer state + images and every gradient against the oracles"""
+    from styl3r_amd.decoder import prepare_views
+    from styl3r_amd.scenes import make_scene
+    sc = make_scene(n_ctx=4, grid_hw=(256, 256), n_views=2, image_hw=(256, 256), sh_degree=0, seed=4321)
+    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(2, 3), True).numpy()
+    s, cov6, cam = _scene_view_cam(sc, views, 0)
+    means, opac, shs = sc.means.numpy() * s, sc.opacities.numpy(), sc.harmonics.numpy().transpose(0, 2, 1)
+    _check_forward(means, cov6, opac, cam, shs=shs, min_ok=0.9)
+    _check_backward(means, cov6, opac, cam, shs=shs, seed=6, f64_rel=5e-4)
+
+
+def test_headline_workload_backward_parity_through_the_decoder():
+    """The bench's own path at the bench's own size: 2 scenes x 4 target views, G = 65 536, 256 x 256, through DecoderSplattingHIP
+    -- k_composite_fwd<false> / k_composite_bwd<false> (no n_touched, no depth gradient), LPT tile order, accumulators pre-zeroed
+    by the forward, Gaussians shared by the 4 views of a scene -- image-only loss; the gradients of scene 1 (the second scene: batch
+    indexing) against the oracle's, summed over its 4 views (decoder_splatting_cuda.py:37-68, cuda_splatting.py:46-133)."""
+    from oracle.gsr_oracle import Oracle
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder, prepare_views
+    from styl3r_amd.scenes import make_scene
+    dev = torch.device("cuda:0")
+    scs = [make_scene(n_ctx=1, grid_hw=(256, 256), n_views=4, image_hw=(256, 256), sh_degree=0, seed=1234 + i) for i in range(2)]
+    st = lambda n: torch.stack([getattr(sc, n) for sc in scs]).to(dev)
+    g = Gaussians(*(st(n).requires_grad_(True) for n in ("means", "covariances", "harmonics", "opacities")))
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    out = dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (256, 256))
+    rng = np.random.default_rng(9)
+    wI = rng.normal(size=(2, 4, 3, 256, 256)).astype(np.float32)
+    (out.color * torch.tensor(wI, device=dev)).sum().backward()
+    sc = scs[1]
+    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(4, 3), True).numpy()
+    G = sc.means.shape[0]
+    for prec, bar in (("f32", 1e-4), ("f64", 3e-4)):
+        orc = Oracle(prec)
+        acc = dict(means=np.zeros((G, 3)), cov=np.zeros((G, 3, 3)), sh=np.zeros((G, 3, 1)), opac=np.zeros(G))
+        for v in range(4):
+            s, cov6, cam = _scene_view_cam(sc, views, v)
+            stt, ctx = orc.forward(np.float32(sc.means.numpy() * s), np.float32(cov6), sc.opacities.numpy(), shs=sc.harmonics.numpy().transpose(0, 2, 1),
+                                   H=256, W=256, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=(0, 0, 0), view=cam["view"], proj=cam["proj"],
+                                   proj_raw=cam["proj_raw"], campos=cam["campos"], nthreads=8)
+            if prec == "f32":
+                ok = stt.fragile == 0
+                assert_close_rel(out.color[1, v].detach().cpu().numpy()[:, ok], stt.image[:, ok], 1e-4, f"view {v} image")
+            gr = orc.backward(stt, ctx, wI[1, v], None, nthreads=8)
+            acc["means"] += gr["means3D"] * s
+            r, c = np.triu_indices(3)
+            acc["cov"][:, r, c] += gr["cov6"] * (s * s)                     # cov3D_precomp = covariances[:, row, col]: upper triangle only
+            acc["sh"] += gr["shs"].transpose(0, 2, 1)
+            acc["opac"] += gr["opacities"]
+        for name, t in (("means", g.means), ("cov", g.covariances), ("sh", g.harmonics), ("opac", g.opacities)):
+            assert_close_rel(t.grad[1].cpu().numpy(), acc[name], bar, f"decoder path d{name} vs {prec} oracle (4 views summed)")
+
+
 def test_build_views_kernel_matches_torch_view_setup():
     """gsr_build_views (one kernel) == prepare_views (the reference's torch op sequence) to a few ulp"""
     from styl3r_amd.decoder import build_views_hip, prepare_views

@@ -165,3 +165,63 @@ def test_inplace_bucket_gradients_match_the_copy_path():
         # by the in-place path, so they only get a sanity bound.  Everything else (the in-place Linear layers included): tight.
         tol = 1e-2 * scale if ".dpt." in n else 5e-4 * scale + 4 * noise + 1e-7
         assert float((got[n] - ref[n]).abs().max()) <= tol + 1e-12, (n, float((got[n] - ref[n]).abs().max()), noise, scale)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
+    """the RCCL branch of the train step had never executed on a GPU (every GPU run was one rank without a
+    process group).  A ONE-rank "nccl" (= RCCL) group with `force_collective=True` issues the module-state broadcast, every 64 MiB
+    bucket all-reduce on RCCL's stream while the backward keeps writing dW / db in place into later buckets, and the used-map
+    exchange; the sum over one rank is the identity, so after two full-size-trunk C3 steps the clipped gradients must equal the
+    no-collective path's to within that path's own run-to-run noise (the weight-gradient kernels' fp32 atomics).  A missing stream
+    dependency between the bucket writers, the pack copy and RCCL's stream would show up here as garbage in a bucket."""
+    import os
+    import torch.distributed as dist
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.scenes import make_scene
+    from styl3r_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        b, v, H = 2, 2, 256
+        sc = make_scene(n_ctx=v, grid_hw=(8, 8), n_views=4, image_hw=(H, H), seed=11)
+        g = torch.Generator(dev).manual_seed(3)
+        ex = lambda t, *shape: t.to(dev)[None].expand(b, *shape).contiguous()
+        batch = dict(context=dict(image=torch.rand(b, v, 3, H, H, device=dev, generator=g) * 2 - 1,
+                                  intrinsics=sc.intrinsics[:1].to(dev).expand(b, v, 3, 3).contiguous()),
+                     target=dict(image=torch.rand(b, 4, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
+                                 intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
+        dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+
+        def run(group, force):
+            torch.manual_seed(0); torch.cuda.manual_seed(0)
+            with torch.device(dev):
+                enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=False)).eval()   # eval: no dropout RNG in the comparison
+            step = TrainStep(enc, dec, dist=group, force_collective=force)
+            assert step.reducer.collective == force
+            losses = [float(step(batch)) for _ in range(2)]
+            flats = [bk["flat"].detach().clone() for bk in step.reducer.buckets]
+            info = dict(synced=step.synced_bytes, buckets=len(flats), unused=len(step.reducer._unused), losses=losses)
+            step.reducer.close()
+            del step, enc
+            torch.cuda.empty_cache()
+            return flats, info
+        a, ia = run(None, False)
+        a2, _ = run(None, False)
+        c, ic = run(dist, True)
+        assert ia["synced"] == 0 and ic["synced"] >= 4 * 1_049_635_033          # the broadcast really went through RCCL
+        assert ic["buckets"] == ia["buckets"] >= 60 and ic["unused"] == ia["unused"] >= 1     # mask_token: unused on "every" rank
+        assert all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(ia["losses"], ic["losses"])), (ia, ic)
+        worst = 0.0
+        for i, (x, x2, y) in enumerate(zip(a, a2, c)):
+            assert torch.isfinite(y).all(), f"bucket {i}"
+            scale = float(x.abs().max())
+            noise = float((x - x2).abs().max())
+            err = float((x - y).abs().max())
+            worst = max(worst, err / max(scale, 1e-30))
+            assert err <= 4 * noise + 1e-6 * scale, (i, err, noise, scale)
+        print(f"  one-rank RCCL vs local: {len(a)} buckets, worst bucket deviation {worst:.2e} of the bucket scale")
+    finally:
+        dist.destroy_process_group()
