@@ -356,13 +356,20 @@ _SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight
 
 def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
-    multiple of 64 with zeros).  Not cached: the ring kernels are experimental and off the default path."""
+    multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
+    key = (id(weight), "block_t" if transposed else "block")
+    hit = _SPLIT_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
     lib = load()
     N, K = weight.shape
     w = weight.detach().contiguous().float()
-    packed = torch.empty(lib.vit_split_weight_block_bytes(N, K, 1 if transposed else 0), dtype=torch.uint8, device=weight.device)
+    nbytes = lib.vit_split_weight_block_bytes(N, K, 1 if transposed else 0)
+    reuse = hit is not None and hit[0]() is weight and hit[3].numel() == nbytes
+    packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     _check(lib.vit_split_weight_block(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight_block")
+    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
     return packed
 
 
@@ -446,9 +453,10 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # (1.2-1.7x) once the 128 x 128 output tiles fill the chip; with fewer tiles it splits K across workgroups (atomics) and is on par down to ~100 tiles, slower below (measured,
 # tools/probes/conv_small.py); smaller problems stay on the library path
 _CONV_X6_MIN_TILES = 100
+_CONV_X6_WGRAD_MIN_PIXELS = 65536   # dW / db on the split-pixel kernel needs this many pixels to split over
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
-CALLS = {"conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
+CALLS = {"linear_x6r": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
          "layernorm_framework": 0, "adapter_hip": 0}
 
 
@@ -507,7 +515,7 @@ class _ConvX6(torch.autograd.Function):
         B_, _, H_, W_ = g.shape
         # dW (+ db) on the bf16x6 split-pixel kernel when there are enough pixels to split (>= 64 x 64 x 16; below that the
         # library's kernel is faster: measured)
-        if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and B_ * H_ * W_ >= 65536:
+        if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and B_ * H_ * W_ >= _CONV_X6_WGRAD_MIN_PIXELS:
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
             CALLS["conv_x6_wgrad"] += 1
@@ -679,6 +687,19 @@ def invalidate_split_cache() -> None:
     _SPLIT_CACHE.clear()
 
 
+# (N, K) -> ring configuration of vit_linear_x6r_fwd, for M >= 4096 rows in bf16x6 mode.  From profiles/r02s_gemm_lab.jsonl (TF, default -> ring):
+# encoder qkv 170 -> 206 (cfg 3: 256 x 256 tiles, ping-pong wave pairs), decoder fc1 174 -> 203, decoder qkv 166 -> 178, encoder fc2
+# 149 -> 165 (cfg 1: 128 x 128 ring).  Every other shape stays on the default kernel (256 x 256 tiles quantise badly at N <= 1024).
+_RING_SHAPES = {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1}
+RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
+
+
+def _ring_cfg(M: int, N: int, K: int) -> int:
+    if not RING_DISPATCH or LINEAR_MODE != "bf16x6" or M < 4096:
+        return 0
+    return _RING_SHAPES.get((N, K), 0)
+
+
 class _FusedLinear(torch.autograd.Function):
     """forward on the hand-written MFMA kernels (f32 or bf16x6); backward in bf16x6 mode: dX with the pre-split transposed
     weight, dW = dY^T X and db in one split-M pass (vit_linear_x6_wgrad); in f32 mode the backward GEMMs are plain library
@@ -700,7 +721,13 @@ class _FusedLinear(torch.autograd.Function):
         w = weight.contiguous().float()
         args = (b.data_ptr() if b is not None else None, res2.data_ptr() if res2 is not None else None, out.data_ptr(),
                 pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
-        if x6:
+        ring = _ring_cfg(M, N, K) if x6 else 0
+        if ring:
+            # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
+            # profiles/r02s_gemm_lab.jsonl measured them faster (six-product mode only: they have no three-product instantiation)
+            CALLS["linear_x6r"] += 1
+            _check(load().vit_linear_x6r_fwd(x2.data_ptr(), split_weight_block(weight).data_ptr(), *args[:-1], ring, args[-1]), "vit_linear_x6r_fwd")
+        elif x6:
             _check(load().vit_linear_x6_fwd(x2.data_ptr(), split_weight(weight).data_ptr(), *args), "vit_linear_x6_fwd")
         else:
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")

@@ -44,7 +44,7 @@ NTHREADS = 8
 # ---- `diff_gaussian_rasterization`, backed by the CPU oracle (both precisions), with autograd ------------------------------
 Settings = namedtuple("GaussianRasterizationSettings", "image_height image_width tanfovx tanfovy bg scale_modifier "
                       "viewmatrix projmatrix projmatrix_raw sh_degree campos prefiltered debug")
-STATES = []          # (FwdState, settings) of every forward, in call order
+STATES = []          # (FwdState, {means, proj}) of every forward, in call order
 
 
 class _OracleRaster(torch.autograd.Function):
@@ -58,7 +58,7 @@ class _OracleRaster(torch.autograd.Function):
                                proj=n(s.projmatrix).reshape(-1), proj_raw=n(s.projmatrix_raw).reshape(-1), campos=n(s.campos),
                                sh_degree=s.sh_degree, nthreads=NTHREADS)
         ctx.orc, ctx.st, ctx.octx = orc, st, octx
-        STATES.append((st, s))
+        STATES.append((st, dict(means=octx["means"].copy(), proj=n(s.projmatrix).reshape(4, 4).copy())))
         T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(means3D.dtype)
         return (T(st.image), torch.from_numpy(st.radii.copy()), T(st.out_depth)[None], T(st.out_opacity)[None],
                 torch.from_numpy(st.n_touched.copy()))
@@ -233,9 +233,9 @@ rel = lambda a, e: float((a.double() - e.double()).abs().max() / e.double().abs(
 # fp32 run survives the mask while > 90 % of the pixels stay in): excluded from the image comparison
 if "--debug-dump" in sys.argv:                                    # mask calibration only (build_tmp/, not shipped)
     import pickle
-    pickle.dump(dict(states=[st for st, _ in states], c32=r32["color"].numpy(), c64=r64["color"].numpy(), ctf=rtf["color"].numpy()),
+    pickle.dump(dict(states=[st for st, _ in states], extra=[e for _, e in states], c32=r32["color"].numpy(), c64=r64["color"].numpy(), ctf=rtf["color"].numpy()),
                 open(ROOT / f"build_tmp/e2e_{TAG}_dbg.pkl", "wb"))
-frag = np.stack([e2e_fragile_mask(st, H, W) for st, _ in states]).reshape(b, -1, H, W)
+frag = np.stack([e2e_fragile_mask(st, H, W, **extra) for st, extra in states]).reshape(b, -1, H, W)
 ok = torch.from_numpy(~frag)[:, :, None].expand_as(r64["color"])
 print("fragile pixel fraction per view:", frag.reshape(frag.shape[1], -1).mean(1))
 

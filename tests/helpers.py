@@ -130,11 +130,15 @@ def closed_form_image(shape):
     return out.float()
 
 
-def e2e_fragile_mask(st, H, W, eps_alpha=5e-3, tie_rel=5e-6, term_rel=0.02, w_min=2e-5):
+def e2e_fragile_mask(st, H, W, eps_alpha=5e-3, tie_rel=5e-6, term_rel=0.02, w_min=2e-5, eps_rect_px=4e-3, means=None, proj=None):
     """Pixels of an oracle render (oracle.gsr_oracle.FwdState) whose value is discontinuity-adjacent when the INPUT Gaussians move
     by what an fp32 evaluation of the encoder moves them (1e-6 .. 1e-5 relative): (i) a contributor whose alpha is within eps_alpha of the
     1/255 cut, (ii) two consecutive visible contributors whose depths differ by less than tie_rel (their order may swap), (iii) the
-    termination test T < 1e-4 decided within term_rel -- each only where the flip could move the pixel by more than w_min.
+    termination test T < 1e-4 decided within term_rel -- each only where the flip could move the pixel by more than w_min; (iv) the
+    tile rectangle: tile t is listed for a Gaussian iff 16 t + 1 <= p + r (A1.7: `(int)((p + r + 15) / 16)`), so a splat whose p + r
+    sits within eps_rect_px of 16 t + 1 gains or loses the first pixel columns / rows of tile t, where its alpha can be far above 1/255
+    -- including splats the golden run SKIPPED because their rectangle was empty (centre 2 .. 3 px outside the left / top image edge:
+    `means` (G,3) and the row-vector `proj` (4,4) of the view let the mask find those).
     Used by the fixture generator only; the mask is stored with the fixture."""
     gx, gy = (W + 15) // 16, (H + 15) // 16
     frag = np.zeros((H, W), bool)
@@ -177,4 +181,49 @@ def e2e_fragile_mask(st, H, W, eps_alpha=5e-3, tie_rel=5e-6, term_rel=0.02, w_mi
         tie = contrib & has_prev & ((d - d_prev) < tie_rel * d) & (T_prev * a_prev * alpha > w_min)
         bad = (near_thr | near_term | tie).any(0)
         frag[py.astype(int), px.astype(int)] |= bad
+    # (iv) tile-rectangle membership
+    vis = np.nonzero(st.radii > 0)[0]
+    r = st.radii[vis].astype(np.float64)
+    for axis, n_px, n_tiles in ((0, W, gx), (1, H, gy)):
+        p = xy[vis, axis]
+        hi = (p + r + 15.0) / 16.0
+        k = np.rint(hi)
+        near = (np.abs(hi - k) * 16.0 < eps_rect_px) & (k >= 1) & (k <= n_tiles)
+        for g, kk in zip(vis[near], k[near].astype(int)):
+            rr = float(st.radii[g])
+            a0 = 16 * (kk - 1)                                     # first column (row) of the tile that toggles
+            strip = np.arange(a0, min(a0 + 3, n_px))
+            o = 1 - axis
+            other = np.arange(max(int(np.floor(xy[g, o] - rr)), 0), min(int(np.ceil(xy[g, o] + rr)) + 1, H if o == 1 else W))
+            if len(strip) == 0 or len(other) == 0:
+                continue
+            ss, oo = np.meshgrid(strip, other)
+            dxx = xy[g, 0] - (ss if axis == 0 else oo); dyy = xy[g, 1] - (oo if axis == 0 else ss)
+            pw = -0.5 * (co[g, 0] * dxx * dxx + co[g, 2] * dyy * dyy) - co[g, 1] * dxx * dyy
+            hit = (pw <= 0) & (co[g, 3] * np.exp(np.minimum(pw, 0)) >= 0.5 * thr)
+            xs_, ys_ = (ss, oo) if axis == 0 else (oo, ss)
+            frag[ys_[hit], xs_[hit]] = True
+    if means is not None:
+        # splats without a rectangle in the golden run (radii == 0): off the left / top edge by about their radius.  Their conic is not
+        # in the state; every splat of these scenes has radius 2 .. 4, so all three are tried and a (2 r + 1)-pixel run is excluded
+        m = np.asarray(means, np.float64); P = np.asarray(proj, np.float64).reshape(4, 4)
+        hom = np.concatenate([m, np.ones((len(m), 1))], 1) @ P
+        pw = 1.0 / (hom[:, 3] + 1e-7)
+        pp = np.stack([((hom[:, 0] * pw + 1.0) * W - 1.0) / 2.0, ((hom[:, 1] * pw + 1.0) * H - 1.0) / 2.0], 1)
+        skipped = np.nonzero((st.radii == 0) & (hom[:, 3] > 0.2))[0]
+        for axis, n_px in ((0, W), (1, H)):
+            o = 1 - axis
+            n_o = H if o == 1 else W
+            for rr in (2.0, 3.0, 4.0):
+                near = np.abs(pp[skipped, axis] + rr - 1.0) < eps_rect_px
+                for g in skipped[near]:
+                    c = pp[g, o]
+                    if c < -rr or c > n_o - 1 + rr:
+                        continue
+                    other = np.arange(max(int(np.floor(c - rr)), 0), min(int(np.ceil(c + rr)) + 1, n_o))
+                    for a in range(0, min(3, n_px)):
+                        if axis == 0:
+                            frag[other, a] = True
+                        else:
+                            frag[a, other] = True
     return frag

