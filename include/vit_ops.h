@@ -200,6 +200,30 @@ int vit_relu_dropout_fwd(const float *x, float *y, int64_t n, float p, uint64_t 
 int vit_relu_dropout_bwd(const float *y, const float *g, float *dx, int64_t n, float p, void *stream);
 
 /*
+ * The tail of every DPT head -- ReLU [-> Dropout(p)] -> Conv2d(C, CO, kernel_size = 1) with CO = 3 or 8 output channels
+ * (heads/dpt_block.py:319-320 'regression', :337-339 'gs_params') -- as ONE pass over the (B, C, H, W) activation each way
+ * (csrc/vit_head_tail.hip; HBM-bound: 4 B C HW bytes read forward, 8 B C HW moved backward):
+ *   y (B, CO, HW) = bias + W (CO, C) . a(h),   a(h) = keep max(h, 0) / (1 - p), keep from the generator of vit_relu_dropout_fwd
+ *   dh = a'(h) W^T dy,   dw (CO, C) = sum dy a(h)^T,   db (CO) = sum dy       (dw / db are zeroed by the call, then accumulated with atomics)
+ * h is the raw (pre-ReLU) output of the convolution in front; nothing else is stored for the backward.  C % 8 == 0, C <= 256, HW % 4 == 0,
+ * p = 0 selects plain ReLU (the seed is ignored).  Any other CO: VIT_EINVAL (callers keep the separate ReLU / Dropout / convolution kernels).
+ */
+int vit_head_tail_fwd(const float *h, const float *w, const float *bias, float *y, int B, int C, int CO, int64_t HW, float p, uint64_t seed,
+                      void *stream);
+int vit_head_tail_bwd(const float *h, const float *w, const float *dy, float *dh, float *dw, float *db, int B, int C, int CO, int64_t HW,
+                      float p, uint64_t seed, void *stream);
+
+/*
+ * Pieces of the 'gs' head's input merger, `feat_up(path_1) + ReLU(Conv2d(3, 256, 7, 1, 3)(imgs))` (dpt_gs_head.py:113-118,146-148):
+ * vit_im2col7 writes the 7x7 / padding-3 patches of a (B, 3, H, W) image as (B, 160, H, W) planes (147 taps in the weight's
+ * (ci, ky, kx) order + 13 zero planes), over which the convolution is a 1x1 convolution on vit_conv_x6_fwd / vit_conv_x6_wgrad;
+ * vit_upsample2x_add_relu_fwd = vit_upsample2x_fwd + max(addend, 0) in the same pass (addend: the convolution's pre-activation,
+ * shape of the output).  W % 4 == 0.
+ */
+int vit_im2col7(const float *img, float *cols, int B, int H, int W, void *stream);
+int vit_upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, void *stream);
+
+/*
  * Head tails + Gaussian adapter in one pass: reg_dense_depth(mode='exp') (postprocess.py:22-60),
  * sigmoid + map_pdf_to_opacity (encoder_noposplat_multi_token_style.py:115-128,205-209), UnifiedGaussianAdapter.forward
  * (gaussian_adapter.py:122-153) and build_covariance / quaternion_to_matrix (gaussians.py:8-44), from the DPT heads' NCHW

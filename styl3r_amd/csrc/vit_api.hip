@@ -27,6 +27,12 @@ int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *
 int layernorm_bwd(const float *dy, const float *x, const float *mean, const float *rstd, const float *gamma, const float *dskip,
                   float *dx, float *dgamma, float *dbeta, float *scratch, int M, int C, int accumulate, hipStream_t stream);
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
+int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, hipStream_t stream);
+int im2col7(const float *img, float *cols, int B, int H, int W, hipStream_t stream);
+int head_tail_fwd(const float *h, const float *w, const float *bias, float *y, int B, int C, int CO, int64_t HW, float p, uint64_t seed,
+                  hipStream_t stream);
+int head_tail_bwd(const float *h, const float *w, const float *dy, float *dh, float *dw, float *db, int B, int C, int CO, int64_t HW, float p,
+                  uint64_t seed, hipStream_t stream);
 int adapter_fwd(const VitAdapterArgs *a, float *means, float *cov, float *sh, float *opac, float *scales, float *rot, hipStream_t s);
 int adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *d_cov, const float *d_sh, const float *d_opac,
                 float *d_pts0, float *d_ptsr, float *d_par0, float *d_parr, float *d_app, hipStream_t s);
@@ -179,6 +185,28 @@ VIT_EXPORT int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, i
 VIT_EXPORT int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream)
 {
     return vit::upsample2x_bwd(dout, din, planes, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, void *stream)
+{
+    return vit::upsample2x_add_relu_fwd(in, addend, out, planes, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_im2col7(const float *img, float *cols, int B, int H, int W, void *stream)
+{
+    return vit::im2col7(img, cols, B, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_head_tail_fwd(const float *h, const float *w, const float *bias, float *y, int B, int C, int CO, int64_t HW, float p,
+                                 uint64_t seed, void *stream)
+{
+    return vit::head_tail_fwd(h, w, bias, y, B, C, CO, HW, p, seed, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_head_tail_bwd(const float *h, const float *w, const float *dy, float *dh, float *dw, float *db, int B, int C, int CO,
+                                 int64_t HW, float p, uint64_t seed, void *stream)
+{
+    return vit::head_tail_bwd(h, w, dy, dh, dw, db, B, C, CO, HW, p, seed, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_adapter_fwd(const VitAdapterArgs *a, float *means, float *cov, float *sh, float *opac, float *scales, float *rot,

@@ -860,7 +860,7 @@ int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int
     const int R = ksize * ksize * Ci;
     const int tiles = ((Co + x6::BM - 1) / x6::BM) * ((R + 127) / 128);
     const int nslab = B * (H * W / x6::BK);
-    int S = split_count(tiles, nslab, 32);
+    int S = split_count(tiles, nslab, 32);   // (r03: 8 / 4 slabs per split measured slower at every DPT shape -- more atomic passes over the tile)
     const bool three = x6_products() == 3;
     (void)hipGetLastError();
     if (hipMemsetAsync(dw, 0, (size_t)Co * R * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }

@@ -13,8 +13,11 @@ namespace vit {
 extern thread_local hipError_t g_last_hip_error;
 
 #pragma clang fp contract(off)
-__global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in, float *__restrict__ out, int64_t planes, int H,
-                                                    int W, float rh, float rw)
+// ADD: out = upsample(in) + max(addend, 0) -- the 'gs' head's `feat_up(path_1) + input_merger(imgs)` (dpt_gs_head.py:146-148) with the
+// input merger's ReLU applied while its pre-activation is read, in the same pass that writes the up-sampled map
+template <bool ADD>
+__global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in, const float *__restrict__ addend, float *__restrict__ out,
+                                                    int64_t planes, int H, int W, float rh, float rw)
 {
     const int OH = 2 * H, OW = 2 * W, OW4 = OW >> 2;
     const int64_t total = planes * OH * OW4;
@@ -37,7 +40,42 @@ __global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in
             const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
             po[e] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
         }
+        if (ADD) {
+            const float4 c = *reinterpret_cast<const float4 *>(addend + (pl * OH + oy) * OW + ox4 * 4);
+            o.x += fmaxf(c.x, 0.f); o.y += fmaxf(c.y, 0.f); o.z += fmaxf(c.z, 0.f); o.w += fmaxf(c.w, 0.f);
+        }
         *reinterpret_cast<float4 *>(out + (pl * OH + oy) * OW + ox4 * 4) = o;
+    }
+}
+
+// 7x7 / stride 1 / padding 3 patches of a 3-channel image as 160 "channels" (147 = 3 x 7 x 7 taps in the weight's (ci, ky, kx)
+// order + 13 zero channels: the bf16x6 convolution kernels contract over multiples of 16): the `input_merger` convolution
+// Conv2d(3, 256, 7, 1, 3) (dpt_gs_head.py:113-118) then IS a 1x1 convolution over these planes on vit_conv_x6_fwd / _wgrad.
+__global__ void __launch_bounds__(256) k_im2col7(const float *__restrict__ img, float *__restrict__ cols, int B, int H, int W)
+{
+    const int W4 = W >> 2;
+    const int64_t total = (int64_t)B * 160 * H * W4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(idx % W4);
+        int64_t t = idx / W4;
+        const int y = (int)(t % H); t /= H;
+        const int k = (int)(t % 160);
+        const int64_t b = t / 160;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < 147) {
+            const int ci = k / 49, r = k - ci * 49, ky = r / 7, kx = r - ky * 7;
+            const int ys = y + ky - 3;
+            if (ys >= 0 && ys < H) {
+                const float *row = img + ((b * 3 + ci) * H + ys) * (int64_t)W;
+                float *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xs = x4 * 4 + e + kx - 3;
+                    po[e] = (xs >= 0 && xs < W) ? row[xs] : 0.f;
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(cols + ((b * 160 + k) * H + y) * (int64_t)W + x4 * 4) = o;
     }
 }
 // Backward as a GATHER (the framework scatters with atomics): input pixel (iy, ix) collects w_y * w_x * dout from the
@@ -116,8 +154,34 @@ int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hi
     const int64_t total = planes * 2 * H * (2 * W / 4);
     const int64_t blocks = (total + 255) / 256;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_upsample2x, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in, out, planes,
-                       H, W, rh, rw);
+    hipLaunchKernelGGL(k_upsample2x<false>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in,
+                       (const float *)nullptr, out, planes, H, W, rh, rw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, hipStream_t stream)
+{
+    if (!in || !addend || !out || planes <= 0 || H <= 0 || W <= 0 || (W & 1)) return VIT_EINVAL;
+    const float rh = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, rw = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
+    const int64_t total = planes * 2 * H * (2 * W / 4);
+    const int64_t blocks = (total + 255) / 256;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_upsample2x<true>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in, addend,
+                       out, planes, H, W, rh, rw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int im2col7(const float *img, float *cols, int B, int H, int W, hipStream_t stream)
+{
+    if (!img || !cols || B <= 0 || H <= 0 || W <= 0 || (W & 3)) return VIT_EINVAL;
+    const int64_t total = (int64_t)B * 160 * H * (W >> 2);
+    const int64_t blocks = (total + 255) / 256;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_im2col7, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, img, cols, B, H, W);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

