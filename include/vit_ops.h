@@ -59,6 +59,10 @@ typedef struct VitAttnArgs {
     const int64_t *qpos, *kpos;       /* (B,Nq,2) / (B,Nk,2) or NULL */
     const float *cos_tab, *sin_tab;   /* (P,16) or NULL */
     int32_t P;
+    /* vit_attention_bwd only: token stride (in floats) of the gradient outputs dq / (dk, dv); 0 = H * 64, i.e. contiguous
+     * (B,N,H,64) tensors.  3 * H * 64 with dq, dk, dv pointing at planes 0 / 1 / 2 of ONE (B,N,3,H,64) buffer writes the gradient
+     * of a packed qkv projection in place (no select_backward fills / copies / adds behind the kernel). */
+    int64_t dq_sn, dkv_sn;
 } VitAttnArgs;
 
 int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,
@@ -115,7 +119,8 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
  * packed[row / 64][k / 8][piece][row % 64][8] bf16 written by vit_split_weight_block (rows padded to a multiple of 64 with
  * zeros; vit_split_weight_block_bytes gives the size).  cfg: 1 = 128 x 128 ring, 2 = 256 x 256 ring, 3 = 256 x 256 with one
  * conversion per workgroup and ping-pong wave pairs, K % 16 == 0.  Experimental: measured against vit_linear_x6_fwd in
- * DESIGN.md 9.2, not used by the default path.
+ * DESIGN.md 9.2; the Python layer dispatches the six-product Linear to cfg 3 / cfg 1 on the shapes where they measured faster
+ * (styl3r_amd/vit_ops.py `_RING_SHAPES`).
  */
 size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);
 int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
@@ -131,6 +136,9 @@ size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits);
 int vit_linear_x6c_choose_splits(int M, int N, int K);
 int vit_linear_x6c_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                        int M, int N, int K, int act, int splits, void *workspace, size_t workspace_bytes, void *stream);
+/* act: 0 = none, 1 = exact GELU (optionally storing the pre-activation in `pre`), 2 = out = (x . W^T) * gelu'(residual): the
+ * input-gradient GEMM of the layer behind a GELU with the GELU's backward in its epilogue (`residual` = the saved pre-activation of the
+ * GELU, no bias, `pre` must be NULL) -- the separate GeluBackward pass over the (M, 4 dim) hidden gradient disappears. */
 int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                       int M, int N, int K, int act, void *stream);
 

@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(256) k_attn_bwd_kv(VitAttnArgs a, const float 
             unrotate(dk0, dk1, half, pp[0], pp[1], a.cos_tab, a.sin_tab);
         }
         // dk, dv contiguous (B,Nk,H,64)
-        float *dkr = dk + (((int64_t)b * a.Nk + key0 + col) * a.H + h) * HD;
-        float *dvr = dv + (((int64_t)b * a.Nk + key0 + col) * a.H + h) * HD;
+        float *dkr = dk + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD;
+        float *dvr = dv + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int d = 8 * gq + 4 * half;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, 3) k_attn_bwd_q(VitAttnArgs a, const floa
             const int64_t *pp = a.qpos + ((int64_t)b * a.Nq + q0 + col) * 2;
             unrotate(dq0, dq1, half, pp[0], pp[1], a.cos_tab, a.sin_tab);
         }
-        float *dqr = dq + (((int64_t)b * a.Nq + q0 + col) * a.H + h) * HD;   // contiguous (B,Nq,H,64)
+        float *dqr = dq + ((int64_t)b * a.Nq + q0 + col) * (a.dq_sn ? a.dq_sn : (int64_t)a.H * HD) + h * HD;   // (B,Nq,H,64), token stride dq_sn
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int d = 8 * gq + 4 * half;

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
             const int64_t *pp = a.qpos + ((int64_t)b * a.Nq + q0 + col) * 2;
             unrotate(dq0, dq1, half, pp[0], pp[1], a.cos_tab, a.sin_tab);
         }
-        store_64(dq + (((int64_t)b * a.Nq + q0 + col) * a.H + h) * HD, dq0, dq1, half);   // contiguous (B,Nq,H,64)
+        store_64(dq + ((int64_t)b * a.Nq + q0 + col) * (a.dq_sn ? a.dq_sn : (int64_t)a.H * HD) + h * HD, dq0, dq1, half);   // (B,Nq,H,64), token stride dq_sn
     }
 }
 
@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
             unrotate(dk0, dk1, half, pp[0], pp[1], a.cos_tab, a.sin_tab);
         }
         // dk, dv contiguous (B,Nk,H,64)
-        store_64(dk + (((int64_t)b * a.Nk + key0 + col) * a.H + h) * HD, dk0, dk1, half);
-        store_64(dv + (((int64_t)b * a.Nk + key0 + col) * a.H + h) * HD, dv0, dv1, half);
+        store_64(dk + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD, dk0, dk1, half);
+        store_64(dv + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD, dv0, dv1, half);
     }
 }
 }  // namespace abx6

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q_tail(VitAttnArgs a, const flo
     __syncthreads();
     float r = tot;
     if (ROPE) r = rope_feature(s_raw, lane, py, px, a.cos_tab, a.sin_tab, -1.f);   // inverse rotation
-    dq[(((int64_t)b * a.Nq + qi) * a.H + h) * HD + lane] = r;
+    dq[((int64_t)b * a.Nq + qi) * (a.dq_sn ? a.dq_sn : (int64_t)a.H * HD) + h * HD + lane] = r;
 }
 
 // ---- backward, key side: dK[kj] = sum_i dS_i q_i , dV[kj] = sum_i P_i dO_i over ALL queries i ----
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv_tail(VitAttnArgs a, const fl
     float tv = 0.f;
 #pragma unroll 8
     for (int l2 = 0; l2 < 64; ++l2) tv += s_acc[l2 * 65 + lane];
-    dv[(((int64_t)b * a.Nk + kj) * a.H + h) * HD + lane] = tv;
+    dv[((int64_t)b * a.Nk + kj) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD + lane] = tv;
     __syncthreads();
     // dK (w.r.t. the rotated key), then rotate back
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv_tail(VitAttnArgs a, const fl
     __syncthreads();
     float r = tk;
     if (ROPE) r = rope_feature(s_raw, lane, py, px, a.cos_tab, a.sin_tab, -1.f);
-    dk[(((int64_t)b * a.Nk + kj) * a.H + h) * HD + lane] = r;
+    dk[((int64_t)b * a.Nk + kj) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD + lane] = r;
 }
 }  // namespace tail
 

@@ -61,6 +61,11 @@ __device__ inline void tile_of_block(int bid, int tiles_m, int tiles_n, int &tm,
 }
 
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// d/dx of the exact GELU: Phi(x) + x phi(x)   (aten's GeluBackward, approximate = "none")
+__device__ inline float gelu_grad_exact(float x)
+{
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 // two fp32 values -> their three bf16 pieces, each packed (lo = first value)
 __device__ inline void split2(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2)
@@ -225,6 +230,10 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
                 if (SPLITK) {
                     if (residual && first) t += residual[o];
                     atomicAdd(out + o, t);
+                    continue;
+                }
+                if (ACT == 2) {          // input-gradient GEMM of the layer BEHIND a GELU: out = (dY . W) * gelu'(pre), `residual` carries pre
+                    out[o] = t * gelu_grad_exact(residual[o]);
                     continue;
                 }
                 if (pre) pre[o] = t;
@@ -767,7 +776,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
                   int K, int act, hipStream_t stream)
 {
     if (!x || !wp || !out) return VIT_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % x6::BK) != 0 || act < 0 || act > 1) return VIT_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6::BK) != 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre))) return VIT_EINVAL;
     const int tm = (M + x6::BM - 1) / x6::BM;
     const bool narrow = tm * ((N + 127) / 128) < 640;
     const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
@@ -793,6 +802,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
         else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);      \
     } while (0)
         if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
+        else if (act == 2) { if (narrow) VIT_LAUNCH_X6(2, 1); else VIT_LAUNCH_X6(2, 2); }
         else { if (narrow) VIT_LAUNCH_X6(0, 1); else VIT_LAUNCH_X6(0, 2); }
 #undef VIT_LAUNCH_X6
     }

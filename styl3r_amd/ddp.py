@@ -182,13 +182,20 @@ class BucketedGradReducer:
         for p in self._unused:
             p.grad = None
 
-    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+    def clip_grad_norm_(self, max_norm: float, defer_to: Optional[torch.optim.Optimizer] = None) -> torch.Tensor:
         """torch.nn.utils.clip_grad_norm_ (L2, eps 1e-6, coefficient clamped to 1) evaluated on the flat buckets:
-        one norm + one scale per bucket instead of one per parameter.  Call after finish()."""
+        one norm + one scale per bucket instead of one per parameter.  Call after finish().
+        `defer_to`: a FUSED Adam / AdamW whose next step() applies the coefficient itself -- its kernel divides every gradient by
+        `optimizer.grad_scale` while it reads it (the hook torch.amp's GradScaler uses), so the separate read-modify-write pass over
+        the 4.2 GB of gradients disappears; the stored gradients are then scaled by that step, not by this call."""
         flats = [b["flat"] for b in self.buckets]
         total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(flats)))
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        torch._foreach_mul_(flats, coef)
+        if defer_to is not None and defer_to.defaults.get("fused"):
+            defer_to.grad_scale = (1.0 / coef).reshape(1).float()          # g / grad_scale == g * coef
+            defer_to.found_inf = torch.zeros(1, dtype=torch.float32, device=coef.device)
+        else:
+            torch._foreach_mul_(flats, coef)
         return total
 
     def bucket_sizes_bytes(self) -> List[int]:

@@ -120,10 +120,17 @@ class PatchEmbedDust3R(nn.Module):
     def forward(self, x: Tensor):
         B, C, H, W = x.shape
         assert H % self.patch_size[0] == 0 and W % self.patch_size[1] == 0, "image size must be a multiple of the patch size"
-        x = _PackGrad.apply(self.proj(x))
-        h, w = x.shape[2], x.shape[3]
+        ph, pw = self.patch_size
+        h, w = H // ph, W // pw
         pos = torch.cartesian_prod(torch.arange(h, device=x.device), torch.arange(w, device=x.device))
         pos = pos.view(1, h * w, 2).expand(B, -1, 2).clone()
+        if x.is_cuda and x.dtype == torch.float32 and (C * ph * pw) % 16 == 0:
+            # kernel == stride: the convolution is a Linear over the (B h w, C ph pw) patch rows (row order = the weight's (c, i, j)
+            # order), on the bf16x6 kernels forward and backward; no library convolution, no NCHW -> token transpose behind it
+            rows = x.reshape(B, C, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C * ph * pw)
+            tok = _tok_linear(rows, self.proj.weight.reshape(self.proj.out_channels, C * ph * pw), self.proj.bias)
+            return tok.reshape(B, h * w, self.proj.out_channels), pos
+        x = _PackGrad.apply(self.proj(x))
         return x.flatten(2).transpose(1, 2), pos
 
 
@@ -349,6 +356,22 @@ class _Up2(nn.Module):
         return upsample2x(x)
 
 
+_TAP_INDEX: dict = {}
+
+
+def _stride2_tap_index(nh: int, nw: int, device) -> Tensor:
+    """flat source index into the (nh * nw + 1)-row token grid (last row = zero padding) of tap (di, dj) of output pixel (oy, ox) of a
+    3x3 / stride 2 / padding 1 convolution, laid out [(oy, ox), (di, dj)]"""
+    key = (nh, nw, str(device))
+    if key not in _TAP_INDEX:
+        oh, ow = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
+        oy, ox, di, dj = torch.meshgrid(torch.arange(oh), torch.arange(ow), torch.arange(3), torch.arange(3), indexing="ij")
+        sy, sx = 2 * oy + di - 1, 2 * ox + dj - 1
+        inside = (sy >= 0) & (sy < nh) & (sx >= 0) & (sx < nw)
+        _TAP_INDEX[key] = torch.where(inside, sy * nw + sx, torch.full_like(sy, nh * nw)).reshape(-1).to(device)
+    return _TAP_INDEX[key]
+
+
 def _tok_linear(x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
     """x . w^T + bias on the fused bf16x6 Linear (device fp32, contraction a multiple of 16), the framework's otherwise"""
     if x.is_cuda and x.dtype == torch.float32 and w.shape[1] % 16 == 0:
@@ -412,10 +435,13 @@ class DPTAdapter(nn.Module):
             return y.reshape(B, nh, nw, C1).permute(0, 3, 1, 2).contiguous()
         cv = seq[1]                                                                       # 3x3, stride 2, padding 1
         oh, ow = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
-        xp = torch.nn.functional.pad(y.reshape(B, nh, nw, C1), (0, 0, 1, 1, 1, 1))
-        cols = torch.cat([xp[:, di:di + 2 * oh - 1:2, dj:dj + 2 * ow - 1:2, :] for di in range(3) for dj in range(3)], dim=-1)
+        # the nine taps of every output pixel with ONE gather (row nh * nw of the padded grid is the zero padding): forward = one index
+        # kernel, backward = one index_add -- not nine slices with a fill + copy + add each
+        idx = _stride2_tap_index(nh, nw, y.device)                                        # (oh * ow * 9,)
+        grid = torch.cat([y.reshape(B, nh * nw, C1), y.new_zeros(B, 1, C1)], dim=1)
+        cols = grid[:, idx].reshape(B * oh * ow, 9 * C1)
         w = cv.weight.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * C1)               # [co, (tap, ci)]
-        z = _tok_linear(cols.reshape(B * oh * ow, 9 * C1), w, cv.bias)
+        z = _tok_linear(cols, w, cv.bias)
         return z.reshape(B, oh, ow, cv.out_channels).permute(0, 3, 1, 2).contiguous()
 
     def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None) -> Tensor:

@@ -104,7 +104,7 @@ class TrainStep:
         total.backward()
         self.reducer.finish()
         if self.clip is not None:                                         # Trainer(gradient_clip_val=0.5), main_style.py:110
-            self.reducer.clip_grad_norm_(self.clip)
+            self.reducer.clip_grad_norm_(self.clip, defer_to=self.optimizer)    # the fused AdamW applies the coefficient while it reads the gradients
         self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()

@@ -18,16 +18,16 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from .vit_ops import LayerNorm, fused_linear, memory_efficient_attention
+from .vit_ops import GeluLink, LayerNorm, attention_qkv, fused_linear, memory_efficient_attention
 
 # Linear layers of the blocks run on the fused kernels (bias / exact GELU / residual in the epilogue); set to False to route
 # them through torch.nn.functional.linear (hipBLASLt) instead (tools/bench_train.py --torch-linear: an A/B switch).
 USE_FUSED_LINEAR = True
 
 
-def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False, link=None, link_in=None) -> Tensor:
     if USE_FUSED_LINEAR and x.is_cuda and layer.in_features % 16 == 0:
-        return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu)
+        return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu, link=link, link_in=link_in)
     y = torch.nn.functional.linear(x, layer.weight, layer.bias)
     if gelu:
         y = torch.nn.functional.gelu(y)
@@ -53,7 +53,8 @@ class Mlp(nn.Module):
 
     def forward(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         if isinstance(self.act, nn.GELU) and self.act.approximate == "none":
-            return _linear(self.fc2, _linear(self.fc1, x, gelu=True), residual=residual)
+            link = GeluLink() if torch.is_grad_enabled() else None     # GELU' runs inside fc2's input-gradient GEMM (vit_ops.GeluLink)
+            return _linear(self.fc2, _linear(self.fc1, x, gelu=True, link=link), residual=residual, link_in=link)
         y = self.fc2(self.act(self.fc1(x)))
         return y if residual is None else residual + y
 
@@ -71,6 +72,11 @@ class Attention(nn.Module):
     def forward(self, x: Tensor, xpos: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         B, N, C = x.shape
         qkv = _linear(self.qkv, x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        if qkv.is_cuda and qkv.dtype == torch.float32:
+            # packed path: the kernels read the three planes in place and the backward writes ONE (B,N,3,H,64) gradient
+            o = attention_qkv(qkv, self.scale, xpos if self.rope is not None else None,
+                              self.rope.freq if self.rope is not None else 100.0, self.rope.max_pos if self.rope is not None else 64)
+            return _linear(self.proj, o.reshape(B, N, C), residual=residual)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B,N,H,64) views, no copies
         if self.rope is not None:
             o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=xpos, kpos=xpos, rope_base=self.rope.freq,

@@ -76,7 +76,7 @@ class VitAttnArgs(C.Structure):
                 ("v_sb", C.c_int64), ("v_sn", C.c_int64), ("v_sh", C.c_int64),
                 ("o_sb", C.c_int64), ("o_sn", C.c_int64), ("o_sh", C.c_int64),
                 ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
-                ("P", C.c_int32)]
+                ("P", C.c_int32), ("dq_sn", C.c_int64), ("dkv_sn", C.c_int64)]
 
 
 def load() -> C.CDLL:
@@ -320,6 +320,55 @@ class _Attention(torch.autograd.Function):
                                      lse.data_ptr(), g.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                      delta.data_ptr(), _stream(q.device)), "vit_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
+
+
+class _AttentionQKV(torch.autograd.Function):
+    """Self-attention on a PACKED projection qkv (B,N,3,H,64) (blocks.py:100-103: `self.qkv(x).reshape(B, N, 3, H, C // H)`): the same
+    kernels as `_Attention` on the three strided planes, but the backward writes dq, dk, dv straight into the planes of ONE
+    (B,N,3,H,64) gradient (VitAttnArgs.dq_sn / dkv_sn) -- autograd's select_backward (a zero fill + a copy per plane) and the two adds
+    that assembled that tensor from three contiguous gradients were 6.5 ms of a 328 ms C3 step."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, pos, base, max_pos):
+        _need_gpu(qkv, "attention")
+        _sync_attention_arith()
+        qkv = qkv.contiguous()
+        B, N, three, H, D = qkv.shape
+        assert three == 3
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        out = torch.empty((B, N, H, D), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        rope = (pos, pos, base, max_pos) if pos is not None else None
+        a, keep = _attn_args(q, k, v, out, scale, rope)
+        _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                        lse.data_ptr(), _stream(qkv.device)), "vit_attention_fwd")
+        ctx.save_for_backward(qkv, out, lse, pos)
+        ctx.cfg = (scale, base, max_pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse, pos = ctx.saved_tensors
+        scale, base, max_pos = ctx.cfg
+        _sync_attention_arith()
+        g = g.contiguous()
+        B, N, _, H, D = qkv.shape
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        dqkv = torch.empty_like(qkv)
+        rope = (pos, pos, base, max_pos) if pos is not None else None
+        a, keep = _attn_args(q, k, v, out, scale, rope)
+        a.dq_sn = a.dkv_sn = 3 * H * D
+        delta = torch.empty_like(lse)
+        base_ptr, plane = dqkv.data_ptr(), H * D * 4
+        _check(load().vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                        lse.data_ptr(), g.data_ptr(), base_ptr, base_ptr + plane, base_ptr + 2 * plane,
+                                        delta.data_ptr(), _stream(qkv.device)), "vit_attention_bwd")
+        return dqkv, None, None, None, None
+
+
+def attention_qkv(qkv: Tensor, scale: float, pos: Optional[Tensor] = None, rope_base: float = 100.0, max_pos: int = 64) -> Tensor:
+    """softmax(q k^T scale) v for a packed (B,N,3,H,64) projection, 2-D RoPE on q and k inside the kernel when `pos` is given"""
+    return _AttentionQKV.apply(qkv, float(scale), pos, rope_base, max_pos)
 
 
 def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[float] = None, p: float = 0.0,
@@ -828,7 +877,7 @@ class _FusedLinear(torch.autograd.Function):
     GEMMs through torch / hipBLASLt."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act):
+    def forward(ctx, x, weight, bias, residual, act, link=None, link_in=None):
         _need_gpu(x, "linear")
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous().float()
@@ -854,6 +903,11 @@ class _FusedLinear(torch.autograd.Function):
         else:
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
         ctx.save_for_backward(x2, w, pre)
+        # GeluLink: `link` (this layer applies the GELU) publishes its pre-activation; `link_in` (this layer consumes that GELU's
+        # output) lets the backward run GELU' inside its input-gradient GEMM -- see GeluLink
+        ctx.link, ctx.link_in = (link if (x6 and need_pre) else None), (link_in if x6 else None)
+        if ctx.link is not None:
+            ctx.link.pre, ctx.link.fused = pre, False
         ctx.weight_ref = weight if x6 else None
         ctx.weight_version = weight._version      # dX re-splits the LIVE parameter: it must still be the forward's value
         ctx.bias_ref = bias if x6 else None
@@ -869,7 +923,7 @@ class _FusedLinear(torch.autograd.Function):
                                "EMA under retain_graph?); dX would be computed with the new value")
         g2 = g.reshape(-1, g.shape[-1])
         g_res = g if has_res else None
-        if act == 1:
+        if act == 1 and not (ctx.link is not None and ctx.link.fused):     # (fused: the layer behind already multiplied by GELU')
             g2 = torch.ops.aten.gelu_backward(g2.contiguous(), pre, approximate="none")
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = None
@@ -878,9 +932,14 @@ class _FusedLinear(torch.autograd.Function):
             if ctx.weight_ref is not None and N % 16 == 0:
                 g2c = g2.contiguous().float()
                 dx = torch.empty((g2c.shape[0], K), dtype=torch.float32, device=g.device)
-                _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None, None,
-                                                dx.data_ptr(), None, g2c.shape[0], K, N, 0, _stream(g.device)),
+                lk = ctx.link_in
+                gelu_pre = lk.pre if (lk is not None and lk.pre is not None and tuple(lk.pre.shape) == (g2c.shape[0], K)) else None
+                _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None,
+                                                gelu_pre.data_ptr() if gelu_pre is not None else None,
+                                                dx.data_ptr(), None, g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, _stream(g.device)),
                        "vit_linear_x6_fwd (dX)")
+                if gelu_pre is not None:
+                    lk.fused = True
                 dx = dx.reshape(shp)
             else:
                 dx = (g2 @ w).reshape(shp)
@@ -905,7 +964,7 @@ class _FusedLinear(torch.autograd.Function):
                 db = bslot["view"].detach()
             if has_bias and need_b and bslot is None:
                 db = g2.sum(0)
-            return dx, dw, db, g_res, None
+            return dx, dw, db, g_res, None, None, None
         if need_w and ctx.weight_ref is not None:         # dW (+ db in the same pass) on the bf16x6 kernel
             g2c = g2.contiguous().float()
             N, K = w.shape
@@ -919,12 +978,23 @@ class _FusedLinear(torch.autograd.Function):
             dw = g2.t() @ x2 if need_w else None          # frozen layers (style stage) skip the weight GEMM
         if db is None and has_bias and need_b:
             db = g2.sum(0)
-        return dx, dw, db, g_res, None
+        return dx, dw, db, g_res, None, None, None
+
+
+class GeluLink:
+    """Ties the two Linear layers of an Mlp (fc1 -> GELU -> fc2, blocks.py:76-82) together for the backward: fc1's node publishes
+    the GELU's pre-activation here, fc2's node -- whose input-gradient GEMM produces exactly the gradient of the GELU's output -- runs
+    GELU'(pre) in that GEMM's epilogue (vit_linear_x6_fwd act = 2) and sets `fused`; fc1's node then skips its GeluBackward pass.  Valid
+    only when the GELU's output feeds NOTHING but that fc2 (true inside Mlp: the hidden tensor is local to its forward)."""
+    __slots__ = ("pre", "fused")
+
+    def __init__(self):
+        self.pre, self.fused = None, False
 
 
 def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-                 gelu: bool = False) -> Tensor:
-    """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd)."""
+                 gelu: bool = False, link: Optional[GeluLink] = None, link_in: Optional[GeluLink] = None) -> Tensor:
+    """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd).  link / link_in: see GeluLink."""
     if not torch.is_grad_enabled() and _x6() and x.is_cuda and x.dtype == torch.float32:
         # serving path: no autograd node, no saved tensors, straight to the kernel
         shp = x.shape
@@ -943,7 +1013,7 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
                                         res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
                                         1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
         return out.reshape(*shp[:-1], N)
-    return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0)
+    return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0, link, link_in)
 
 
 # --------------------------------------------------------------------------- LayerNorm (E2, E5, E6: norm1..3, norm_y, enc/dec_norm)

@@ -611,8 +611,8 @@ def test_input_merger_path_matches_fp64():
     ref = torch.nn.functional.interpolate(pd, scale_factor=2, mode="bilinear", align_corners=True) + \
         torch.relu(torch.nn.functional.conv2d(imgs.double(), wd, bd, padding=3))
     (ref * g.double()).sum().backward()
-    assert_close_rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 3e-6, "input merger fwd")
-    assert_close_rel(p1.grad.cpu().numpy(), pd.grad.cpu().numpy(), 3e-6, "input merger d path_1")
+    assert_close_rel(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "input merger fwd")
+    assert_close_rel(p1.grad.cpu().numpy(), pd.grad.cpu().numpy(), 1e-5, "input merger d path_1")
     assert_close_rel(conv7.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "input merger dW")
     assert_close_rel(conv7.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "input merger db")
     # an image that needs a gradient (parity fixtures only) keeps the framework path
@@ -641,3 +641,89 @@ def test_dpt_reassemble_as_linear_layers_equals_the_convolution_stack():
         assert_close_rel(new.detach().cpu().numpy(), old.detach().cpu().numpy(), 3e-6, f"reassemble {i}")
         for a, b_, nm in zip(ga, gb, ["tok"] + [n for n, _ in seq.named_parameters()]):
             assert_close_rel(a.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"reassemble {i} d{nm}")
+
+
+@pytest.mark.parametrize("arith", ["bf16x6", "f32"])
+@pytest.mark.parametrize("B,N,H", [(3, 257, 12), (2, 514, 16), (2, 256, 4)])
+def test_packed_qkv_attention_equals_the_three_tensor_path_and_writes_one_gradient(B, N, H, arith, monkeypatch):
+    """attention_qkv (self-attention on the packed (B,N,3,H,64) projection; the backward writes dq / dk / dv into the planes of ONE
+    gradient through VitAttnArgs.dq_sn / dkv_sn) == memory_efficient_attention on the three strided views (whose gradient autograd
+    assembles with select_backward fills, copies and adds): same kernels, so outputs and gradients must agree to the bit, and both
+    match float64 (blocks.py:97-134).  N = 257 runs the tail kernels, too."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", arith)
+    torch.manual_seed(B + N)
+    qkv0 = torch.randn(B, N, 3, H, 64, device=DEV)
+    pos = torch.stack(torch.meshgrid(torch.arange(B), torch.arange(N), indexing="ij"), -1)[..., 1:].repeat(1, 1, 2).to(DEV) % 17
+    pos = pos.to(torch.int64).contiguous()
+    g = torch.randn(B, N, H, 64, device=DEV)
+    a = qkv0.clone().requires_grad_(True)
+    oa = vit_ops.attention_qkv(a, 0.125, pos, 100.0, 16)
+    (oa * g).sum().backward()
+    b = qkv0.clone().requires_grad_(True)
+    ob = vit_ops.memory_efficient_attention(b[:, :, 0], b[:, :, 1], b[:, :, 2], scale=0.125, qpos=pos, kpos=pos, rope_base=100.0, max_pos=16)
+    (ob * g).sum().backward()
+    assert torch.equal(oa, ob)
+    assert torch.equal(a.grad, b.grad)
+    # float64 of the same expression (RoPE through the module's own rotation of a copy)
+    qd = qkv0.double()
+    rope = vit_ops.RoPE2D(100.0, max_pos=16)
+    qr = rope(qkv0[:, :, 0].transpose(1, 2).contiguous().clone(), pos).transpose(1, 2).double()
+    kr = rope(qkv0[:, :, 1].transpose(1, 2).contiguous().clone(), pos).transpose(1, 2).double()
+    att = torch.softmax(torch.einsum("bnhd,bmhd->bhnm", qr, kr) * 0.125, -1)
+    ref = torch.einsum("bhnm,bmhd->bnhd", att, qd[:, :, 2])
+    assert_close_rel(oa.detach().cpu().numpy(), ref.cpu().numpy(), 5e-6, "packed attention fwd vs fp64")
+
+
+def test_gelu_backward_inside_the_fc2_input_gradient_gemm():
+    """vit.Mlp with GeluLink (GELU' applied in the epilogue of fc2's dX GEMM, vit_linear_x6_fwd act = 2; no GeluBackward pass) vs the
+    same two Linear layers without the link and vs float64 (blocks.py:76-82)."""
+    from styl3r_amd import vit, vit_ops
+    torch.manual_seed(5)
+    m = vit.Mlp(768, 3072).to(DEV)
+    x0 = torch.randn(1300, 768, device=DEV)
+    res = torch.randn(1300, 768, device=DEV)
+    g = torch.randn(1300, 768, device=DEV)
+
+    def run(linked):
+        for p in m.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if linked:
+            y = m(x, residual=res)
+        else:
+            y = vit_ops.fused_linear(vit_ops.fused_linear(x, m.fc1.weight, m.fc1.bias, gelu=True), m.fc2.weight, m.fc2.bias, residual=res)
+        (y * g).sum().backward()
+        return y.detach(), x.grad, [p.grad.clone() for p in m.parameters()]
+    ya, xa, pa = run(True)
+    yb, xb, pb = run(False)
+    assert torch.equal(ya, yb)
+    xd = x0.double().requires_grad_(True)
+    md = [p.detach().double().requires_grad_(True) for p in m.parameters()]
+    yd = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xd, md[0], md[1])), md[2], md[3]) + res.double()
+    (yd * g.double()).sum().backward()
+    assert_close_rel(xa.cpu().numpy(), xd.grad.cpu().numpy(), 5e-6, "dx (GELU' in the epilogue) vs fp64")
+    assert_close_rel(xa.cpu().numpy(), xb.cpu().numpy(), 2e-6, "dx linked vs unlinked")
+    for a, b_, d, n in zip(pa, pb, md, ("fc1.w", "fc1.b", "fc2.w", "fc2.b")):
+        assert_close_rel(a.cpu().numpy(), d.grad.cpu().numpy(), 1e-5, f"d{n} vs fp64")
+        assert_close_rel(a.cpu().numpy(), b_.cpu().numpy(), 5e-6, f"d{n} linked vs unlinked")
+
+
+def test_patch_embed_as_linear_equals_the_strided_convolution():
+    """PatchEmbedDust3R (croco/patch_embed.py:19-29: Conv2d(3, D, 16, 16)) as a Linear over patch rows vs the convolution in float64"""
+    from styl3r_amd.encoder import PatchEmbedDust3R
+    torch.manual_seed(1)
+    pe = PatchEmbedDust3R((512, 512), 16, 3, 1024).to(DEV)
+    x = (torch.rand(3, 3, 64, 96, device=DEV) * 2 - 1).requires_grad_(True)
+    tok, pos = pe(x)
+    g = torch.randn_like(tok)
+    (tok * g).sum().backward()
+    xd = x.detach().double().requires_grad_(True)
+    wd = pe.proj.weight.detach().double().requires_grad_(True); bd = pe.proj.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, wd, bd, stride=16).flatten(2).transpose(1, 2)
+    (ref * g.double()).sum().backward()
+    assert tok.shape == (3, 24, 1024) and pos.shape == (3, 24, 2) and pos[0, 7].tolist() == [1, 1]
+    assert_close_rel(tok.detach().cpu().numpy(), ref.detach().cpu().numpy(), 3e-6, "patch embed fwd")
+    assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 5e-6, "patch embed dx")
+    assert_close_rel(pe.proj.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "patch embed dW")
+    assert_close_rel(pe.proj.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "patch embed db")

@@ -225,3 +225,30 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
         print(f"  one-rank RCCL vs local: {len(a)} buckets, worst bucket deviation {worst:.2e} of the bucket scale")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_clip_coefficient_deferred_into_the_fused_adamw_equals_the_explicit_scale():
+    """BucketedGradReducer.clip_grad_norm_(defer_to=optimizer): the fused AdamW divides by `grad_scale` while it reads the gradients
+    (Trainer(gradient_clip_val=0.5), main_style.py:110, + AdamW, model_wrapper_style.py:885-895) -- same parameters after the step as
+    scaling the buckets first."""
+    from torch import nn
+    from styl3r_amd.ddp import BucketedGradReducer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(64, 128, device=dev)
+
+    def run(defer):
+        torch.manual_seed(1)
+        m = nn.Sequential(nn.Linear(128, 256), nn.GELU(), nn.Linear(256, 32)).to(dev)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.05, betas=(0.9, 0.95), fused=True)
+        red = BucketedGradReducer(m.parameters(), None, bucket_bytes=64 * 1024)
+        for _ in range(3):
+            red.prepare(); (m(x) * 7).pow(2).sum().backward(); red.finish()
+            total = red.clip_grad_norm_(0.5, defer_to=opt if defer else None)
+            assert float(total) > 0.5                       # the coefficient really is below one
+            opt.step()
+        return [p.detach().clone() for p in m.parameters()]
+    a, b = run(True), run(False)
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max())

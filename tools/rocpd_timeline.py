@@ -32,7 +32,7 @@ if AGG:
     for n, s_, e in rows[a:b]:
         agg[n][0] += 1; agg[n][1] += e - s_
     lines = ["| kernel | calls/step | ms/step | % of span |", "|---|---|---|---|"]
-    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:80]:
         lines.append(f"| `{n[:110]}` | {c} | {t / 1e6:.3f} | {100 * t / span:.1f} |")
 lines.append(f"\nstep span {span / 1e3:.1f} us, kernel time {busy / 1e3:.1f} us, idle {100 * (1 - busy / span):.1f} %")
 out = "\n".join(lines)
