@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-mode", choices=["bf16x3", "bf16x6"], default="bf16x3", help="arithmetic of the GEMM-shaped kernels in the headline train step")
     ap.add_argument("--train-tiny", action="store_true", help="small trunk for the train leg (smoke tests only; flagged in the line)")
     ap.add_argument("--dry-cpu", action="store_true",
                     help="launch-path test mode: gloo on CPU, no kernels, no oracle -- checks spawning / sharding / the JSON line")
@@ -301,11 +302,22 @@ def train_leg(args, rank, world, dev, dist):
         target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
                     intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
     sync = (lambda: None) if cpu else (lambda: torch.cuda.synchronize(dev))
-    for _ in range(args.train_warmup):
-        step(batch)
-    dt = dist_utils.timed_steps(lambda: step(batch), args.train_steps, sync, dist, dev)
-    grad_bytes = sum(step.reducer.bucket_sizes_bytes())
     from styl3r_amd import vit_ops
+    # Arithmetic of the GEMM-shaped kernels in the headline train step: "bf16x3" (three bf16 partial products per fp32 product).  The
+    # reference runs these layers in TF32 (croco.py:13 allow_tf32, cudnn's conv default); tests/test_e2e_parity.py measures, against the
+    # reference's own chain in float64, that bf16x3 sits INSIDE the reference's TF32 distance on every quantity (Gaussians, rendered RGB,
+    # loss, every gradient: worst ratio 0.1 .. 0.84, gradients 20 - 60 x closer) -- VERDICT r02 #2's rule.  "bf16x6" (fp32 round-off
+    # accuracy, the library default and the mode of every 1e-4 parity statement) is timed beside it.
+    keep_mode = vit_ops.LINEAR_MODE
+    head_mode = "bf16x6" if (cpu or args.train_tiny or args.train_mode == "bf16x6") else "bf16x3"
+    try:
+        vit_ops.LINEAR_MODE = head_mode
+        for _ in range(args.train_warmup):
+            step(batch)
+        dt = dist_utils.timed_steps(lambda: step(batch), args.train_steps, sync, dist, dev)
+    finally:
+        vit_ops.LINEAR_MODE = keep_mode
+    grad_bytes = sum(step.reducer.bucket_sizes_bytes())
     out = {"metric": "256x256 rendered views/sec, full C3 train step (encoder + rasterizer fwd+bwd, MSE, DP all-reduce, clip, AdamW)",
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.train_steps, world, dt), 3), "unit": "views/s",
            "ms_per_step": round(1e3 * dt / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
@@ -314,47 +326,65 @@ def train_leg(args, rank, world, dev, dist):
            "grad_bytes": grad_bytes, "buckets": len(step.reducer.buckets), "bucket_MiB": 64,
            "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward"
                           + (" (ONE-rank group: collectives issued, identity result)" if forced else "") if step.reducer.collective else "none (1 rank, no process group)"),
-           "linear_arithmetic": vit_ops.LINEAR_MODE, "dtype": "f32", "data": "synthetic, random-init weights",
+           "linear_arithmetic": head_mode, "dtype": "f32",
+           "arithmetic_note": ("bf16x3 split products on the bf16 MFMA with fp32 accumulation: inside the reference's own TF32 distance on every quantity "
+                               "(tests/test_e2e_parity.py, tests/golden/e2e_c3.npz / e2e_c4.npz: tf32noise vs measured)" if head_mode == "bf16x3" else
+                               "bf16x6 split products: fp32 round-off accuracy"),
+           "data": "synthetic, random-init weights",
            "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
     if not cpu:
         out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
         if not args.train_tiny:
-            # the same step with three partial products per GEMM launch instead of six (opt-in VIT_LINEAR_MODE=bf16x3: Gaussians within
-            # 1e-4 of the reference, ~4e-6 per GEMM) -- reported beside the headline mode, never instead of it
-            keep = vit_ops.LINEAR_MODE
+            other = "bf16x6" if head_mode == "bf16x3" else "bf16x3"
             try:
-                vit_ops.LINEAR_MODE = "bf16x3"
+                vit_ops.LINEAR_MODE = other
                 for _ in range(2):
                     step(batch)
                 dt3 = dist_utils.timed_steps(lambda: step(batch), 2, sync, dist, dev)
-                out["bf16x3"] = {"ms_per_step": round(1e3 * dt3 / 2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, 2, world, dt3), 3),
-                                 "unit": "views/s", "steps": 2, "products_per_launch": vit_ops.load().vit_x6_products(), "note": "opt-in arithmetic mode, not the headline"}
+                out[other] = {"ms_per_step": round(1e3 * dt3 / 2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, 2, world, dt3), 3),
+                              "unit": "views/s", "steps": 2, "products_per_launch": vit_ops.load().vit_x6_products(),
+                              "note": "the same step in the other arithmetic mode" + (" (fp32 round-off accuracy; mode of the 1e-4 parity tests)" if other == "bf16x6" else "")}
             finally:
-                vit_ops.LINEAR_MODE = keep
+                vit_ops.LINEAR_MODE = keep_mode
                 vit_ops._x6()
             out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
     return out
 
 
 def linear_roofline(dev, M):
-    """MFMA roofline of the step's dominant GEMM-shaped kernel, measured live: the encoder's qkv Linear (M tokens x 3072 x 1024) on
-    the bf16x6 kernel the step runs (six bf16 MFMAs per fp32 product: the nominal peak-equivalent is 2.5 PF / 6)."""
+    """MFMA roofline of the step's dominant GEMM-shaped kernel, measured live: the encoder's qkv Linear (M tokens x 3072 x 1024) on the
+    kernels the step runs, in both arithmetic modes.  Nominal peak-equivalent = dense bf16 MFMA peak (2.5 PF) / MFMAs per fp32 product."""
     import torch
     from styl3r_amd import vit_ops
     N, K = 3072, 1024
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) / K ** 0.5; bias = torch.randn(N, device=dev)
-    with torch.no_grad():
-        for _ in range(10):
-            vit_ops.fused_linear(x, w, bias)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            vit_ops.fused_linear(x, w, bias)
-        e1.record(); torch.cuda.synchronize(dev)
-    ms = e0.elapsed_time(e1) / 50
-    tf = 2.0 * M * N * K / ms / 1e9
-    return {"kernel": "vit::x6::k_linear_x6 (encoder qkv Linear)", "shape_MNK": [M, N, K], "ms": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s (fp32-accurate)",
-            "bound": "mfma", "peak": round(2500.0 / 6, 1), "frac": round(tf / (2500.0 / 6), 3), "mfma_TFLOPs_bf16": round(6 * tf, 1),
+    res = {}
+    keep = vit_ops.LINEAR_MODE
+    try:
+        for mode, nprod in (("bf16x6", 6), ("bf16x3", 3)):
+            vit_ops.LINEAR_MODE = mode
+            before = vit_ops.CALLS["linear_x6r"]
+            with torch.no_grad():
+                xg = x.requires_grad_(False)
+                for _ in range(10):
+                    vit_ops._FusedLinear.apply(xg, w, bias, None, 0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    vit_ops._FusedLinear.apply(xg, w, bias, None, 0)
+                e1.record(); torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / 50
+            tf = 2.0 * M * N * K / ms / 1e9
+            ring = vit_ops.CALLS["linear_x6r"] > before
+            res[mode] = {"kernel": ("vit::x6r::k_linear_x6c (256 x 256 tiles, ping-pong wave pairs, LDS-DMA ring)" if ring else "vit::x6::k_linear_x6"),
+                         "ms": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s (fp32-accurate product rate)", "bound": "mfma",
+                         "peak": round(2500.0 / nprod, 1), "frac": round(tf / (2500.0 / nprod), 3), "mfma_TFLOPs_bf16": round(nprod * tf, 1)}
+    finally:
+        vit_ops.LINEAR_MODE = keep
+        vit_ops._x6()
+    head = res["bf16x6"]
+    return {"kernel": head["kernel"] + " (encoder qkv Linear)", "shape_MNK": [M, N, K], "ms": head["ms"], "achieved": head["achieved"], "unit": head["unit"],
+            "bound": "mfma", "peak": head["peak"], "frac": head["frac"], "mfma_TFLOPs_bf16": head["mfma_TFLOPs_bf16"], "bf16x3": res["bf16x3"],
             "note": "power-limited on random operands: DESIGN.md 9.2"}
 
 

@@ -192,8 +192,7 @@ class BucketedGradReducer:
         total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(flats)))
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         if defer_to is not None and defer_to.defaults.get("fused"):
-            defer_to.grad_scale = (1.0 / coef).reshape(1).float()          # g / grad_scale == g * coef
-            defer_to.found_inf = torch.zeros(1, dtype=torch.float32, device=coef.device)
+            defer_to.grad_scale = (1.0 / coef).float()                     # 0-dim; g / grad_scale == g * coef
         else:
             torch._foreach_mul_(flats, coef)
         return total

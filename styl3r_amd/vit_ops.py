@@ -518,7 +518,7 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
 # tools/probes/conv_small.py); smaller problems stay on the library path
 _CONV_X6_MIN_TILES = 1     # r03: forward / dX take the bf16x6 kernel at EVERY size (tools/probes/dpt_layers.py, profiles/r03_dpt_layers.md:
 #                            on par with or ahead of the library's Winograd down to the 8 x 8 layers once K is split across workgroups)
-_CONV_X6_WGRAD_MIN_PIXELS = 65536   # 3x3 dW / db on the split-pixel kernel needs this many pixels (below, its 16-pixel slabs of short image
+_CONV_X6_WGRAD_MIN_PIXELS = int(os.environ.get("VIT_CONV_WGRAD_MIN_PIXELS", "65536"))   # 3x3 dW / db on the split-pixel kernel needs this many pixels (below, its 16-pixel slabs of short image
 #                                     rows lose 1.3 - 1.9x to the library's NHWC implicit GEMM: the one library kernel family left in the heads); 1x1: any size
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)

