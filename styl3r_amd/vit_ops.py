@@ -408,6 +408,17 @@ def _x6() -> bool:
         _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
     return True
 
+def _pin_products(mode: str) -> None:
+    """libvit_hip.so keeps the products-per-launch per HOST THREAD (thread_local): autograd runs a node's backward on its own engine
+    thread, so every backward re-states the mode its forward ran in before it launches anything (a step never mixes modes, whatever
+    LINEAR_MODE has become in the meantime)."""
+    if mode in ("bf16x6", "bf16x3"):
+        want = 3 if mode == "bf16x3" else 6
+        lib = load()
+        if lib.vit_x6_products() != want:
+            _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
+
+
 _SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
 
 
@@ -544,12 +555,15 @@ class _ConvX6(torch.autograd.Function):
         x = x.contiguous().float()
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.has_res, ctx.relu_in = bias is not None, residual is not None, bool(relu_in)
+        ctx.mode = LINEAR_MODE
+        _pin_products(ctx.mode)
         CALLS["conv_x6_fwd"] += 1
         return conv_x6_forward(x, weight, bias, residual, relu_in)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        _pin_products(ctx.mode)
         g = g.contiguous().float()
         k = weight.shape[2]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
@@ -908,6 +922,7 @@ class _FusedLinear(torch.autograd.Function):
         ctx.link, ctx.link_in = (link if (x6 and need_pre) else None), (link_in if x6 else None)
         if ctx.link is not None:
             ctx.link.pre, ctx.link.fused = pre, False
+        ctx.mode = LINEAR_MODE
         ctx.weight_ref = weight if x6 else None
         ctx.weight_version = weight._version      # dX re-splits the LIVE parameter: it must still be the forward's value
         ctx.bias_ref = bias if x6 else None
@@ -918,6 +933,7 @@ class _FusedLinear(torch.autograd.Function):
     def backward(ctx, g):
         x2, w, pre = ctx.saved_tensors
         shp, has_bias, has_res, act = ctx.meta
+        _pin_products(ctx.mode)
         if ctx.weight_ref is not None and ctx.weight_ref._version != ctx.weight_version:
             raise RuntimeError("fused Linear: the weight was modified in place between forward and backward (optimizer step / "
                                "EMA under retain_graph?); dX would be computed with the new value")
