@@ -53,7 +53,9 @@ def parse(argv=None):
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-views", type=int, default=2, help="views in the CPU-baseline sample")
+    ap.add_argument("--cpu-views", type=int, default=2, help="minimum number of views in the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: keep taking views until this much wall time is spent")
+    ap.add_argument("--no-infer-leg", action="store_true", help="skip the C2 inference leg")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
     ap.add_argument("--train-steps", type=int, default=3)
@@ -110,32 +112,39 @@ def algorithmic_bytes(stage, V, B, G, P, n_sh, R, R_eff):
 
 
 def cpu_baseline(args, scenes):
-    """Oracle (kind 'port') on `cpu_views` views of scene 0, fwd + bwd, all host cores in the OpenMP loops."""
+    """Oracle (kind 'port') on a bounded sample of the SAME workload: views of the step's own scenes, fwd + bwd, all host cores in the
+    OpenMP loops, until `--cpu-seconds` (default 10 s) of CPU work or the whole step's views are done."""
     import numpy as np
     import torch
     from oracle.gsr_oracle import Oracle
     from styl3r_amd.decoder import prepare_views
-    sc = scenes[0]
     orc = Oracle("f32")
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # cores this process may use
-    nv = min(args.cpu_views, args.views)
-    views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(args.views, 3), True).numpy()
-    cov = sc.covariances.numpy()
-    cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
-    shs = sc.harmonics.numpy().transpose(0, 2, 1)
     H = W = args.res
     gI = np.ones((3, H, W), np.float32) / (3 * H * W)
-    t0 = time.perf_counter()
-    for v in range(nv):
-        row = views[v]
-        s = np.float32(row[56])
-        st, ctx = orc.forward(sc.means.numpy() * s, cov6 * (s * s), sc.opacities.numpy(), shs=shs, H=H, W=W,
-                              tanfovx=row[51], tanfovy=row[52], bg=(0, 0, 0), view=row[0:16], proj=row[16:32],
-                              proj_raw=row[32:48], campos=row[48:51], sh_degree=args.sh_degree, nthreads=cores)
-        orc.backward(st, ctx, gI, None, nthreads=cores)
+    done, t0 = 0, time.perf_counter()
+    G = scenes[0].means.shape[0]
+    for sc in scenes:
+        views = prepare_views(sc.extrinsics, sc.intrinsics, sc.near, sc.far, torch.zeros(args.views, 3), True).numpy()
+        cov = sc.covariances.numpy()
+        cov6 = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+        shs = sc.harmonics.numpy().transpose(0, 2, 1)
+        for v in range(args.views):
+            row = views[v]
+            s = np.float32(row[56])
+            st, ctx = orc.forward(sc.means.numpy() * s, cov6 * (s * s), sc.opacities.numpy(), shs=shs, H=H, W=W,
+                                  tanfovx=row[51], tanfovy=row[52], bg=(0, 0, 0), view=row[0:16], proj=row[16:32],
+                                  proj_raw=row[32:48], campos=row[48:51], sh_degree=args.sh_degree, nthreads=cores)
+            orc.backward(st, ctx, gI, None, nthreads=cores)
+            done += 1
+            if done >= max(args.cpu_views, 1) and time.perf_counter() - t0 >= args.cpu_seconds:
+                break
+        else:
+            continue
+        break
     dt = time.perf_counter() - t0
-    return {"value": round(nv / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"{nv} of the {args.views} views of scene 0 (G={sc.means.shape[0]}, {H}x{W}), fwd+bwd, "
+    return {"value": round(done / dt, 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{done} of the step's {len(scenes) * args.views} views (scene order, G={G}, {H}x{W}), fwd+bwd, {dt:.1f} s of wall time, "
                       f"oracle/gsr_oracle.c f32, OpenMP: per-Gaussian stages (preprocess, key emission + radix sort, preprocess-backward) on "
                       f"min(cores, 32) threads, per-tile stages (composite forward / backward) on all cores"}
 
@@ -351,6 +360,49 @@ def train_leg(args, rank, world, dev, dist):
     return out
 
 
+def infer_leg(args, dev):
+    """C2 (BASELINE.json configs[1]): inference latency, 2 context views 256 x 256 -> 131 072 Gaussians on the full-size encoder
+    (random init: re10k_2v.ckpt is absent), 3 target views rendered forward only, `no_grad`, bf16x6 arithmetic (the mode of the 1e-4 RGB
+    statement), heads and style branch on side streams (infer_model_re10k.py:262-560 call order)."""
+    import torch
+    from styl3r_amd import vit_ops
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.scenes import make_scene
+    torch.manual_seed(0)
+    with torch.device(dev):
+        enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg()).eval()
+    enc.head_streams = True
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    H, v_ctx, v_tgt = 256, 2, 3
+    sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234)
+    g = torch.Generator(dev).manual_seed(1234)
+    ctx = dict(image=torch.rand(1, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=sc.intrinsics[:1].to(dev).expand(1, v_ctx, 3, 3).contiguous())
+    style = dict(image=ctx["image"][:, 0])
+    ex = lambda t: t.to(dev)[None].contiguous()
+    cams = [ex(sc.extrinsics), ex(sc.intrinsics), ex(sc.near), ex(sc.far)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_enc = t_ras = 0.0
+    steps, warm = 20, 4
+    with torch.no_grad():
+        for i in range(warm + steps):
+            ev[0].record()
+            gs = enc(ctx, style, 0)
+            ev[1].record()
+            dec.forward(gs, *cams, (H, H))
+            ev[2].record()
+            torch.cuda.synchronize(dev)
+            if i >= warm:
+                t_enc += ev[0].elapsed_time(ev[1]); t_ras += ev[1].elapsed_time(ev[2])
+    out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", "encoder_ms": round(t_enc / steps, 3),
+           "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3), "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2),
+           "gaussians": int(gs.means.shape[1]), "steps": steps, "linear_arithmetic": vit_ops.LINEAR_MODE, "encoder_launch": "eager, heads + style branch on side streams",
+           "dtype": "f32", "data": "synthetic, random-init weights"}
+    del enc, dec
+    torch.cuda.empty_cache()
+    return out
+
+
 def linear_roofline(dev, M):
     """MFMA roofline of the step's dominant GEMM-shaped kernel, measured live: the encoder's qkv Linear (M tokens x 3072 x 1024) on the
     kernels the step runs, in both arithmetic modes.  Nominal peak-equivalent = dense bf16 MFMA peak (2.5 PF) / MFMAs per fp32 product."""
@@ -448,6 +500,11 @@ def main():
             res["train_step"]["n_gpus"] = world
         except Exception as e:   # the headline line must survive a failure of the secondary leg; it is reported, not hidden
             res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    if rank == 0 and not args.no_infer_leg and not args.dry_cpu:
+        try:
+            res["infer"] = infer_leg(args, dev)
+        except Exception as e:
+            res["infer"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0:
         if not args.no_cpu_baseline and not args.dry_cpu:
             res["cpu_baseline"] = cpu_baseline(args, scenes)

@@ -533,7 +533,7 @@ _CONV_X6_WGRAD_MIN_PIXELS = int(os.environ.get("VIT_CONV_WGRAD_MIN_PIXELS", "655
 #                                     rows lose 1.3 - 1.9x to the library's NHWC implicit GEMM: the one library kernel family left in the heads); 1x1: any size
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
-CALLS = {"linear_x6r": 0, "head_tail": 0, "input_merger_x6": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
+CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_merger_x6": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
          "layernorm_framework": 0, "adapter_hip": 0}
 
 
@@ -602,10 +602,51 @@ class _ConvX6(torch.autograd.Function):
             _check(load().vit_conv_x6_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
                                             B_, weight.shape[1], weight.shape[0], H_, W_, k, 1 if ctx.relu_in else 0,
                                             _stream(g.device)), "vit_conv_x6_wgrad")
+        elif need_w and k == 3 and weight.shape[1] % 16 == 0 and _x6():
+            # 3x3 layers with few pixels (the 8 x 8 .. 64 x 64 stages): the split-pixel kernel's 16-pixel slabs of short image rows
+            # lose there, so the gradient goes through the LINEAR weight-gradient kernel instead: dW (Co, 9 Ci) = dY^T (Co, P) . cols (P, 9 Ci)
+            # with the pixel-major operands built by one channels-last copy each and ONE gather of the nine taps (row h w of the
+            # padded grid = zeros); the ReLU of a residual unit is applied to the channels-last copy.  No library kernel.
+            Co, Ci = weight.shape[0], weight.shape[1]
+            P, HW = B_ * H_ * W_, H_ * W_
+            grid = torch.empty((B_, HW + 1, Ci), dtype=torch.float32, device=g.device)
+            grid[:, HW].zero_()
+            dst, src = grid[:, :HW].view(B_, H_, W_, Ci), x.permute(0, 2, 3, 1)
+            if ctx.relu_in:
+                torch.clamp_min(src, 0.0, out=dst)          # channels-last copy and ReLU in one pass
+            else:
+                dst.copy_(src)
+            cols = torch.index_select(grid.view(B_ * (HW + 1), Ci), 0, _tap3_index(B_, H_, W_, g.device)).view(P, 9 * Ci)
+            gt = g.permute(0, 2, 3, 1).reshape(P, Co).contiguous()
+            buf = torch.empty(Co * 9 * Ci + (Co if need_b else 0), dtype=torch.float32, device=g.device)
+            dwl = buf[:Co * 9 * Ci].view(Co, 9 * Ci)
+            db = buf[Co * 9 * Ci:] if need_b else None
+            CALLS["conv_wgrad_via_linear"] += 1
+            _check(load().vit_linear_x6_wgrad(gt.data_ptr(), cols.data_ptr(), dwl.data_ptr(), db.data_ptr() if need_b else None, P, Co, 9 * Ci,
+                                              _stream(g.device)), "vit_linear_x6_wgrad (conv)")
+            dw = dwl.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         elif need_w or need_b:
             _, dw, db = torch.ops.aten.convolution_backward(g, f_x(), weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
                                                             [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
         return dx, dw, db, (g if need_r else None), None
+
+
+_TAP3: dict = {}
+
+
+def _tap3_index(B: int, H: int, W: int, device) -> Tensor:
+    """flat row index into the (B, H W + 1, Ci) channels-last grid (row H W of every image = zero padding) of tap (dy, dx) of pixel
+    (b, y, x) of a 3x3 / stride 1 / padding 1 convolution, laid out [(b, y, x), (dy, dx)]"""
+    key = (B, H, W, str(device))
+    if key not in _TAP3:
+        if len(_TAP3) > 64:
+            _TAP3.clear()
+        y, x, dy, dx = torch.meshgrid(torch.arange(H), torch.arange(W), torch.arange(3), torch.arange(3), indexing="ij")
+        sy, sx = y + dy - 1, x + dx - 1
+        inside = (sy >= 0) & (sy < H) & (sx >= 0) & (sx < W)
+        one = torch.where(inside, sy * W + sx, torch.full_like(sy, H * W)).reshape(-1)
+        _TAP3[key] = (one[None, :] + torch.arange(B)[:, None] * (H * W + 1)).reshape(-1).to(device)
+    return _TAP3[key]
 
 
 class Conv2dX6(nn.Conv2d):
