@@ -5,17 +5,20 @@ set -u
 OUT=${1:-gpurun_out/benchmarks}; mkdir -p "$OUT"
 run() { echo "== $*"; "$@" 2>&1 | tail -1 | tee -a "$OUT/all.jsonl" | cut -c1-260; }
 run python bench.py                                                              # headline M1 (+ roofline, CPU baseline)
-run python bench.py --grid 128 --no-cpu-baseline --no-train-leg                                 # 16 384 Gaussians / scene
-run python bench.py --ctx 2 --no-cpu-baseline --no-train-leg                                    # 131 072
-run python bench.py --ctx 4 --no-cpu-baseline --no-train-leg                                    # 262 144
-run python bench.py --ctx 4 --res 512 --sh-degree 4 --scenes 3 --no-cpu-baseline --no-train-leg # C5 stress shapes
-run python bench.py --grid 512 --ctx 4 --res 512 --scenes 2 --no-cpu-baseline --no-train-leg    # 1 048 576
+run python bench.py --grid 128 --no-cpu-baseline --no-train-leg --no-infer-leg                                 # 16 384 Gaussians / scene
+run python bench.py --ctx 2 --no-cpu-baseline --no-train-leg --no-infer-leg                                    # 131 072
+run python bench.py --ctx 4 --no-cpu-baseline --no-train-leg --no-infer-leg                                    # 262 144
+run python bench.py --ctx 4 --res 512 --sh-degree 4 --scenes 3 --no-cpu-baseline --no-train-leg --no-infer-leg # C5 stress shapes
+run python bench.py --grid 512 --ctx 4 --res 512 --scenes 2 --no-cpu-baseline --no-train-leg --no-infer-leg    # 1 048 576
 run python tools/bench_train.py --config c3 --scenes 10 --steps 3 --warmup 2     # M2, C3
 run python tools/bench_train.py --config c3 --scenes 8 --steps 3 --warmup 2
 run python tools/bench_train.py --config c3 --scenes 10 --steps 3 --warmup 2 --linear-mode bf16x3   # opt-in three-product arithmetic
+run python tools/bench_train.py --config c3 --scenes 8 --steps 3 --warmup 2 --linear-mode bf16x3
 run python tools/bench_train.py --config c4 --scenes 2 --steps 2 --warmup 1      # style stage
 run python tools/bench_train.py --config c4 --scenes 6 --steps 3 --warmup 2      # style stage at the reference's batch
+run python tools/bench_train.py --config c4 --scenes 6 --steps 3 --warmup 2 --linear-mode bf16x3
 run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1      # 512^2 / sh 4 stress step
+run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1 --linear-mode bf16x3
 run python tools/bench_infer.py                                                  # C2 inference
 run python tools/bench_infer.py --streams                                        # C2 inference, style branch + heads on side streams
 run python tools/bench_vit.py                                                    # kernel microbenchmarks
