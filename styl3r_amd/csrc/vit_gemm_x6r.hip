@@ -39,6 +39,7 @@
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
+int x6_products();     // vit_gemm_x6.hip: partial products per launch (6 / 3), per host thread
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -119,7 +120,7 @@ template <int N> __device__ inline void wait_vmcnt()
 }
 
 // BM x BN output tile, WM x WN wavefronts of (BM/WM) x (BN/WN) sub-tiles, NST LDS stages
-template <int ACT, int BM, int BN, int WM, int WN, int NST, int OCC>
+template <int ACT, int BM, int BN, int WM, int WN, int NST, int OCC, int NPROD = 6>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                    const float *__restrict__ bias, const float *__restrict__ residual,
                                                                    float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
@@ -226,9 +227,11 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
             for (int j = 0; j < RN; ++j) {      // smallest partial products first
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
                 f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b2, c, 0, 0, 0);
+                if constexpr (NPROD == 6) {     // the three 2^-16-level products; left out in three-product mode (vit_x6_set_products(3))
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, b0, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b2, c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b0, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b1, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b0, c, 0, 0, 0);
@@ -291,7 +294,7 @@ __device__ inline void lds_wait_all(f32x4 (&b)[2][3], f32x4 (&a)[4][3])
 // reads (A like B).  Per wave and slab: 2 + 3*(RM+RN) 16-byte LDS reads, 3 writes, one split8 -- instead of RM split8's.
 // LDS: raw A x2, B x2, converted A x2; every DMA is issued one whole slab before its consumer, so the top-of-slab wait is
 // a plain vmcnt(0) with nothing young in flight.
-template <int ACT, int BM, int BN, int WM, int WN, bool PROF = false>
+template <int ACT, int BM, int BN, int WM, int WN, bool PROF = false, int NPROD = 6>
 __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
                                                                  float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
@@ -423,9 +426,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 for (int j = 0; j < RN; ++j) {
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                    if constexpr (NPROD == 6) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
@@ -623,8 +628,12 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
+    const bool three = x6_products() == 3;
     if (cfg == 1) {
-        if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+        if (three) {
+            if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
+            else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
+        } else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
     } else if (cfg == 2) {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
@@ -634,6 +643,9 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
         hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     } else if (cfg >= 34) {
         return VIT_EINVAL;            // K splits need a workspace: vit_linear_x6c_fwd
+    } else if (three) {
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     } else {
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
         else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);

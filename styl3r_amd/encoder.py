@@ -243,7 +243,7 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         """first half of forward(): the 24 encoder blocks over all views -> (feat (b,v,l,c), pos (b,v,l,2))"""
         b, v, _, h, w = context["image"].shape
         images = context["image"].reshape(b * v, -1, h, w)
-        token = self.intrinsic_encoder(context["intrinsics"].flatten(2)).reshape(b * v, 1, -1)
+        token = _intrinsics_token(self.intrinsic_encoder, context["intrinsics"]).reshape(b * v, 1, -1)
         feat, pos = self._encode_image(images, token)
         return feat.view(b, v, feat.shape[1], -1), pos.view(b, v, pos.shape[1], 2)
 
@@ -354,6 +354,17 @@ class _FusionBlock(nn.Module):
 class _Up2(nn.Module):
     def forward(self, x):
         return upsample2x(x)
+
+
+def _intrinsics_token(layer: nn.Linear, K: Tensor) -> Tensor:
+    """`intrinsic_encoder` = Linear(9, 1024) on the flattened intrinsics (backbone_croco_multiview.py:77-78,204-206).  On the device the
+    contraction is zero-padded from 9 to 16 so that this layer, too, runs on the fused bf16x6 Linear (forward, dX, dW) -- it was the one
+    Linear of the step left on the GEMM library."""
+    x = K.flatten(2)
+    if x.is_cuda and x.dtype == torch.float32:
+        pad = (0, 16 - x.shape[-1])
+        return fused_linear(torch.nn.functional.pad(x, pad).reshape(-1, 16), torch.nn.functional.pad(layer.weight, pad), layer.bias).reshape(*x.shape[:-1], -1)
+    return layer(x)
 
 
 _TAP_INDEX: dict = {}
@@ -822,7 +833,7 @@ class EncoderNoPoSplatTokenStyle(EncoderNoPoSplatMultiTokenStyle):
         assert v == 2, "noposplat_token_style is the 2-view encoder"
         bb = self.backbone
         images = context["image"].reshape(b * v, -1, h, w)
-        token = bb.intrinsic_encoder(context["intrinsics"].flatten(2)).reshape(b * v, 1, -1)
+        token = _intrinsics_token(bb.intrinsic_encoder, context["intrinsics"]).reshape(b * v, 1, -1)
         feat, pos = bb._encode_image(images, token)
         feat, pos = feat.view(b, v, feat.shape[1], -1), pos.view(b, v, pos.shape[1], 2)
         st1, st2 = self.structure_builder(feat[:, 0], pos[:, 0], feat[:, 1], pos[:, 1])

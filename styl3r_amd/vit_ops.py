@@ -531,6 +531,7 @@ _CONV_X6_MIN_TILES = 1     # r03: forward / dX take the bf16x6 kernel at EVERY s
 #                            on par with or ahead of the library's Winograd down to the 8 x 8 layers once K is split across workgroups)
 _CONV_X6_WGRAD_MIN_PIXELS = int(os.environ.get("VIT_CONV_WGRAD_MIN_PIXELS", "65536"))   # 3x3 dW / db on the split-pixel kernel needs this many pixels (below, its 16-pixel slabs of short image
 #                                     rows lose 1.3 - 1.9x to the library's NHWC implicit GEMM: the one library kernel family left in the heads); 1x1: any size
+SMALL_CONV_WGRAD = os.environ.get("VIT_CONV_SMALL_WGRAD", "linear")   # 3x3 weight gradients below that pixel count: "linear" (own kernels, default) | "library"
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
 CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_merger_x6": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
@@ -602,7 +603,7 @@ class _ConvX6(torch.autograd.Function):
             _check(load().vit_conv_x6_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
                                             B_, weight.shape[1], weight.shape[0], H_, W_, k, 1 if ctx.relu_in else 0,
                                             _stream(g.device)), "vit_conv_x6_wgrad")
-        elif need_w and k == 3 and weight.shape[1] % 16 == 0 and _x6():
+        elif need_w and k == 3 and weight.shape[1] % 16 == 0 and _x6() and SMALL_CONV_WGRAD == "linear":
             # 3x3 layers with few pixels (the 8 x 8 .. 64 x 64 stages): the split-pixel kernel's 16-pixel slabs of short image rows
             # lose there, so the gradient goes through the LINEAR weight-gradient kernel instead: dW (Co, 9 Ci) = dY^T (Co, P) . cols (P, 9 Ci)
             # with the pixel-major operands built by one channels-last copy each and ONE gather of the nine taps (row h w of the

@@ -27,6 +27,7 @@ shapes = dict(enc_qkv=(5140, 3072, 1024), enc_fc1=(5140, 4096, 1024), enc_fc2=(5
               dec_qkv=(5120, 2304, 768), dec_fc1=(5120, 3072, 768), dec_fc2=(5120, 768, 3072), dec_proj=(5120, 768, 768), odd=(1000, 200, 48))
 if len(sys.argv) > 2:
     shapes = {k: (shapes[k] if k in shapes else tuple(int(v) for v in k.split("x"))) for k in sys.argv[2].split(",")}
+assert lib.vit_x6_set_products(int(os.environ.get("PRODUCTS", "6"))) == 0      # 6 (default) or 3: partial products per launch
 ACT = int(os.environ.get("ACT", "0")); USE_RES = int(os.environ.get("RES", "1")); USE_PRE = int(os.environ.get("PRE", "0"))
 torch.manual_seed(0)
 _w = torch.randn(4096, 4096, device=dev)
