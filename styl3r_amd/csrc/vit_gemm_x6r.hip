@@ -50,6 +50,10 @@ namespace x6r {
 constexpr int BK = 16;
 
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float gelu_grad_exact(float x)     // as in vit_gemm_x6.hip (act = 2: the input-gradient GEMM of the layer behind a GELU)
+{
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 
 __device__ inline void split2(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2)
 {
@@ -256,6 +260,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
                 float t = acc[i][j][r] + bv;
+                if (ACT == 2) { out[o] = t * gelu_grad_exact(residual[o]); continue; }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
@@ -563,6 +568,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
                 float t = acc[i][j][r] + bv;
+                if (ACT == 2) { out[o] = t * gelu_grad_exact(residual[o]); continue; }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
@@ -624,18 +630,22 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
                    int K, int act, int cfg, hipStream_t stream)
 {
     if (!x || !wp || !out) return VIT_EINVAL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split
+    if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre || (cfg != 1 && cfg != 3))) ||
+        !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split; act 2: see vit_linear_x6_fwd
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
     const bool three = x6_products() == 3;
     if (cfg == 1) {
         if (three) {
-            if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
+            if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
+            else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
             else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
-        } else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+        } else if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
     } else if (cfg == 2) {
+        if (act == 2) return VIT_EINVAL;
         if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
         else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
     } else if (cfg == 4) {      // phase-timing instantiation (tools/probes/gemm_lab.py): needs `pre` with room for 32 floats
@@ -644,10 +654,12 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     } else if (cfg >= 34) {
         return VIT_EINVAL;            // K splits need a workspace: vit_linear_x6c_fwd
     } else if (three) {
-        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
         else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     } else {
-        if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
         else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
     }
 #undef X6R_ARGS

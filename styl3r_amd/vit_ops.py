@@ -914,17 +914,24 @@ def invalidate_split_cache() -> None:
     _SPLIT_CACHE.clear()
 
 
-# (N, K) -> ring configuration of vit_linear_x6r_fwd, for M >= 4096 rows in bf16x6 mode.  From profiles/r02s_gemm_lab.jsonl (TF, default -> ring):
-# encoder qkv 170 -> 206 (cfg 3: 256 x 256 tiles, ping-pong wave pairs), decoder fc1 174 -> 203, decoder qkv 166 -> 178, encoder fc2
-# 149 -> 165 (cfg 1: 128 x 128 ring).  Every other shape stays on the default kernel (256 x 256 tiles quantise badly at N <= 1024).
-_RING_SHAPES = {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1}
+# (N, K) -> ring configuration of vit_linear_x6r_fwd for launches of M >= 4096 rows, per arithmetic mode (cfg 3: 256 x 256 tiles, one
+# activation split per workgroup, ping-pong wave pairs; cfg 1: 128 x 128 LDS-DMA ring).  Measured with tools/probes/gemm_lab.py at M ~ 5 140
+# (profiles/r03_gemm_lab.md; TF default -> ring).  Six products: encoder qkv 168 -> 206, decoder fc1 171 -> 200, decoder qkv 166 -> 177, encoder
+# fc2 150 -> 164, encoder fc1 167 -> 175.  Three products, where the default kernel is bound by its data path, not by the matrix pipes: encoder qkv
+# 221 -> 311, fc1 223 -> 276, fc2 164 -> 283, proj 161 -> 224, decoder qkv 210 -> 252, fc1 224 -> 294, fc2 198 -> 234.  The same table serves the
+# input-gradient GEMMs (dX = dY . W is the Linear with N and K exchanged).  Outputs are bit-identical to vit_linear_x6_fwd in either mode.
+_RING_SHAPES = {
+    "bf16x6": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1, (4096, 1024): 1},
+    "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
+               (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
+}
 RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
 
 def _ring_cfg(M: int, N: int, K: int) -> int:
-    if not RING_DISPATCH or LINEAR_MODE != "bf16x6" or M < 4096:
+    if not RING_DISPATCH or M < 4096:
         return 0
-    return _RING_SHAPES.get((N, K), 0)
+    return _RING_SHAPES.get(LINEAR_MODE, {}).get((N, K), 0)
 
 
 class _FusedLinear(torch.autograd.Function):
@@ -951,7 +958,7 @@ class _FusedLinear(torch.autograd.Function):
         ring = _ring_cfg(M, N, K) if x6 else 0
         if ring:
             # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
-            # profiles/r02s_gemm_lab.jsonl measured them faster (six-product mode only: they have no three-product instantiation)
+            # tools/probes/gemm_lab.py measured them faster (per arithmetic mode: _RING_SHAPES)
             CALLS["linear_x6r"] += 1
             _check(load().vit_linear_x6r_fwd(x2.data_ptr(), split_weight_block(weight).data_ptr(), *args[:-1], ring, args[-1]), "vit_linear_x6r_fwd")
         elif x6:
@@ -992,10 +999,17 @@ class _FusedLinear(torch.autograd.Function):
                 dx = torch.empty((g2c.shape[0], K), dtype=torch.float32, device=g.device)
                 lk = ctx.link_in
                 gelu_pre = lk.pre if (lk is not None and lk.pre is not None and tuple(lk.pre.shape) == (g2c.shape[0], K)) else None
-                _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None,
-                                                gelu_pre.data_ptr() if gelu_pre is not None else None,
-                                                dx.data_ptr(), None, g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, _stream(g.device)),
-                       "vit_linear_x6_fwd (dX)")
+                ring = _ring_cfg(g2c.shape[0], K, N) if ctx.mode == LINEAR_MODE else 0
+                if ring:
+                    CALLS["linear_x6r"] += 1
+                    _check(load().vit_linear_x6r_fwd(g2c.data_ptr(), split_weight_block(ctx.weight_ref, True).data_ptr(), None,
+                                                     gelu_pre.data_ptr() if gelu_pre is not None else None, dx.data_ptr(), None,
+                                                     g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, ring, _stream(g.device)), "vit_linear_x6r_fwd (dX)")
+                else:
+                    _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None,
+                                                    gelu_pre.data_ptr() if gelu_pre is not None else None,
+                                                    dx.data_ptr(), None, g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, _stream(g.device)),
+                           "vit_linear_x6_fwd (dX)")
                 if gelu_pre is not None:
                     lk.fused = True
                 dx = dx.reshape(shp)

@@ -727,3 +727,35 @@ def test_patch_embed_as_linear_equals_the_strided_convolution():
     assert_close_rel(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 5e-6, "patch embed dx")
     assert_close_rel(pe.proj.weight.grad.cpu().numpy(), wd.grad.cpu().numpy(), 1e-5, "patch embed dW")
     assert_close_rel(pe.proj.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "patch embed db")
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("N,K,gelu", [(3072, 1024, False), (4096, 1024, True), (1024, 4096, False), (2304, 768, False), (768, 3072, False)])
+def test_ring_kernel_dispatch_is_bit_identical_forward_and_input_gradient(N, K, gelu, mode, monkeypatch):
+    """vit_ops._RING_SHAPES sends the large-M Linear shapes (forward and the input-gradient GEMM, incl. the GELU' epilogue of an fc2 behind
+    a GELU) to the LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip): same split arithmetic, same accumulation order per output element, so
+    outputs and dX must equal the default kernel's bit for bit, in six- and in three-product mode."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    torch.manual_seed(N + K)
+    M = 4100                                            # ragged: not a multiple of any tile height
+    x0 = torch.randn(M, K, device=DEV); w = (torch.randn(N, K, device=DEV) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV, requires_grad=True); g = torch.randn(M, N, device=DEV)
+    pre_for_gelu_grad = torch.randn(M, K, device=DEV)
+
+    def run(ring):
+        monkeypatch.setattr(vit_ops, "RING_DISPATCH", ring)
+        before = vit_ops.CALLS["linear_x6r"]
+        x = x0.clone().requires_grad_(True)
+        link_in = None
+        if not gelu and (K, N) in ((4096, 1024), (3072, 768)):      # this layer plays fc2: its dX runs GELU'(pre) in the epilogue
+            link_in = vit_ops.GeluLink(); link_in.pre = pre_for_gelu_grad
+        y = vit_ops.fused_linear(x, w, b, gelu=gelu, link_in=link_in)
+        (gx,) = torch.autograd.grad(y, x, g)
+        return y.detach(), gx, vit_ops.CALLS["linear_x6r"] - before
+    ya, xa, na = run(True)
+    yb, xb, nb = run(False)
+    assert nb == 0
+    want = (1 if vit_ops._RING_SHAPES[mode].get((N, K)) else 0) + (1 if vit_ops._RING_SHAPES[mode].get((K, N)) else 0)
+    assert na == want and want >= 1, (na, want)
+    assert torch.equal(ya, yb) and torch.equal(xa, xb)
