@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
         uint4 q0_, q1_, q2_;                                                                                         \
         X6_SPLIT8(S.a0, S.a1, q0_, q1_, q2_);                                                                        \
         uint4 *pa_ = sA[buf] + lrow * ROWQ;                                                                          \
-        pa_[swz(lrow, kg * 3 + 0)] = q0_; pa_[swz(lrow, kg * 3 + 1)] = q1_; pa_[swz(lrow, kg * 3 + 2)] = q2_;        \
+        pa_[swz(lrow, kg * 3 + 0)] = q0_; pa_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pa_[swz(lrow, kg * 3 + 2)] = q2_;   /* three-product mode never reads the third piece */        \
         uint4 *pb_ = sB[buf] + brow * ROWQ;                                                                          \
         pb_[swz(brow, bkg * 3 + pc0)] = S.b0; pb_[swz(brow, bkg * 3 + pc1)] = S.b1;                                  \
         if (TN == 2) pb_[swz(brow, bkg * 3 + 2)] = S.b2;                                                             \
@@ -298,10 +298,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
         uint4 q0_, q1_, q2_;                                                                                          \
         split8(make_float4(va[0], va[1], va[2], va[3]), make_float4(va[4], va[5], va[6], va[7]), q0_, q1_, q2_);      \
         uint4 *p_ = sA[buf] + c * ROWQ;                                                                               \
-        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; p_[swz(c, g * 3 + 2)] = q2_;                        \
+        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz(c, g * 3 + 2)] = q2_;                        \
         split8(make_float4(vb[0], vb[1], vb[2], vb[3]), make_float4(vb[4], vb[5], vb[6], vb[7]), q0_, q1_, q2_);      \
         p_ = sB[buf] + c * ROWQ;                                                                                      \
-        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; p_[swz(c, g * 3 + 2)] = q2_;                        \
+        p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz(c, g * 3 + 2)] = q2_;                        \
     } while (0)
 
     f32x16 acc[2][TN];
@@ -445,14 +445,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
 #define C6_LSTORE(buf, T)                                                                                             \
     do {                                                                                                              \
         uint4 *pa_ = sA[buf] + lrow * ROWQ;                                                                           \
-        pa_[swz(lrow, kg * 3 + 0)] = a0_##T; pa_[swz(lrow, kg * 3 + 1)] = a1_##T; pa_[swz(lrow, kg * 3 + 2)] = a2_##T; \
+        pa_[swz(lrow, kg * 3 + 0)] = a0_##T; pa_[swz(lrow, kg * 3 + 1)] = a1_##T; if (NPROD == 6) pa_[swz(lrow, kg * 3 + 2)] = a2_##T; \
         const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = m_##T;   /* border taps contribute zero (clamped loads) */    \
         uint4 q0_, q1_, q2_;                                                                                          \
         split8(make_float4(fmaxf(b0_##T, lo_) * mm_, fmaxf(b1_##T, lo_) * mm_, fmaxf(b2_##T, lo_) * mm_, fmaxf(b3_##T, lo_) * mm_), \
                make_float4(fmaxf(b4_##T, lo_) * mm_, fmaxf(b5_##T, lo_) * mm_, fmaxf(b6_##T, lo_) * mm_, fmaxf(b7_##T, lo_) * mm_), \
                q0_, q1_, q2_);                                                                                        \
         uint4 *pb_ = sB[buf] + c * ROWQ;                                                                              \
-        pb_[swz(c, g * 3 + 0)] = q0_; pb_[swz(c, g * 3 + 1)] = q1_; pb_[swz(c, g * 3 + 2)] = q2_;                     \
+        pb_[swz(c, g * 3 + 0)] = q0_; pb_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) pb_[swz(c, g * 3 + 2)] = q2_;                     \
     } while (0)
 
     f32x16 acc[2][TN];
@@ -603,14 +603,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
         uint4 q0_, q1_, q2_;                                                                                          \
         split8(va0, va1, q0_, q1_, q2_);                                                                              \
         uint4 *pa2_ = sA[buf] + lrow * ROWQ;                                                                          \
-        pa2_[swz(lrow, kg * 3 + 0)] = q0_; pa2_[swz(lrow, kg * 3 + 1)] = q1_; pa2_[swz(lrow, kg * 3 + 2)] = q2_;      \
+        pa2_[swz(lrow, kg * 3 + 0)] = q0_; pa2_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pa2_[swz(lrow, kg * 3 + 2)] = q2_;      \
         const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = my_##T;                                                     \
         const float m0_ = (x0_##T >= 0) ? mm_ : 0.f, m7_ = (x0_##T + 7 < W) ? mm_ : 0.f;   /* only the ends can leave the row */ \
         split8(make_float4(fmaxf(b0_##T.x, lo_) * m0_, fmaxf(b0_##T.y, lo_) * mm_, fmaxf(b0_##T.z, lo_) * mm_, fmaxf(b0_##T.w, lo_) * mm_), \
                make_float4(fmaxf(b1_##T.x, lo_) * mm_, fmaxf(b1_##T.y, lo_) * mm_, fmaxf(b1_##T.z, lo_) * mm_, fmaxf(b1_##T.w, lo_) * m7_), \
                q0_, q1_, q2_);                                                                                        \
         uint4 *pb2_ = sB[buf] + lrow * ROWQ;                                                                          \
-        pb2_[swz(lrow, kg * 3 + 0)] = q0_; pb2_[swz(lrow, kg * 3 + 1)] = q1_; pb2_[swz(lrow, kg * 3 + 2)] = q2_;      \
+        pb2_[swz(lrow, kg * 3 + 0)] = q0_; pb2_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pb2_[swz(lrow, kg * 3 + 2)] = q2_;      \
     } while (0)
 
     f32x16 acc[2][TN];

@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         bf16x8 f0, f1, f2;
         split8(lo, hi, f0, f1, f2);
         const uint32_t w = c_wr + (s_ & 1) * AC_BYTES;
-        lds_write<0>(w, f0); lds_write<BM * 16>(w, f1); lds_write<2 * BM * 16>(w, f2);
+        lds_write<0>(w, f0); lds_write<BM * 16>(w, f1);
+        if constexpr (NPROD == 6) lds_write<2 * BM * 16>(w, f2);      // three-product mode never reads the third plane
     };
 
     // prologue: A(0), A(1), A(2), B(0) land; everybody converts its share of slab 0
@@ -459,7 +460,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         }
         const uint32_t w = c_wr + (s_conv & 1) * AC_BYTES;
         lds_write<0>(w, __builtin_bit_cast(bf16x8, q0)); lds_write<BM * 16>(w, __builtin_bit_cast(bf16x8, q1));
-        lds_write<2 * BM * 16>(w, __builtin_bit_cast(bf16x8, q2));
+        if constexpr (NPROD == 6) lds_write<2 * BM * 16>(w, __builtin_bit_cast(bf16x8, q2));
     };
 
     // The two waves that share a SIMD (w and w + 4) belong to the two row halves of the tile.  The first half runs

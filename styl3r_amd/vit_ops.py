@@ -917,11 +917,11 @@ def invalidate_split_cache() -> None:
 # (N, K) -> ring configuration of vit_linear_x6r_fwd for launches of M >= 4096 rows, per arithmetic mode (cfg 3: 256 x 256 tiles, one
 # activation split per workgroup, ping-pong wave pairs; cfg 1: 128 x 128 LDS-DMA ring).  Measured with tools/probes/gemm_lab.py at M ~ 5 140
 # (profiles/r03_gemm_lab.md; TF default -> ring).  Six products: encoder qkv 168 -> 206, decoder fc1 171 -> 200, decoder qkv 166 -> 177, encoder
-# fc2 150 -> 164, encoder fc1 167 -> 175.  Three products, where the default kernel is bound by its data path, not by the matrix pipes: encoder qkv
+# fc2 150 -> 164.  Three products, where the default kernel is bound by its data path, not by the matrix pipes: encoder qkv
 # 221 -> 311, fc1 223 -> 276, fc2 164 -> 283, proj 161 -> 224, decoder qkv 210 -> 252, fc1 224 -> 294, fc2 198 -> 234.  The same table serves the
 # input-gradient GEMMs (dX = dY . W is the Linear with N and K exchanged).  Outputs are bit-identical to vit_linear_x6_fwd in either mode.
 _RING_SHAPES = {
-    "bf16x6": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1, (4096, 1024): 1},
+    "bf16x6": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1},
     "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
                (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
 }
