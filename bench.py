@@ -317,15 +317,15 @@ def train_leg(args, rank, world, dev, dist):
     # reference's own chain in float64, that bf16x3 sits INSIDE the reference's TF32 distance on every quantity (Gaussians, rendered RGB,
     # loss, every gradient: worst ratio 0.1 .. 0.84, gradients 20 - 60 x closer) -- VERDICT r02 #2's rule.  "bf16x6" (fp32 round-off
     # accuracy, the library default and the mode of every 1e-4 parity statement) is timed beside it.
-    keep_mode = vit_ops.LINEAR_MODE
+    keep_mode, keep_attn = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
     head_mode = "bf16x6" if (cpu or args.train_tiny or args.train_mode == "bf16x6") else "bf16x3"
     try:
-        vit_ops.LINEAR_MODE = head_mode
+        vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = head_mode        # Linear / conv / attention contractions: one mode
         for _ in range(args.train_warmup):
             step(batch)
         dt = dist_utils.timed_steps(lambda: step(batch), args.train_steps, sync, dist, dev)
     finally:
-        vit_ops.LINEAR_MODE = keep_mode
+        vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
     grad_bytes = sum(step.reducer.bucket_sizes_bytes())
     out = {"metric": "256x256 rendered views/sec, full C3 train step (encoder + rasterizer fwd+bwd, MSE, DP all-reduce, clip, AdamW)",
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.train_steps, world, dt), 3), "unit": "views/s",
@@ -346,7 +346,7 @@ def train_leg(args, rank, world, dev, dist):
         if not args.train_tiny:
             other = "bf16x6" if head_mode == "bf16x3" else "bf16x3"
             try:
-                vit_ops.LINEAR_MODE = other
+                vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = other
                 for _ in range(3):          # (the first steps after a switch build the other mode's packed-weight buffers)
                     step(batch)
                 dt3 = dist_utils.timed_steps(lambda: step(batch), 3, sync, dist, dev)
@@ -354,7 +354,7 @@ def train_leg(args, rank, world, dev, dist):
                               "unit": "views/s", "steps": 3, "products_per_launch": vit_ops.load().vit_x6_products(),
                               "note": "the same step in the other arithmetic mode" + (" (fp32 round-off accuracy; mode of the 1e-4 parity tests)" if other == "bf16x6" else "")}
             finally:
-                vit_ops.LINEAR_MODE = keep_mode
+                vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
                 vit_ops._x6()
             out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
     return out

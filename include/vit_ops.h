@@ -70,7 +70,8 @@ int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, cons
 /*
  * Arithmetic of the contractions of vit_attention_fwd and vit_attention_bwd: 1 (default) = bf16x6 split arithmetic on the bf16
  * MFMA (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernels'
- * error against float64 -- forward 1.3 - 1.6x, backward 1.3 - 1.55x faster), 0 = exact-f32 MFMA.  Strides that are not multiples
+ * error against float64 -- forward 1.3 - 1.6x, backward 1.3 - 1.55x faster), 0 = exact-f32 MFMA, 2 = the split-arithmetic kernels with three
+ * instead of six partial products per contraction step ("bf16x3": operands good to 2^-18, the attention counterpart of vit_x6_set_products(3)).  Strides that are not multiples
  * of 4 floats (or bases that are not 16-byte aligned) always take the f32 kernels.  Per calling thread (thread_local), read at launch time on that thread.
  */
 int vit_attention_set_arith(int mode);

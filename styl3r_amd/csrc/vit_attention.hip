@@ -217,15 +217,16 @@ __global__ void __launch_bounds__(256) k_attn_fwd(VitAttnArgs a, const float *__
 
 int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
 hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, dim3 grid,
-                                   hipStream_t stream);
+                                   int products, hipStream_t stream);
 
-// 0: both contractions on the exact-f32 MFMA (this file); 1 (default): bf16x6 split arithmetic on the bf16 MFMA (vit_attention_x6.hip).
+// 0: both contractions on the exact-f32 MFMA (this file); 1 (default): bf16x6 split arithmetic on the bf16 MFMA (vit_attention_x6.hip);
+// 2: the same kernels with three partial products per contraction step ("bf16x3": operands good to 2^-18, as vit_x6_set_products(3)).
 // Per HOST THREAD (thread_local, like vit_x6_set_products): a thread's set + launch pair cannot be interleaved with another
 // thread's choice; read at launch time on the launching thread.
 static thread_local int g_attn_arith = 1;
 int attention_set_arith(int mode)
 {
-    if (mode != 0 && mode != 1) return VIT_EINVAL;
+    if (mode < 0 || mode > 2) return VIT_EINVAL;
     g_attn_arith = mode;
     return VIT_OK;
 }
@@ -250,7 +251,7 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     // the split-arithmetic kernel loads q / k rows as float4: strides in multiples of 4 floats, 16-byte aligned bases
     const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb) & 3) && !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15);
     hipError_t e;
-    if (attention_arith() == 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, stream);
+    if (attention_arith() >= 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, attention_arith() == 2 ? 3 : 6, stream);
     else {
         if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
         else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);

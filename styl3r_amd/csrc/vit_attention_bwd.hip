@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, 3) k_attn_bwd_q(VitAttnArgs a, const floa
 int attention_tail_rows(int n_rows, int n_other, int heads_times_batch);
 int attention_arith();
 hipError_t launch_attention_bwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *dout, const float *lse,
-                                   const float *delta, float *dq, float *dk, float *dv, dim3 gkv, dim3 gq, hipStream_t stream);
+                                   const float *delta, float *dq, float *dk, float *dv, dim3 gkv, dim3 gq, int products, hipStream_t stream);
 int attention_bwd_tails(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *lse, const float *dout,
                         const float *delta, float *dq, float *dk, float *dv, int q_rows, int k_rows, hipStream_t stream);
 
@@ -303,8 +303,8 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb | a.v_sn | a.v_sh | a.v_sb) & 3) &&
                        !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15);
     hipError_t e;
-    if (attention_arith() == 1 && x6_ok) {
-        e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, stream);
+    if (attention_arith() >= 1 && x6_ok) {
+        e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, attention_arith() == 2 ? 3 : 6, stream);
     } else {
         if (rope) {
             hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);

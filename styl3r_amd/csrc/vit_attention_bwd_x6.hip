@@ -58,12 +58,16 @@ __device__ inline void split8(const float *v, bf16x8 (&f)[3])
     split2(v[6], v[7], q0.w, q1.w, q2.w);
     f[0] = __builtin_bit_cast(bf16x8, q0); f[1] = __builtin_bit_cast(bf16x8, q1); f[2] = __builtin_bit_cast(bf16x8, q2);
 }
-// six partial products, smallest first
+// NP = 6: six partial products, smallest first; NP = 3 ("bf16x3", vit_attention_set_arith(2)): the three 2^-16-level products are left
+// out -- the third bf16 piece of every operand is then never used: the compiler drops its computation, the image stores skip it
+template <int NP>
 __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c)
 {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    if (NP == 6) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
@@ -115,7 +119,7 @@ __device__ inline void fetch_row_item(RowItem &it, const float *__restrict__ bas
     it.b0 = *reinterpret_cast<const float4 *>(rp + 16); it.b1 = *reinterpret_cast<const float4 *>(rp + 20);
     if (ROPE) { it.py = (int)pos[(int64_t)gi * 2 + 0]; it.px = (int)pos[(int64_t)gi * 2 + 1]; }
 }
-template <bool ROPE>
+template <bool ROPE, int NP>
 __device__ inline void store_row_item(unsigned char *__restrict__ img, const RowItem &it, int row0, int n_valid, int i,
                                       const float *__restrict__ cos_tab, const float *__restrict__ sin_tab)
 {
@@ -139,9 +143,11 @@ __device__ inline void store_row_item(unsigned char *__restrict__ img, const Row
     bf16x8 f[3];
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(img + row * ROWB);
     split8(u, f);
-    dst[sg * 3 + 0] = f[0]; dst[sg * 3 + 1] = f[1]; dst[sg * 3 + 2] = f[2];
+    dst[sg * 3 + 0] = f[0]; dst[sg * 3 + 1] = f[1];
+    if (NP == 6) dst[sg * 3 + 2] = f[2];
     split8(w, f);
-    dst[(sg + 2) * 3 + 0] = f[0]; dst[(sg + 2) * 3 + 1] = f[1]; dst[(sg + 2) * 3 + 2] = f[2];
+    dst[(sg + 2) * 3 + 0] = f[0]; dst[(sg + 2) * 3 + 1] = f[1];
+    if (NP == 6) dst[(sg + 2) * 3 + 2] = f[2];
 }
 
 // Transposed image: item (m = i >> 5: rows 4 m .. 4 m + 3, pd = i & 31: the feature pair (d, d + 16), d = pd + 16 (pd >> 4)),
@@ -160,7 +166,7 @@ __device__ inline void fetch_t_item(TItem &it, const float *__restrict__ base, i
         if (ROPE) it.pos[e] = (int)pos[(int64_t)gi * 2 + (pd >> 4)];
     }
 }
-template <bool ROPE>
+template <bool ROPE, int NP>
 __device__ inline void store_t_item(unsigned char *__restrict__ img, const TItem &it, int row0, int n_valid, int i,
                                     const float *__restrict__ cos_tab, const float *__restrict__ sin_tab)
 {
@@ -181,14 +187,17 @@ __device__ inline void store_t_item(unsigned char *__restrict__ img, const TItem
     split2(u[0], u[1], a0.x, a1.x, a2.x);
     split2(u[2], u[3], a0.y, a1.y, a2.y);
     unsigned char *dst = img + d * TROWB + p0 * 2;
-    *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1; *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
+    *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1;
+    if (NP == 6) *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
     split2(w[0], w[1], a0.x, a1.x, a2.x);
     split2(w[2], w[3], a0.y, a1.y, a2.y);
     dst += 16 * TROWB;
-    *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1; *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
+    *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1;
+    if (NP == 6) *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
 }
 
 // first products of a tile: acc (32 tile rows x 32 lanes) = rows image . register pieces^T
+template <int NP>
 __device__ inline f32x16 rows_times_regs(const unsigned char *__restrict__ img, int col, int half, const bf16x8 (&reg)[4][3])
 {
     f32x16 acc = {0};
@@ -198,11 +207,12 @@ __device__ inline f32x16 rows_times_regs(const unsigned char *__restrict__ img, 
         bf16x8 f[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf16x8 *>(ra + t * 96 + p * 16);
-        acc = mfma6(f, reg[t], acc);
+        acc = mfma6<NP>(f, reg[t], acc);
     }
     return acc;
 }
 // second products: (lo, hi) (64 d x 32 lanes) += transposed image . x, x = 16 values per lane in D-layout register order
+template <int NP>
 __device__ inline void t_times_regs(const unsigned char *__restrict__ img, int col, int half, const f32x16 &x, f32x16 &lo, f32x16 &hi)
 {
     const unsigned char *ta = img + col * TROWB + half * 16;           // d = col (+ 32), positions 16 u + 8 half ..
@@ -215,10 +225,10 @@ __device__ inline void t_times_regs(const unsigned char *__restrict__ img, int c
         split8(xv, xf);
 #pragma unroll
         for (int p = 0; p < 3; ++p) tf[p] = *reinterpret_cast<const bf16x8 *>(ta + u * 32 + p * HD * TROWB);
-        lo = mfma6(tf, xf, lo);
+        lo = mfma6<NP>(tf, xf, lo);
 #pragma unroll
         for (int p = 0; p < 3; ++p) tf[p] = *reinterpret_cast<const bf16x8 *>(ta + u * 32 + 32 * TROWB + p * HD * TROWB);
-        hi = mfma6(tf, xf, hi);
+        hi = mfma6<NP>(tf, xf, hi);
     }
 }
 
@@ -248,7 +258,7 @@ __device__ inline void store_64(float *__restrict__ row, const f32x16 &lo, const
 }
 
 // ------------------------------------------------------------------ dQ
-template <bool ROPE>
+template <bool ROPE, int NP>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
                                                           const float *__restrict__ v, const float *__restrict__ g,
                                                           const float *__restrict__ lse, const float *__restrict__ delta,
@@ -284,14 +294,14 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
     fetch(0);
     for (int k0 = 0; k0 < a.Nk; k0 += TR) {
         __syncthreads();
-        if (tid < 128) store_row_item<ROPE>(s_k, ri, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
-        else store_row_item<false>(s_v, ri, k0, a.Nk, tid - 128, nullptr, nullptr);
-        store_t_item<ROPE>(s_kt, ti, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
+        if (tid < 128) store_row_item<ROPE, NP>(s_k, ri, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
+        else store_row_item<false, NP>(s_v, ri, k0, a.Nk, tid - 128, nullptr, nullptr);
+        store_t_item<ROPE, NP>(s_kt, ti, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
         __syncthreads();
         if (k0 + TR < a.Nk) fetch(k0 + TR);
         if (!wave_active) continue;
-        f32x16 st = rows_times_regs(s_k, col, half, qf);
-        f32x16 dp = rows_times_regs(s_v, col, half, gf);
+        f32x16 st = rows_times_regs<NP>(s_k, col, half, qf);
+        f32x16 dp = rows_times_regs<NP>(s_v, col, half, gf);
         // element r: key k0 + rowmap(r), query = this lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -299,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
             const float p = key < a.Nk ? exp2f(st[r] - lse2) : 0.f;
             dp[r] = p * (dp[r] - del) * a.scale;
         }
-        t_times_regs(s_kt, col, half, dp, dq0, dq1);
+        t_times_regs<NP>(s_kt, col, half, dp, dq0, dq1);
     }
     if (q0 + col < a.Nq) {
         if (ROPE) {
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
 }
 
 // ------------------------------------------------------------------ dK, dV
-template <bool ROPE>
+template <bool ROPE, int NP>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
                                                            const float *__restrict__ v, const float *__restrict__ g,
                                                            const float *__restrict__ lse, const float *__restrict__ delta,
@@ -354,10 +364,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
         fetch_t_item<ROPE>(tq, qb, a.q_sn, q0, a.Nq, tid, qpos);
         fetch_t_item<false>(tg, gb, g_sn, q0, a.Nq, tid, nullptr);
         __syncthreads();
-        if (tid < 128) store_row_item<ROPE>(s_q, ri, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
-        else store_row_item<false>(s_g, ri, q0, a.Nq, tid - 128, nullptr, nullptr);
-        store_t_item<ROPE>(s_qt, tq, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
-        store_t_item<false>(s_gt, tg, q0, a.Nq, tid, nullptr, nullptr);
+        if (tid < 128) store_row_item<ROPE, NP>(s_q, ri, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
+        else store_row_item<false, NP>(s_g, ri, q0, a.Nq, tid - 128, nullptr, nullptr);
+        store_t_item<ROPE, NP>(s_qt, tq, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
+        store_t_item<false, NP>(s_gt, tg, q0, a.Nq, tid, nullptr, nullptr);
         if (tid < TR) {
             const int qi = q0 + tid;
             s_lse[tid] = qi < a.Nq ? lse_b[qi] * LOG2E : INFINITY;   // padded queries: P = exp2(-inf) = 0
@@ -366,8 +376,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
         __syncthreads();
         if (q0 + TR < a.Nq) fetch(q0 + TR);
         if (!wave_active) continue;
-        f32x16 sc = rows_times_regs(s_q, col, half, kf);
-        f32x16 dp = rows_times_regs(s_g, col, half, vf);
+        f32x16 sc = rows_times_regs<NP>(s_q, col, half, kf);
+        f32x16 dp = rows_times_regs<NP>(s_g, col, half, vf);
         // element r: query q0 + rowmap(r), key = this lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -376,8 +386,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
             sc[r] = p;                                        // P
             dp[r] = p * (dp[r] - s_delta[qr]) * a.scale;      // dS (w.r.t. the unscaled dot product)
         }
-        t_times_regs(s_gt, col, half, sc, dv0, dv1);
-        t_times_regs(s_qt, col, half, dp, dk0, dk1);
+        t_times_regs<NP>(s_gt, col, half, sc, dv0, dv1);
+        t_times_regs<NP>(s_qt, col, half, dp, dk0, dk1);
     }
     if (key0 + col < a.Nk) {
         if (ROPE) {
@@ -393,15 +403,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
 
 // launched by attention_bwd (vit_attention_bwd.hip) in place of its two f32 kernels when the split-arithmetic mode is on
 hipError_t launch_attention_bwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *dout, const float *lse,
-                                   const float *delta, float *dq, float *dk, float *dv, dim3 gkv, dim3 gq, hipStream_t stream)
+                                   const float *delta, float *dq, float *dk, float *dv, dim3 gkv, dim3 gq, int products, hipStream_t stream)
 {
-    if (a.cos_tab) {
-        hipLaunchKernelGGL(abx6::k_attn_bwd_kv_x6<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dk, dv);
-        hipLaunchKernelGGL(abx6::k_attn_bwd_q_x6<true>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dq);
-    } else {
-        hipLaunchKernelGGL(abx6::k_attn_bwd_kv_x6<false>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dk, dv);
-        hipLaunchKernelGGL(abx6::k_attn_bwd_q_x6<false>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dq);
-    }
+#define ABX_LAUNCH(RP, NP_)                                                                                                              \
+    do {                                                                                                                                 \
+        hipLaunchKernelGGL((abx6::k_attn_bwd_kv_x6<RP, NP_>), gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dk, dv);          \
+        hipLaunchKernelGGL((abx6::k_attn_bwd_q_x6<RP, NP_>), gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dq);                \
+    } while (0)
+    if (a.cos_tab) { if (products == 3) ABX_LAUNCH(true, 3); else ABX_LAUNCH(true, 6); }
+    else { if (products == 3) ABX_LAUNCH(false, 3); else ABX_LAUNCH(false, 6); }
+#undef ABX_LAUNCH
     return hipGetLastError();
 }
 }  // namespace vit

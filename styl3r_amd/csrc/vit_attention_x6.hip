@@ -63,19 +63,22 @@ __device__ inline float wave_xor32(float x)
     return (threadIdx.x & 32) ? x : y;
 }
 
-// six partial products, smallest first
+// NP = 6: six partial products, smallest first; NP = 3 ("bf16x3"): without the three 2^-16-level products (see vit_attention_bwd_x6.hip)
+template <int NP>
 __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c)
 {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    if (NP == 6) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    }
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
     return c;
 }
 
-template <bool ROPE>
+template <bool ROPE, int NP>
 __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const float *__restrict__ q, const float *__restrict__ k,
                                                         const float *__restrict__ v, float *__restrict__ out, float *__restrict__ lse)
 {
@@ -169,9 +172,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
             bf16x8 f0, f1, f2;
             bf16x8 *row = reinterpret_cast<bf16x8 *>(s_k + skey * KROW);
             split8(u, f0, f1, f2);
-            row[sg * 3 + 0] = f0; row[sg * 3 + 1] = f1; row[sg * 3 + 2] = f2;
+            row[sg * 3 + 0] = f0; row[sg * 3 + 1] = f1;
+            if (NP == 6) row[sg * 3 + 2] = f2;
             split8(w, f0, f1, f2);
-            row[(sg + 2) * 3 + 0] = f0; row[(sg + 2) * 3 + 1] = f1; row[(sg + 2) * 3 + 2] = f2;
+            row[(sg + 2) * 3 + 0] = f0; row[(sg + 2) * 3 + 1] = f1;
+            if (NP == 6) row[(sg + 2) * 3 + 2] = f2;
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {   // ---- V -> transposed pieces, key axis permuted ----
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
             unsigned char *dst = s_v + lane * VROW + pos * 2;
             *reinterpret_cast<uint2 *>(dst) = w0;
             *reinterpret_cast<uint2 *>(dst + HD * VROW) = w1;
-            *reinterpret_cast<uint2 *>(dst + 2 * HD * VROW) = w2;
+            if (NP == 6) *reinterpret_cast<uint2 *>(dst + 2 * HD * VROW) = w2;
         }
         __syncthreads();
         if (k0 + KT < a.Nk) fetch(k0 + KT);
@@ -204,11 +209,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
                 bf16x8 kf[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8 *>(ka + t * 96 + p * 16);
-                st0 = mfma6(kf, qf[t], st0);
+                st0 = mfma6<NP>(kf, qf[t], st0);
                 if (two) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8 *>(kc + t * 96 + p * 16);
-                    st1 = mfma6(kf, qf[t], st1);
+                    st1 = mfma6<NP>(kf, qf[t], st1);
                 }
             }
         }
@@ -257,10 +262,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
                     const unsigned char *vp = va + blk * 64 + u * 32;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8 *>(vp + p * HD * VROW);
-                    o0 = mfma6(vf, pf, o0);
+                    o0 = mfma6<NP>(vf, pf, o0);
 #pragma unroll
                     for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8 *>(vp + 32 * VROW + p * HD * VROW);
-                    o1 = mfma6(vf, pf, o1);
+                    o1 = mfma6<NP>(vf, pf, o1);
                 }
             }
         }
@@ -283,10 +288,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
 
 // launched by attention_fwd (vit_attention.hip) when the split-arithmetic mode is on; same grid, same tail handling
 hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, dim3 grid,
-                                   hipStream_t stream)
+                                   int products, hipStream_t stream)
 {
-    if (a.cos_tab) hipLaunchKernelGGL(ax6::k_attn_fwd_x6<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
-    else hipLaunchKernelGGL(ax6::k_attn_fwd_x6<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+    if (a.cos_tab) {
+        if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        else hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 6>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+    } else {
+        if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        else hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 6>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+    }
     return hipGetLastError();
 }
 }  // namespace vit

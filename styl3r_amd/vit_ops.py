@@ -273,13 +273,17 @@ def _attn_args(q, k, v, out, scale, rope):
     return a, keep
 
 
-ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # attention contractions, forward and backward: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "f32" (exact-f32 MFMA)
+ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # attention contractions, forward and backward: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "bf16x3" (three of the six partial products) | "f32" (exact-f32 MFMA)
+_ATTN_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
 
 
-def _sync_attention_arith() -> None:
-    if ATTENTION_ARITH not in ("f32", "bf16x6"):
-        raise ValueError(f"VIT_ATTENTION = {ATTENTION_ARITH!r}: expected f32 or bf16x6")
-    want = 1 if ATTENTION_ARITH == "bf16x6" else 0
+def _sync_attention_arith(mode: Optional[str] = None) -> None:
+    """state the attention arithmetic for the calling thread (thread_local in the library): the module global by default, the mode a
+    node's forward ran in when its backward calls this from the autograd engine thread"""
+    mode = ATTENTION_ARITH if mode is None else mode
+    if mode not in _ATTN_MODES:
+        raise ValueError(f"VIT_ATTENTION = {mode!r}: expected f32, bf16x6 or bf16x3")
+    want = _ATTN_MODES[mode]
     lib = load()
     if lib.vit_attention_arith() != want:
         _check(lib.vit_attention_set_arith(want), "vit_attention_set_arith")
@@ -299,6 +303,7 @@ class _Attention(torch.autograd.Function):
                                         lse.data_ptr(), _stream(q.device)), "vit_attention_fwd")
         ctx.save_for_backward(q, k, v, out, lse, qpos, kpos)
         ctx.cfg = (scale, base, max_pos)
+        ctx.arith = ATTENTION_ARITH
         return out
 
     @staticmethod
@@ -308,7 +313,7 @@ class _Attention(torch.autograd.Function):
         lib = load()
         if not hasattr(lib, "vit_attention_bwd"):
             raise RuntimeError("vit_attention_bwd is not built into libvit_hip.so")
-        _sync_attention_arith()
+        _sync_attention_arith(ctx.arith)
         g = g.contiguous()
         dq = torch.empty(q.shape, dtype=torch.float32, device=q.device)
         dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
@@ -344,13 +349,14 @@ class _AttentionQKV(torch.autograd.Function):
                                         lse.data_ptr(), _stream(qkv.device)), "vit_attention_fwd")
         ctx.save_for_backward(qkv, out, lse, pos)
         ctx.cfg = (scale, base, max_pos)
+        ctx.arith = ATTENTION_ARITH
         return out
 
     @staticmethod
     def backward(ctx, g):
         qkv, out, lse, pos = ctx.saved_tensors
         scale, base, max_pos = ctx.cfg
-        _sync_attention_arith()
+        _sync_attention_arith(ctx.arith)
         g = g.contiguous()
         B, N, _, H, D = qkv.shape
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
@@ -925,13 +931,16 @@ _RING_SHAPES = {
     "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
                (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
 }
+# 2048 <= M < 4096 (the dual decoders' 2 570-row launches): only the wide layers still fill the chip with 128 x 128 tiles (three products,
+# M = 2 570: decoder qkv 155 -> 198, fc1 167 -> 252; the N = 768 layers LOSE there: 118 -> 89)
+_RING_SHAPES_MID = {"bf16x3": {(2304, 768): 1, (3072, 768): 1}}
 RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
 
 def _ring_cfg(M: int, N: int, K: int) -> int:
-    if not RING_DISPATCH or M < 4096:
+    if not RING_DISPATCH or M < 2048:
         return 0
-    return _RING_SHAPES.get(LINEAR_MODE, {}).get((N, K), 0)
+    return (_RING_SHAPES if M >= 4096 else _RING_SHAPES_MID).get(LINEAR_MODE, {}).get((N, K), 0)
 
 
 class _FusedLinear(torch.autograd.Function):

@@ -39,4 +39,4 @@ def _arithmetic_modes_do_not_leak():
     vo = sys.modules.get("styl3r_amd.vit_ops")
     if vo is not None and getattr(vo, "_lib", None) is not None:
         vo._lib.vit_x6_set_products(6)
-        vo._lib.vit_attention_set_arith(1 if os.environ.get("VIT_ATTENTION", "bf16x6") == "bf16x6" else 0)
+        vo._lib.vit_attention_set_arith({"f32": 0, "bf16x6": 1, "bf16x3": 2}.get(os.environ.get("VIT_ATTENTION", "bf16x6"), 1))

@@ -76,6 +76,7 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     v, H, W = SHAPES[tag]
     dev = "cuda:0"
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", mode)          # the three-product mode covers the attention contractions, too
     m = _load_heads(deterministic_init_(_mid()), G).to(dev)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
     T = lambda k: torch.tensor(G[k], device=dev)

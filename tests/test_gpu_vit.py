@@ -59,6 +59,52 @@ def attention_arith(request, monkeypatch):
     assert vit_ops.load().vit_attention_arith() == (1 if request.param == "bf16x6" else 0)     # the launch really took that kernel
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, True), (1, 2, 130, 771, False), (3, 12, 514, 256, True)])
+def test_attention_three_product_mode_forward_and_backward(B, H, Nq, Nk, rope, monkeypatch):
+    """vit_attention_set_arith(2) ("bf16x3": the split-arithmetic attention kernels without the three 2^-16-level products, third bf16
+    pieces neither computed nor staged): forward and all three gradients against float64, at the three-product accuracy (~1e-5: two
+    orders tighter than a TF32 contraction), and measurably different from the six-product result (the mode really took)."""
+    from styl3r_amd import vit_ops
+    g = torch.Generator(DEV).manual_seed(Nq + Nk)
+    q0 = torch.randn(B, Nq, H, 64, device=DEV, generator=g); k0 = torch.randn(B, Nk, H, 64, device=DEV, generator=g)
+    v0 = torch.randn(B, Nk, H, 64, device=DEV, generator=g); go = torch.randn(B, Nq, H, 64, device=DEV, generator=g)
+    qpos = (torch.arange(Nq, device=DEV)[None, :, None].expand(B, -1, 2) % 17).contiguous() if rope else None
+    kpos = (torch.arange(Nk, device=DEV)[None, :, None].expand(B, -1, 2) % 17).contiguous() if rope else None
+    res = {}
+    for mode in ("bf16x3", "bf16x6"):
+        monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", mode)
+        q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+        o = vit_ops.memory_efficient_attention(q, k, v, scale=0.125, qpos=qpos, kpos=kpos, rope_base=100.0, max_pos=16)
+        assert vit_ops.load().vit_attention_arith() == (2 if mode == "bf16x3" else 1)
+        (o * go).sum().backward()
+        res[mode] = [t.detach().double().cpu() for t in (o, q.grad, k.grad, v.grad)]
+    # float64 reference
+    qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q0, k0, v0))
+    def ref_attn(qq, kk, vv):
+        if rope:
+            def rot64(t, pos):
+                out = t.clone()
+                base = 100.0
+                inv = 1.0 / (base ** (torch.arange(0, 16, dtype=torch.float64) / 16))
+                for half, p in ((0, pos[..., 0]), (1, pos[..., 1])):
+                    ang = p.double().cpu()[..., None] * inv                   # (B, N, 16)
+                    c, s_ = ang.cos()[:, :, None, :], ang.sin()[:, :, None, :]
+                    u, w = t[..., 32 * half: 32 * half + 16], t[..., 32 * half + 16: 32 * half + 32]
+                    out = torch.cat([out[..., :32 * half], u * c - w * s_, w * c + u * s_, out[..., 32 * half + 32:]], -1)
+                return out
+            qq, kk = rot64(qq, qpos), rot64(kk, kpos)
+        att = torch.softmax(torch.einsum("bnhd,bmhd->bhnm", qq, kk) * 0.125, -1)
+        return torch.einsum("bhnm,bmhd->bnhd", att, vv)
+    od = ref_attn(qd, kd, vd)
+    (od * go.double().cpu()).sum().backward()
+    want = [od.detach(), qd.grad, kd.grad, vd.grad]
+    for name, a3, a6, w in zip(("out", "dq", "dk", "dv"), res["bf16x3"], res["bf16x6"], want):
+        e3 = float((a3 - w).abs().max() / w.abs().max()); e6 = float((a6 - w).abs().max() / w.abs().max())
+        assert e6 <= 5e-6, (name, e6)
+        assert e3 <= 5e-5, (name, e3)
+    assert not torch.equal(res["bf16x3"][0], res["bf16x6"][0])
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1), (11, 16, 257, 257), (11, 16, 260, 129), (1, 1, 1025, 1025)])
 def test_attention_forward_vs_oracle(B, H, Nq, Nk, attention_arith):
     from styl3r_amd.vit_ops import memory_efficient_attention

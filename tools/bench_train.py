@@ -29,6 +29,8 @@ args = ap.parse_args()
 if args.linear_mode:
     from styl3r_amd import vit_ops as _vo
     _vo.LINEAR_MODE = args.linear_mode
+    if args.linear_mode in ("bf16x3", "bf16x6"):
+        _vo.ATTENTION_ARITH = args.linear_mode          # one arithmetic mode for every GEMM-shaped kernel of the step
 if args.torch_linear:
     from styl3r_amd import vit as _vit
     _vit.USE_FUSED_LINEAR = False
