@@ -230,6 +230,12 @@ int vit_head_tail_bwd(const float *h, const float *w, const float *dy, float *dh
  * shape of the output).  W % 4 == 0.
  */
 int vit_im2col7(const float *img, float *cols, int B, int H, int W, void *stream);
+/*
+ * 3x3 / stride 1 / padding 1 patches of an NCHW tensor as pixel-major rows: cols (B H W, 9 Ci), column (tap, ci) with tap = 3 dy + dx,
+ * zeros outside the image, ReLU applied on the way when relu != 0.  The weight gradient of a 3x3 convolution over few pixels is then
+ * vit_linear_x6_wgrad(dY as (B H W, Co) rows, cols): the small stages of the DPT heads (dpt_block.py:79-218) need no library kernel.
+ */
+int vit_im2col3_rows(const float *in, float *cols, int B, int Ci, int H, int W, int relu, void *stream);
 int vit_upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, void *stream);
 
 /*

@@ -29,6 +29,7 @@ int layernorm_bwd(const float *dy, const float *x, const float *mean, const floa
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream);
 int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, hipStream_t stream);
 int im2col7(const float *img, float *cols, int B, int H, int W, hipStream_t stream);
+int im2col3_rows(const float *in, float *cols, int B, int Ci, int H, int W, int relu, hipStream_t stream);
 int head_tail_fwd(const float *h, const float *w, const float *bias, float *y, int B, int C, int CO, int64_t HW, float p, uint64_t seed,
                   hipStream_t stream);
 int head_tail_bwd(const float *h, const float *w, const float *dy, float *dh, float *dw, float *db, int B, int C, int CO, int64_t HW, float p,
@@ -195,6 +196,11 @@ VIT_EXPORT int vit_upsample2x_add_relu_fwd(const float *in, const float *addend,
 VIT_EXPORT int vit_im2col7(const float *img, float *cols, int B, int H, int W, void *stream)
 {
     return vit::im2col7(img, cols, B, H, W, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_im2col3_rows(const float *in, float *cols, int B, int Ci, int H, int W, int relu, void *stream)
+{
+    return vit::im2col3_rows(in, cols, B, Ci, H, W, relu, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_head_tail_fwd(const float *h, const float *w, const float *bias, float *y, int B, int C, int CO, int64_t HW, float p,

@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     // part): part 0 moves pieces 0 and 1, part 1 moves piece 2 (twice, same address): every thread issues the same two
     // loads and two LDS stores, no predication
     const int brow = TN == 2 ? lrow : (tid >> 2), bkg = TN == 2 ? kg : ((tid >> 1) & 1);
-    const int pc0 = TN == 2 ? 0 : ((tid & 1) ? 2 : 0), pc1 = TN == 2 ? 1 : ((tid & 1) ? 2 : 1);
+    // (three-product mode never reads piece 2: the part-1 threads then duplicate their partner's pieces 0 / 1 -- same cache lines, same
+    // LDS words -- instead of fetching it)
+    const int pc0 = TN == 2 ? 0 : (((tid & 1) && NPROD == 6) ? 2 : 0), pc1 = TN == 2 ? 1 : (((tid & 1) && NPROD == 6) ? 2 : 1);
     const uint4 *wb = wp + ((int64_t)min(n0 + brow, N - 1) * KG + bkg) * 3;
     // two register stages: the global loads of slab k+2 are in flight while slab k feeds the MFMAs (one slab of MFMA work,
     // ~0.35 us, is shorter than the L2/HBM latency, so a single stage leaves the wave waiting at every LDS store)
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
         S.a0 = *reinterpret_cast<const float4 *>(xa + k_); S.a1 = *reinterpret_cast<const float4 *>(xa + k_ + 4);     \
         const uint4 *p_ = wb + (k_ >> 3) * 3;                                                                        \
         S.b0 = p_[pc0]; S.b1 = p_[pc1];                                                                              \
-        if (TN == 2) S.b2 = p_[2];                                                                                   \
+        if (TN == 2 && NPROD == 6) S.b2 = p_[2];                                                                     \
     } while (0)
 #define X6_LSTORE(buf, S)                                                                                            \
     do {                                                                                                             \
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
         pa_[swz(lrow, kg * 3 + 0)] = q0_; pa_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pa_[swz(lrow, kg * 3 + 2)] = q2_;   /* three-product mode never reads the third piece */        \
         uint4 *pb_ = sB[buf] + brow * ROWQ;                                                                          \
         pb_[swz(brow, bkg * 3 + pc0)] = S.b0; pb_[swz(brow, bkg * 3 + pc1)] = S.b1;                                  \
-        if (TN == 2) pb_[swz(brow, bkg * 3 + 2)] = S.b2;                                                             \
+        if (TN == 2 && NPROD == 6) pb_[swz(brow, bkg * 3 + 2)] = S.b2;                                               \
     } while (0)
 
     f32x16 acc[2][TN];

@@ -161,6 +161,49 @@ int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hi
     return VIT_OK;
 }
 
+// 3x3 / stride 1 / padding 1 patches of an NCHW tensor as pixel-major rows: cols[(b, y, x)][(tap, ci)] = f(in[b, ci, y + dy - 1, x + dx - 1])
+// (zero outside the image; f = ReLU when `relu`), tap = 3 dy + dx.  With it the weight gradient of a 3x3 convolution over FEW pixels
+// (the 8 x 8 .. 64 x 64 stages of the DPT heads) is the Linear weight gradient dW (Co, 9 Ci) = dY^T . cols on vit_linear_x6_wgrad.
+// One workgroup = 32 pixels of one image row x 32 channels: the three source rows go through LDS (coalesced along x on the way in,
+// along ci on the way out; row stride 35 floats: conflict-free for lanes that differ in the channel).
+__global__ void __launch_bounds__(256) k_im2col3_rows(const float *__restrict__ in, float *__restrict__ cols, int B, int Ci, int H, int W, int relu)
+{
+    __shared__ float s[3][32][35];
+    const int x0 = blockIdx.x * 32, y = blockIdx.y;
+    const int ctiles = (Ci + 31) / 32;
+    const int b = blockIdx.z / ctiles, c0 = (blockIdx.z % ctiles) * 32;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * 32 * 34; i += 256) {
+        const int px = i % 34, ch = (i / 34) % 32, r = i / (34 * 32);
+        const int ys = y + r - 1, xs = x0 + px - 1, c = c0 + ch;
+        float v = 0.f;
+        if (ys >= 0 && ys < H && xs >= 0 && xs < W && c < Ci) v = in[(((int64_t)b * Ci + c) * H + ys) * W + xs];
+        s[r][ch][px] = relu ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
+    const int ch = tid & 31, pr = tid >> 5;
+    if (c0 + ch >= Ci) return;
+    for (int px = pr; px < 32; px += 8) {
+        const int x = x0 + px;
+        if (x >= W) break;
+        float *row = cols + (((int64_t)b * H + y) * W + x) * (9 * (int64_t)Ci) + c0 + ch;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) row[(int64_t)tap * Ci] = s[tap / 3][ch][px + tap % 3];
+    }
+}
+
+int im2col3_rows(const float *in, float *cols, int B, int Ci, int H, int W, int relu, hipStream_t stream)
+{
+    if (!in || !cols || B <= 0 || Ci <= 0 || H <= 0 || W <= 0) return VIT_EINVAL;
+    const int64_t gz = (int64_t)B * ((Ci + 31) / 32);
+    if (gz > 65535 || H > 65535) return VIT_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_im2col3_rows, dim3((W + 31) / 32, H, (unsigned)gz), dim3(256), 0, stream, in, cols, B, Ci, H, W, relu);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
 int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, int64_t planes, int H, int W, hipStream_t stream)
 {
     if (!in || !addend || !out || planes <= 0 || H <= 0 || W <= 0 || (W & 1)) return VIT_EINVAL;

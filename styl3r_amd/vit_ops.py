@@ -35,7 +35,7 @@ LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
            "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
-           "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_upsample2x_add_relu_fwd", "vit_version", "vit_last_error")
+           "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
 
@@ -155,6 +155,8 @@ def load() -> C.CDLL:
     lib.vit_head_tail_bwd.restype = C.c_int
     lib.vit_im2col7.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_im2col7.restype = C.c_int
+    lib.vit_im2col3_rows.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_im2col3_rows.restype = C.c_int
     lib.vit_upsample2x_add_relu_fwd.argtypes = [vp, vp, vp, C.c_int64, C.c_int, C.c_int, vp]
     lib.vit_upsample2x_add_relu_fwd.restype = C.c_int
     lib.vit_version.restype = C.c_char_p
@@ -612,18 +614,12 @@ class _ConvX6(torch.autograd.Function):
         elif need_w and k == 3 and weight.shape[1] % 16 == 0 and _x6() and SMALL_CONV_WGRAD == "linear":
             # 3x3 layers with few pixels (the 8 x 8 .. 64 x 64 stages): the split-pixel kernel's 16-pixel slabs of short image rows
             # lose there, so the gradient goes through the LINEAR weight-gradient kernel instead: dW (Co, 9 Ci) = dY^T (Co, P) . cols (P, 9 Ci)
-            # with the pixel-major operands built by one channels-last copy each and ONE gather of the nine taps (row h w of the
-            # padded grid = zeros); the ReLU of a residual unit is applied to the channels-last copy.  No library kernel.
+            # with the pixel-major operands built by vit_im2col3_rows (the nine taps, the ReLU of a residual unit applied on the way) and one
+            # channels-last copy of dY.  No library kernel.
             Co, Ci = weight.shape[0], weight.shape[1]
-            P, HW = B_ * H_ * W_, H_ * W_
-            grid = torch.empty((B_, HW + 1, Ci), dtype=torch.float32, device=g.device)
-            grid[:, HW].zero_()
-            dst, src = grid[:, :HW].view(B_, H_, W_, Ci), x.permute(0, 2, 3, 1)
-            if ctx.relu_in:
-                torch.clamp_min(src, 0.0, out=dst)          # channels-last copy and ReLU in one pass
-            else:
-                dst.copy_(src)
-            cols = torch.index_select(grid.view(B_ * (HW + 1), Ci), 0, _tap3_index(B_, H_, W_, g.device)).view(P, 9 * Ci)
+            P = B_ * H_ * W_
+            cols = torch.empty((P, 9 * Ci), dtype=torch.float32, device=g.device)
+            _check(load().vit_im2col3_rows(x.data_ptr(), cols.data_ptr(), B_, Ci, H_, W_, 1 if ctx.relu_in else 0, _stream(g.device)), "vit_im2col3_rows")
             gt = g.permute(0, 2, 3, 1).reshape(P, Co).contiguous()
             buf = torch.empty(Co * 9 * Ci + (Co if need_b else 0), dtype=torch.float32, device=g.device)
             dwl = buf[:Co * 9 * Ci].view(Co, 9 * Ci)
@@ -636,24 +632,6 @@ class _ConvX6(torch.autograd.Function):
             _, dw, db = torch.ops.aten.convolution_backward(g, f_x(), weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
                                                             [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
         return dx, dw, db, (g if need_r else None), None
-
-
-_TAP3: dict = {}
-
-
-def _tap3_index(B: int, H: int, W: int, device) -> Tensor:
-    """flat row index into the (B, H W + 1, Ci) channels-last grid (row H W of every image = zero padding) of tap (dy, dx) of pixel
-    (b, y, x) of a 3x3 / stride 1 / padding 1 convolution, laid out [(b, y, x), (dy, dx)]"""
-    key = (B, H, W, str(device))
-    if key not in _TAP3:
-        if len(_TAP3) > 64:
-            _TAP3.clear()
-        y, x, dy, dx = torch.meshgrid(torch.arange(H), torch.arange(W), torch.arange(3), torch.arange(3), indexing="ij")
-        sy, sx = y + dy - 1, x + dx - 1
-        inside = (sy >= 0) & (sy < H) & (sx >= 0) & (sx < W)
-        one = torch.where(inside, sy * W + sx, torch.full_like(sy, H * W)).reshape(-1)
-        _TAP3[key] = (one[None, :] + torch.arange(B)[:, None] * (H * W + 1)).reshape(-1).to(device)
-    return _TAP3[key]
 
 
 class Conv2dX6(nn.Conv2d):
@@ -924,8 +902,8 @@ def invalidate_split_cache() -> None:
 # activation split per workgroup, ping-pong wave pairs; cfg 1: 128 x 128 LDS-DMA ring).  Measured with tools/probes/gemm_lab.py at M ~ 5 140
 # (profiles/r03_gemm_lab.md; TF default -> ring).  Six products: encoder qkv 168 -> 206, decoder fc1 171 -> 200, decoder qkv 166 -> 177, encoder
 # fc2 150 -> 164.  Three products, where the default kernel is bound by its data path, not by the matrix pipes: encoder qkv
-# 221 -> 311, fc1 223 -> 276, fc2 164 -> 283, proj 161 -> 224, decoder qkv 210 -> 252, fc1 224 -> 294, fc2 198 -> 234.  The same table serves the
-# input-gradient GEMMs (dX = dY . W is the Linear with N and K exchanged).  Outputs are bit-identical to vit_linear_x6_fwd in either mode.
+# 221 -> 311, fc1 223 -> 276, fc2 164 -> 283, proj 161 -> 224, decoder qkv 210 -> 252, fc1 224 -> 294, fc2 198 -> 234.  In three-product mode the
+# same table serves the input-gradient GEMMs (dX = dY . W is the Linear with N and K exchanged).  Outputs are bit-identical to vit_linear_x6_fwd.
 _RING_SHAPES = {
     "bf16x6": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1},
     "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
@@ -1008,7 +986,8 @@ class _FusedLinear(torch.autograd.Function):
                 dx = torch.empty((g2c.shape[0], K), dtype=torch.float32, device=g.device)
                 lk = ctx.link_in
                 gelu_pre = lk.pre if (lk is not None and lk.pre is not None and tuple(lk.pre.shape) == (g2c.shape[0], K)) else None
-                ring = _ring_cfg(g2c.shape[0], K, N) if ctx.mode == LINEAR_MODE else 0
+                # (input-gradient GEMMs take the ring kernels in three-product mode only: in six-product mode the A/B on the whole step lost 3 ms)
+                ring = _ring_cfg(g2c.shape[0], K, N) if (ctx.mode == LINEAR_MODE == "bf16x3") else 0
                 if ring:
                     CALLS["linear_x6r"] += 1
                     _check(load().vit_linear_x6r_fwd(g2c.data_ptr(), split_weight_block(ctx.weight_ref, True).data_ptr(), None,
