@@ -123,10 +123,8 @@ __global__ void __launch_bounds__(256) k_upsample2x_bwd(const float *__restrict_
             const float *row = dout + (pl * OH + oy) * OW;
             float r = 0.f;
 #pragma unroll
-            for (int e = 0; e < 6; ++e) {
-                const int ox = ox0 + e;
-                if (wx[e] != 0.f) r += wx[e] * row[ox];
-            }
+            for (int e = 0; e < 6; ++e)      // branch-free: columns outside the row carry weight 0 and read a clamped address
+                r += wx[e] * row[min(max(ox0 + e, 0), OW - 1)];
             acc += wy * r;
         }
         din[idx] = acc;

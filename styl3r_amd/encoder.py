@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from .decoder import Gaussians
-from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg
+from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg, _linear
 from .vit_ops import Conv2dX6, fused_linear, head_tail, input_merger_upsample_add, relu_dropout, upsample2x
 
 inf = float("inf")
@@ -210,7 +210,7 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         the memory of the other decoder is the first tensor itself, so the C2 / C3 path copies nothing at all.  For
         v > 2 the memory of view i >= 1 (view 0 followed by the other rest views) is gathered once per layer."""
         b, v, l, c = feat.shape
-        cur = self.decoder_embed(feat)
+        cur = _linear(self.decoder_embed, feat)
         f1, f2 = cur[:, 0].contiguous(), cur[:, 1:].reshape(b * (v - 1), l, -1)
         p1 = pos[:, 0].contiguous()
         p2 = pos[:, 1:].reshape(b * (v - 1), l, 2)
@@ -272,13 +272,13 @@ class TokenStylizer(CrocoTrunk):
         x, spos = self.patch_embed(style["image"])
         for blk in self.enc_blocks:
             x = blk(x, spos)
-        return self.decoder_embed(self.enc_norm(x)), spos
+        return _linear(self.decoder_embed, self.enc_norm(x)), spos
 
     def forward(self, style: dict, content_feat: Tensor, content_pos: Tensor, encoded=None):
         style_feat, spos = encoded if encoded is not None else self.encode_style(style)
         b, v, l, c = content_feat.shape
         outs = [content_feat]
-        cf = self.decoder_embed(content_feat.reshape(b, v * l, c))
+        cf = _linear(self.decoder_embed, content_feat.reshape(b, v * l, c))
         cpos = content_pos.reshape(b, v * l, 2)
         for blk in self.dec_blocks:
             cf, _ = blk(cf, style_feat, cpos, spos)
@@ -306,7 +306,7 @@ class StructureBuilder(nn.Module):
 
     def forward(self, feat1: Tensor, pos1: Tensor, feat2: Tensor, pos2: Tensor):
         outs = [(feat1, feat2)]
-        x = torch.cat((self.decoder_embed(feat1), self.decoder_embed(feat2)), dim=1)
+        x = torch.cat((_linear(self.decoder_embed, feat1), _linear(self.decoder_embed, feat2)), dim=1)
         pos = torch.cat((pos1, pos2), dim=1)
         for blk in self.dec_blocks:
             x = blk(x, pos)
