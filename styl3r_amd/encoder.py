@@ -14,9 +14,11 @@ Own restatement (same parameter names, so reference checkpoints load unchanged) 
   * `get_encoder`                   src/model/encoder/__init__.py:20-25
 Everything heavy runs on hand-written gfx950 kernels, all fp32-accurate like the reference (heads under
 autocast(enabled=False), encoder_noposplat_multi_token_style.py:150): transformer blocks on styl3r_amd.vit (flash attention with
-fused RoPE in bf16x6 split arithmetic on the bf16 MFMA -- exact-f32-MFMA kernels behind VIT_ATTENTION=f32 -- bf16x6 Linear layers with bias / GELU / residual epilogues, HIP LayerNorm), the DPT heads' 3x3 /
-1x1 stride-1 convolutions and x2 resampling on vit_conv_x6_* / vit_upsample2x_*, the head tails + Gaussian adapter on
-vit_adapter_*.  Only the small-resolution / strided / transposed / 7x7 convolutions stay on MIOpen.
+fused RoPE in bf16x6 split arithmetic on the bf16 MFMA -- exact-f32-MFMA kernels behind VIT_ATTENTION=f32 -- bf16x6 Linear layers with bias / GELU / residual epilogues, HIP LayerNorm), the DPT heads entirely on own kernels since
+round 3: reassemble stage (1x1 / transposed / strided convolutions on the token grid) and patch embedding as Linear layers, every 3x3 / 1x1
+stride-1 convolution on vit_conv_x6_* at every size, x2 resampling on vit_upsample2x_*, the 7x7 input merger via vit_im2col7, the head tails
+(ReLU [-> Dropout] -> 1x1 convolution) on vit_head_tail_*, then the Gaussian adapter on vit_adapter_*.  No library convolution or GEMM is left
+on the float32 device path (CPU tensors -- the fixture generators' side -- take the framework ops).
 """
 from __future__ import annotations
 
