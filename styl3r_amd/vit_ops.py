@@ -5,13 +5,18 @@ Mirrors the reference operator interfaces:
     (in-place on the (B,H,N,D) view, backward = same kernel with -F0)                          -> vit_rope2d
   * `memory_efficient_attention(q, k, v, scale=, p=0)` on (B,N,H,64) fp32 tensors, blocks.py:129,195
                                                                                               -> vit_attention_fwd / _bwd
-    (bf16x6 split arithmetic on the bf16 MFMA by default, VIT_ATTENTION=f32: exact-f32 MFMA; fused RoPE in both)
+    (bf16x6 split arithmetic on the bf16 MFMA by default, VIT_ATTENTION=f32: exact-f32 MFMA, =bf16x3: three products; fused RoPE in all;
+     `attention_qkv`: the packed (B,N,3,H,64) projection of a self-attention, whose backward writes ONE gradient tensor)
   * `nn.Linear` (+ exact GELU, + residual add) of Mlp / Attention / Block, blocks.py:76-82,100,131,149-152
     -> `fused_linear`: vit_linear_x6_fwd (fp32-accurate bf16x6, default) or vit_linear_fwd (exact-f32 MFMA), dX on the
        pre-split transposed weight, dW + db on vit_linear_x6_wgrad (accumulating into all-reduce bucket slices);
-       VIT_LINEAR_MODE=bf16x3: three instead of six partial products per launch (opt-in, ~4e-6 per GEMM)
+       VIT_LINEAR_MODE=bf16x3: three instead of six partial products per launch (~4e-6 per GEMM; third pieces neither computed nor staged);
+       large-M shapes go to the LDS-DMA ring kernels (vit_linear_x6r_fwd, `_RING_SHAPES`); `GeluLink`: GELU' in fc2's dX epilogue
   * `nn.LayerNorm(eps=1e-6)`, blocks.py:144-152,205-222                                        -> `LayerNorm` (vit_layernorm_*)
-  * `nn.Conv2d` 3x3 / 1x1 stride 1 of the DPT heads and VGG, dpt_block.py:79-218,350-419      -> `Conv2dX6` (vit_conv_x6_*)
+  * `nn.Conv2d` 3x3 / 1x1 stride 1 of the DPT heads and VGG, dpt_block.py:79-218,350-419      -> `Conv2dX6` (vit_conv_x6_*; small 3x3 dW:
+    vit_im2col3_rows + vit_linear_x6_wgrad)
+  * head tails ReLU [-> Dropout] -> Conv2d(C, 3 | 8, 1), dpt_block.py:319-320,337-339         -> `head_tail` (vit_head_tail_*)
+  * `feat_up(path_1) + ReLU(Conv2d(3, 256, 7, 1, 3)(imgs))`, dpt_gs_head.py:113-118,146-148   -> `input_merger_upsample_add`
   * `F.interpolate(scale_factor=2, bilinear, align_corners=True)`                             -> `upsample2x`
   * reg_dense_depth + opacity map + UnifiedGaussianAdapter + build_covariance                 -> `gaussian_adapter_hip`
 `CALLS` counts how often each hand-written kernel was taken (the parity tests assert on it).
