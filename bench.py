@@ -382,21 +382,31 @@ def infer_leg(args, dev):
     ex = lambda t: t.to(dev)[None].contiguous()
     cams = [ex(sc.extrinsics), ex(sc.intrinsics), ex(sc.near), ex(sc.far)]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    t_enc = t_ras = 0.0
     steps, warm = 20, 4
-    with torch.no_grad():
-        for i in range(warm + steps):
-            ev[0].record()
-            gs = enc(ctx, style, 0)
-            ev[1].record()
-            dec.forward(gs, *cams, (H, H))
-            ev[2].record()
-            torch.cuda.synchronize(dev)
-            if i >= warm:
-                t_enc += ev[0].elapsed_time(ev[1]); t_ras += ev[1].elapsed_time(ev[2])
-    out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", "encoder_ms": round(t_enc / steps, 3),
-           "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3), "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2),
-           "gaussians": int(gs.means.shape[1]), "steps": steps, "linear_arithmetic": vit_ops.LINEAR_MODE, "encoder_launch": "eager, heads + style branch on side streams",
+
+    def timed(mode):
+        keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
+        vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = mode
+        t_enc = t_ras = 0.0
+        try:
+            with torch.no_grad():
+                for i in range(warm + steps):
+                    ev[0].record()
+                    gs = enc(ctx, style, 0)
+                    ev[1].record()
+                    dec.forward(gs, *cams, (H, H))
+                    ev[2].record()
+                    torch.cuda.synchronize(dev)
+                    if i >= warm:
+                        t_enc += ev[0].elapsed_time(ev[1]); t_ras += ev[1].elapsed_time(ev[2])
+        finally:
+            vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
+        return {"encoder_ms": round(t_enc / steps, 3), "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3),
+                "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1])}
+
+    # bf16x6 = the arithmetic of the 1e-4 RGB statement against fp32; bf16x3 = the TF32-class mode the train leg's headline uses (tests/test_e2e_parity.py bounds both)
+    out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("bf16x6"), "steps": steps,
+           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "encoder_launch": "eager, heads + style branch on side streams",
            "dtype": "f32", "data": "synthetic, random-init weights"}
     del enc, dec
     torch.cuda.empty_cache()

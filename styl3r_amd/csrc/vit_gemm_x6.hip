@@ -21,6 +21,7 @@
 // loads of slab k+2 in flight while slab k feeds the MFMAs; three workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <atomic>
 
@@ -274,34 +275,40 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
     const int base = nslab / S, rem = nslab % S;
     const int s_lo = sp * base + min(sp, rem), nk = base + (sp < rem ? 1 : 0);
 
-    const int c = tid & 127, g = tid >> 7;                      // column of the tile, 8-row group of the slab
-    const float *pa = dy + min(n0 + c, N - 1);                  // + m * N
-    const float *pb = x + min(k0 + c, K - 1);                   // + m * K
+    // column of the tile, 8-row group of the slab (the group is wave-uniform: waves 0-1 / 2-3)
+    const int c = tid & 127, g = __builtin_amdgcn_readfirstlane(tid >> 7);
+    // Buffer loads: the row walk (m * N * 4 bytes) is a wave-uniform scalar added to the thread's constant column offset -- one 32-bit
+    // add per load instead of 64-bit address arithmetic (r03: the flat-pointer form spent 2/3 of its VALU cycles on v_mad_i64 /
+    // v_lshl_add_u64, twice the MFMA time in three-product mode).  The descriptors start at the split's first row and end at row M:
+    // rows past M read as zero in hardware, so there is no clamp and no mask.
+    const int64_t row0 = (int64_t)s_lo * BK;
+    const int64_t left = max((int64_t)M - row0, (int64_t)0);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + row0 * N), 0, (int)min(left * N * 4, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + row0 * K), 0, (int)min(left * K * 4, (int64_t)0x7fffffff), 0x00020000);
+    const int voa = min(n0 + c, N - 1) * 4, vob = min(k0 + c, K - 1) * 4;
+    const int N4 = N * 4, K4 = K * 4;
+    const bool want_bias = dbias != nullptr && tk_ == 0;          // (workgroup-uniform)
     struct Stage { float a[8], b[8]; };
     Stage st0, st1;
     float bsum = 0.f;
 #define W6_GLOAD(S_, slab)                                                                                            \
     do {                                                                                                              \
-        const int m_ = (s_lo + min((slab), nk - 1)) * BK + g * 8;                                                     \
+        const int m_ = (slab) * BK + g * 8;            /* row within the split (past its end: loaded, never consumed) */ \
         _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                               \
-            const int mr = min(m_ + r, M - 1);                                                                        \
-            S_.a[r] = pa[(int64_t)mr * N]; S_.b[r] = pb[(int64_t)mr * K];                                             \
+            S_.a[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_a, voa + (m_ + r) * N4, 0, 0));   \
+            S_.b[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, vob + (m_ + r) * K4, 0, 0));   \
         }                                                                                                             \
     } while (0)
 #define W6_LSTORE(buf, S_, slab)                                                                                      \
     do {                                                                                                              \
-        const int m_ = (s_lo + (slab)) * BK + g * 8;                                                                  \
-        float va[8], vb[8];                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                               \
-            const bool ok = (slab) < nk && m_ + r < M;   /* rows past M / past this split: zero (loads were clamped) */ \
-            va[r] = ok ? S_.a[r] : 0.f; vb[r] = ok ? S_.b[r] : 0.f;                                                   \
-            bsum += va[r];                                                                                            \
+        if (want_bias && (slab) < nk) {                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) bsum += S_.a[r];                                            \
         }                                                                                                             \
         uint4 q0_, q1_, q2_;                                                                                          \
-        split8(make_float4(va[0], va[1], va[2], va[3]), make_float4(va[4], va[5], va[6], va[7]), q0_, q1_, q2_);      \
+        split8(make_float4(S_.a[0], S_.a[1], S_.a[2], S_.a[3]), make_float4(S_.a[4], S_.a[5], S_.a[6], S_.a[7]), q0_, q1_, q2_); \
         uint4 *p_ = sA[buf] + c * ROWQ;                                                                               \
         p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz(c, g * 3 + 2)] = q2_;                        \
-        split8(make_float4(vb[0], vb[1], vb[2], vb[3]), make_float4(vb[4], vb[5], vb[6], vb[7]), q0_, q1_, q2_);      \
+        split8(make_float4(S_.b[0], S_.b[1], S_.b[2], S_.b[3]), make_float4(S_.b[4], S_.b[5], S_.b[6], S_.b[7]), q0_, q1_, q2_); \
         p_ = sB[buf] + c * ROWQ;                                                                                      \
         p_[swz(c, g * 3 + 0)] = q0_; p_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz(c, g * 3 + 2)] = q2_;                        \
     } while (0)
@@ -340,6 +347,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
             }
     };
 
+    // (r03, measured and dropped: four register stages instead of two -- one workgroup alone needs 0.65 us per 16-row slab either way,
+    // so that chain is not memory latency; the extra 32 VGPRs only cost the third resident workgroup per CU)
     if (nk > 0) {
         W6_GLOAD(st0, 0);
         W6_GLOAD(st1, 1);
@@ -353,7 +362,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
             W6_GLOAD(st1, kt + 3);
             __syncthreads();
             compute(1);
-            W6_LSTORE(0, st0, kt + 2);   // (past the last slab: rows >= M of this split are masked or never read)
+            W6_LSTORE(0, st0, kt + 2);   // (past the split's last slab: staged, never multiplied)
             W6_GLOAD(st0, kt + 4);
             __syncthreads();
         }
@@ -381,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
             }
         }
     }
-    if (dbias && tk_ == 0 && n0 + c < N) atomicAdd(dbias + n0 + c, bsum);
+    if (want_bias && n0 + c < N) atomicAdd(dbias + n0 + c, bsum);
 }
 
 // 3x3 (pad 1, stride 1) and 1x1 convolution of the DPT heads (E9) as an implicit GEMM on the same bf16x6 core:
@@ -747,10 +756,11 @@ static int split_count(int tiles, int nslab, int min_slabs)
     // of atomics over the output tile (-1 % per split in the score)
     int best = 1;
     float best_score = -1.f;
+    constexpr int slots = 512;
     for (int S = 1; S <= 128; ++S) {
         if (S > 1 && nslab / S < min_slabs) break;
-        const int wg = tiles * S, rounds = (wg + 511) / 512;
-        const float score = (float)wg / (float)(rounds * 512) - 0.002f * (float)S;
+        const int wg = tiles * S, rounds = (wg + slots - 1) / slots;
+        const float score = (float)wg / (float)(rounds * slots) - 0.002f * (float)S;
         if (score > best_score) { best_score = score; best = S; }
     }
     return best;
@@ -813,6 +823,29 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     return VIT_OK;
 }
 
+// Contraction splits of the Linear weight gradient from a measured cost model (tools/probes/wgrad_lab.py, VIT_WGRAD_S sweeps at M = 5 140,
+// profiles/r03_wgrad_splits.md).  k_wgrad_x6 keeps up to three workgroups resident per CU; a workgroup advances one 16-row slab every
+// t[c] us with c of them on its CU, and the CU's throughput saturates at two (t_sat = t[2] / 2); every workgroup also pays ~8 slabs' worth
+// of pipeline fill + atomic epilogue, every split one more pass of atomics over the output:
+//     cost(S) = max(chain x t[c], workgroups per CU x chain x t_sat) + S us,    chain = slabs per split + 8
+// r02's rule ("fill 512 slots once") left the 192- / 108- / 144-tile outputs (qkv, decoder fc) at S = 2 / 4 / 3 where S = 4 / 7 / 5 is 16 - 25 % faster.
+static int wgrad_splits(int tiles, int nslab, int products)
+{
+    static const float t3[4] = {0.f, 0.66f, 1.07f, 1.53f}, t6[4] = {0.f, 0.95f, 1.62f, 2.48f};
+    const float *t = products == 3 ? t3 : t6;
+    const float t_sat = 0.5f * t[2];
+    int best = 1;
+    float best_cost = 1e30f;
+    for (int S = 1; S <= 64; ++S) {
+        if (S > 1 && nslab / S < 8) break;
+        const float per_cu = (float)tiles * (float)S / 256.f, chain = (float)((nslab + S - 1) / S) + 8.f;
+        const int c = per_cu <= 1.f ? 1 : (per_cu <= 2.f ? 2 : 3);
+        const float cost = fmaxf(chain * t[c], per_cu * chain * t_sat) + (float)S;
+        if (cost < best_cost) { best_cost = cost; best = S; }
+    }
+    return best;
+}
+
 int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, int M, int N, int K, int accumulate,
                     hipStream_t stream)
 {
@@ -820,7 +853,11 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     const int tiles = ((N + x6::BM - 1) / x6::BM) * ((K + 127) / 128);
     const int nslab = (M + x6::BK - 1) / x6::BK;
     // split M so that tiles x S fills the 512 resident workgroups (256 CUs x 2) ONCE: 1.1 rounds cost as much as 2
-    int S = split_count(tiles, nslab, 16);
+    int S = wgrad_splits(tiles, nslab, x6_products());
+    { static const char *force = getenv("VIT_WGRAD_S"); if (force) S = atoi(force); }   // (tools/probes/wgrad_lab.py sweeps)
+    // the kernel addresses a split's rows with 32-bit byte offsets from the split's first row (+ 4 slabs of prefetch)
+    while (((int64_t)(nslab / S) + 6) * x6::BK * (int64_t)(N > K ? N : K) * 4 >= 0x7fffffffLL && S < 65535) ++S;
+    if (((int64_t)(nslab / S) + 6) * x6::BK * (int64_t)(N > K ? N : K) * 4 >= 0x7fffffffLL) return VIT_EINVAL;
     (void)hipGetLastError();
     if (!accumulate) {   // accumulate: dw / dbias already hold the running gradient (e.g. a zeroed all-reduce bucket slice)
         // one memset when the caller laid db out right behind dw (vit_ops.py does)

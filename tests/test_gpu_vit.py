@@ -286,6 +286,37 @@ def test_bf16x6_linear_matches_fp64_like_the_f32_mfma_path(M, N, K, gelu, monkey
         assert errs["bf16x6"][k] <= 3.0 * errs["f32"][k] + 2e-7, errs
 
 
+@pytest.mark.parametrize("M,N,K", [(5140, 1024, 1024), (1028, 3072, 768), (77, 40, 64), (16, 128, 128), (9, 8, 264), (2570, 200, 4096), (40000, 24, 2304)])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_linear_weight_gradient_kernel_ragged_shapes_vs_fp64(M, N, K, mode, monkeypatch):
+    """vit_linear_x6_wgrad (buffer-load row walk, rows past M read as zero in hardware, M split across workgroups): dW and db against
+    float64 on ragged M / N / K (not multiples of the 16-row slab or the 128 x 128 tile), with and without the bias gradient, and in
+    accumulate mode on top of a running gradient"""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    vit_ops._x6()                                                    # products per launch follow LINEAR_MODE
+    lib = vit_ops.load()
+    g = torch.Generator(DEV).manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, device=DEV, generator=g); dy = torch.randn(M, N, device=DEV, generator=g)
+    want_w = dy.double().t() @ x.double(); want_b = dy.double().sum(0)
+    bar = 4e-6 if mode == "bf16x6" else 2e-5
+    s = torch.cuda.current_stream().cuda_stream
+    for with_bias in (True, False):
+        buf = torch.full((N * K + N,), float("nan"), device=DEV)
+        dw, db = buf[:N * K].view(N, K), buf[N * K:]
+        rc = lib.vit_linear_x6_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if with_bias else None, M, N, K, s)
+        assert rc == 0
+        assert float((dw.double() - want_w).abs().max() / want_w.abs().max()) <= bar
+        if with_bias:
+            assert float((db.double() - want_b).abs().max() / want_b.abs().max()) <= 4e-6
+    run_w = torch.randn(N, K, device=DEV, generator=g); run_b = torch.randn(N, device=DEV, generator=g)
+    buf = torch.cat((run_w.flatten(), run_b))
+    dw, db = buf[:N * K].view(N, K), buf[N * K:]
+    assert lib.vit_linear_x6_wgrad_acc(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), M, N, K, s) == 0
+    assert float((dw.double() - (want_w + run_w.double())).abs().max() / want_w.abs().max()) <= bar
+    assert float((db.double() - (want_b + run_b.double())).abs().max() / want_b.abs().max()) <= 4e-6
+
+
 def test_bf16x3_mode_is_two_orders_tighter_than_tf32_on_every_split_arithmetic_kernel(monkeypatch):
     """VIT_LINEAR_MODE=bf16x3 (three partial products per launch instead of six: include/vit_ops.h vit_x6_set_products): Linear
     forward / dX / dW / db and the 3x3 convolution forward / dX / dW against float64.  Bars: 2e-5 of the output scale (measured
