@@ -265,6 +265,24 @@ int vit_adapter_bwd(const VitAdapterArgs *a, const float *d_means, const float *
 const char *vit_version(void);
 const char *vit_last_error(void);
 
+/* ---- optimizer pass (vit_optim.hip): AdamW of model_wrapper_style.py:885-895 over every parameter of a group in ONE launch ----
+ * chunks: device array; chunk i = n contiguous fp32 elements of one parameter (p), its gradient (g), first / second moment (m, v) and the
+ * parameter's device-resident step counter (float, already incremented for this step, torch.optim.AdamW's state["step"] of a fused optimizer);
+ * vec != 0 promises that p, g, m, v are 16-byte aligned.  grad_scale (device, may be NULL): every gradient is divided by it while it is read
+ * (the clip coefficient deferred by ddp.BucketedGradReducer.clip_grad_norm_(defer_to=...)); the stored gradient is left as it is.
+ * Arithmetic and update order of the framework's fused AdamW (amsgrad = maximize = false). */
+typedef struct VitAdamChunk {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    const float *step;
+    int32_t n;
+    int32_t vec;
+} VitAdamChunk;
+int vit_adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   const float *grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

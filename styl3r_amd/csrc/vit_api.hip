@@ -45,6 +45,8 @@ size_t x6c_workspace_bytes(int M, int N, int splits);
 int x6c_choose_splits(int M, int N, int K);
 int linear_x6c_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K,
                    int act, int splits, void *workspace, size_t workspace_bytes, hipStream_t stream);
+int adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+               const float *grad_scale, hipStream_t stream);
 int x6_set_products(int n);
 int x6_products();
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
@@ -100,6 +102,11 @@ VIT_EXPORT int vit_linear_x6_fwd(const float *x, const void *w_packed, const flo
 
 VIT_EXPORT int vit_attention_set_arith(int mode) { return vit::attention_set_arith(mode); }
 VIT_EXPORT int vit_attention_arith(void) { return vit::attention_arith(); }
+VIT_EXPORT int vit_adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              const float *grad_scale, void *stream)
+{
+    return vit::adamw_step(chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, grad_scale, static_cast<hipStream_t>(stream));
+}
 VIT_EXPORT int vit_x6_set_products(int n) { return vit::x6_set_products(n); }
 VIT_EXPORT int vit_x6_products(void) { return vit::x6_products(); }
 

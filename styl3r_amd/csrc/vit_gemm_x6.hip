@@ -301,8 +301,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
     } while (0)
 #define W6_LSTORE(buf, S_, slab)                                                                                      \
     do {                                                                                                              \
-        if (want_bias && (slab) < nk) {                                                                               \
-            _Pragma("unroll") for (int r = 0; r < 8; ++r) bsum += S_.a[r];                                            \
+        {   /* (branch-free: one scheduling region from barrier to barrier) */                                        \
+            const float keep_ = (want_bias && (slab) < nk) ? 1.f : 0.f;                                               \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) bsum = fmaf(keep_, S_.a[r], bsum);                           \
         }                                                                                                             \
         uint4 q0_, q1_, q2_;                                                                                          \
         split8(make_float4(S_.a[0], S_.a[1], S_.a[2], S_.a[3]), make_float4(S_.a[4], S_.a[5], S_.a[6], S_.a[7]), q0_, q1_, q2_); \
@@ -356,16 +357,32 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
         W6_GLOAD(st0, 2);
         __syncthreads();
         int kt = 0;
+        // Interleave request to the scheduler: the slab's MFMAs are independent of the next slab's split (VALU), its LDS stores and the
+        // loads of the slab after; left alone the compiler emits them phase by phase and every pipe idles while another works
+        // (r03 PMC, three-product mode: MFMA 34 %, LDS 34 %, VALU 25 %, TA 31 % busy -- they add up to one)
+#define W6_SCHED()                                                                                                    \
+    do {                                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, NPROD == 6 ? 12 : 8, 0);                                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < (NPROD == 6 ? 24 : 12); ++q_) {                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, NPROD == 6 ? 5 : 6, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x020, NPROD == 6 ? 1 : 2, 0);                                       \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x200, NPROD == 6 ? 6 : 4, 0);                                           \
+    } while (0)
         for (; kt + 1 < nk; kt += 2) {
             compute(0);
             W6_LSTORE(1, st1, kt + 1);
             W6_GLOAD(st1, kt + 3);
+            W6_SCHED();
             __syncthreads();
             compute(1);
             W6_LSTORE(0, st0, kt + 2);   // (past the split's last slab: staged, never multiplied)
             W6_GLOAD(st0, kt + 4);
+            W6_SCHED();
             __syncthreads();
         }
+#undef W6_SCHED
         if (kt < nk) compute(0);
     }
 #undef W6_GLOAD

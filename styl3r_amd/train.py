@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -42,12 +44,20 @@ def select_trainable(encoder: nn.Module) -> Tuple[List[nn.Parameter], List[nn.Pa
     return new, pre, frozen
 
 
+OPTIMIZER_IMPL = os.environ.get("STYL3R_OPTIMIZER", "hip")      # "hip": styl3r_amd.optim.AdamWHIP (one launch per group) | "torch": torch.optim.AdamW(fused=True); CPU parameters always take torch's
+
+
 def make_optimizer(new: Sequence[nn.Parameter], pre: Sequence[nn.Parameter], lr: float = 2e-4,
                    backbone_lr_multiplier: float = 0.1) -> torch.optim.Optimizer:
-    """AdamW(param_dicts, lr, weight_decay=0.05, betas=(0.9, 0.95)) of `:885-895`; on a GPU the single-pass fused
-    implementation (the foreach one makes ~10 passes over the 4.2 GB of parameter / moment state per step)."""
+    """AdamW(param_dicts, lr, weight_decay=0.05, betas=(0.9, 0.95)) of `:885-895`; on a GPU the single-pass optimizer kernel
+    (csrc/vit_optim.hip through optim.AdamWHIP, state-compatible with the framework's fused AdamW; the foreach implementation makes
+    ~10 passes over the 4.2 GB of parameter / moment state per step)."""
     groups = [g for g in ({"params": list(new), "lr": lr}, {"params": list(pre), "lr": lr * backbone_lr_multiplier})
               if g["params"]]
+    on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+    if on_gpu and OPTIMIZER_IMPL == "hip" and all(p.dtype == torch.float32 for g in groups for p in g["params"]):
+        from .optim import AdamWHIP
+        return AdamWHIP(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95))
     fused = any(p.is_cuda for g in groups for p in g["params"])
     return torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95), fused=fused)
 

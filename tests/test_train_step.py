@@ -252,3 +252,60 @@ def test_clip_coefficient_deferred_into_the_fused_adamw_equals_the_explicit_scal
     a, b = run(True), run(False)
     for p, q in zip(a, b):
         assert float((p - q).abs().max()) <= 2e-5 * float(q.abs().max())        # g / s vs g * (1 / s): one rounding apart, through three Adam steps
+
+
+@pytest.mark.gpu
+def test_hip_adamw_pass_equals_the_frameworks_fused_adamw_and_shares_its_state_layout():
+    """optim.AdamWHIP (csrc/vit_optim.hip, one launch per parameter group) against torch.optim.AdamW(fused=True) on the reference's
+    configuration (two groups, lr / 0.1 lr, weight_decay 0.05, betas (0.9, 0.95), model_wrapper_style.py:885-895): parameters and both
+    moments after 12 steps with a changing learning rate, a deferred clip coefficient (`grad_scale`) on some steps, tensors whose size is
+    not a multiple of four, a misaligned gradient view, a parameter without gradient; then the state dicts are swapped between the two
+    optimizers and both keep producing the same numbers."""
+    from styl3r_amd.optim import AdamWHIP
+    dev = "cuda:0"
+    g = torch.Generator(dev).manual_seed(11)
+    shapes = [(1024, 1024), (3, 7, 7, 5), (40000,), (1,), (16385,), (257, 129), (5,)]
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, device=dev, generator=torch.Generator(dev).manual_seed(i))) for i, s in enumerate(shapes)]
+        return ps, [{"params": ps[:4], "lr": 2e-4}, {"params": ps[4:], "lr": 2e-5}]
+    pa, ga = make(); pb, gb = make()
+    oa = torch.optim.AdamW(ga, lr=2e-4, weight_decay=0.05, betas=(0.9, 0.95), fused=True)
+    ob = AdamWHIP(gb, lr=2e-4, weight_decay=0.05, betas=(0.9, 0.95))
+    flat = torch.empty(sum(p.numel() for p in pb) + 8, device=dev)      # gradients of `b` are views of one buffer, like the all-reduce buckets
+    def step(k, swap=False):
+        off = 1                                                          # every view starts 4 bytes off a 16-byte boundary
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 6 and k % 2 == 0:
+                a.grad = None; b.grad = None                              # a parameter that was not used in this step
+                continue
+            gr = torch.randn(a.shape, device=dev, generator=g) * (10.0 if k == 3 else 1.0)
+            a.grad = gr.clone()
+            view = flat[off:off + a.numel()].view(a.shape); view.copy_(gr); b.grad = view
+            off += a.numel()
+        for o in (oa, ob):
+            for gi, grp in enumerate(o.param_groups):
+                grp["lr"] = (2e-4 if gi == 0 else 2e-5) * (0.5 + 0.1 * k)
+            if k % 3 == 1:
+                o.grad_scale = torch.tensor(1.7 + k, device=dev)          # == gradients multiplied by 1 / (1.7 + k)
+            elif hasattr(o, "grad_scale"):
+                del o.grad_scale
+            o.step()
+    def compare(tag):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) <= 2e-6, (tag, i, "param")
+            sa, sb = oa.state.get(a, {}), ob.state.get(b, {})
+            assert (len(sa) == 0) == (len(sb) == 0)
+            if sa:
+                assert float(sa["step"]) == float(sb["step"]) and sb["step"].is_cuda and sb["step"].dtype == torch.float32
+                for k_ in ("exp_avg", "exp_avg_sq"):
+                    assert float((sa[k_] - sb[k_]).abs().max() / sa[k_].abs().max().clamp_min(1e-30)) <= 2e-6, (tag, i, k_)
+    for k in range(12):
+        step(k)
+    compare("12 steps")
+    assert float(oa.state[pa[6]]["step"]) == 6.0                          # per-parameter step counters, like the framework's
+    sd_a, sd_b = oa.state_dict(), ob.state_dict()
+    assert sd_a["param_groups"][0].keys() == sd_b["param_groups"][0].keys()
+    oa.load_state_dict(sd_b); ob.load_state_dict(sd_a)                    # interchangeable checkpoints
+    for k in range(12, 16):
+        step(k)
+    compare("after swapping the state dicts")

@@ -16,7 +16,9 @@ M = int(os.environ.get("ROWS", "5140"))
 SHAPES = {"enc_qkv": (3072, 1024), "enc_proj": (1024, 1024), "enc_fc1": (4096, 1024), "enc_fc2": (1024, 4096),
           "dec_qkv": (2304, 768), "dec_proj": (768, 768), "dec_fc1": (3072, 768), "dec_fc2": (768, 3072)}
 s = torch.cuda.current_stream().cuda_stream
+ONLY = os.environ.get("ONLY")
 for name, (N, K) in SHAPES.items():
+    if ONLY and name != ONLY: continue
     x = torch.randn(M, K, device=dev); dy = torch.randn(M, N, device=dev)
     buf = torch.empty(N * K + N, device=dev)
     run = lambda: lib.vit_linear_x6_wgrad(dy.data_ptr(), x.data_ptr(), buf.data_ptr(), buf[N * K:].data_ptr(), M, N, K, s)
