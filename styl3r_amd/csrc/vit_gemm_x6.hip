@@ -857,7 +857,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
 // t[c] us with c of them on its CU, and the CU's throughput saturates at two (t_sat = t[2] / 2); every workgroup also pays ~8 slabs' worth
 // of pipeline fill + atomic epilogue, every split one more pass of atomics over the output:
 //     cost(S) = max(chain x t[c], workgroups per CU x chain x t_sat) + S us,    chain = slabs per split + 8
-// r02's rule ("fill 512 slots once") left the 192- / 108- / 144-tile outputs (qkv, decoder fc) at S = 2 / 4 / 3 where S = 4 / 7 / 5 is 16 - 25 % faster.
+// r02's rule ("fill whole rounds of 512 slots") put the 192- / 108- / 144-tile outputs (qkv, decoder fc) at S = 8 / 14 / 7 where S = 4 / 7 / 5 is 15 - 25 % faster.
 static int wgrad_splits(int tiles, int nslab, int products)
 {
     static const float t3[4] = {0.f, 0.66f, 1.07f, 1.53f}, t6[4] = {0.f, 0.95f, 1.62f, 2.48f};
