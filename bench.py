@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: keep taking views until this much wall time is spent")
     ap.add_argument("--no-infer-leg", action="store_true", help="skip the C2 inference leg")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
+    ap.add_argument("--no-stage-legs", action="store_true", help="skip the C4 style-stage and C5 stress train steps")
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-warmup", type=int, default=2)
@@ -360,6 +361,62 @@ def train_leg(args, rank, world, dev, dist):
     return out
 
 
+def stage_leg(args, rank, world, dev, dist, config):
+    """The other two train configurations of SURVEY 8 on the full-size encoder, bf16x3 like the C3 headline (tools/bench_train.py runs the same steps):
+    "c4" = style stage at the reference's per-GPU batch: 6 scenes, 4 ctx / 6 tgt views 256 x 256, VGG style loss + identity pass (two encoder + decoder
+    passes per step), backbone frozen (model_wrapper_style.py:118-232; random-init VGG: no weights here);  "c5" = stress shapes: 1 scene, 4 ctx views
+    512 x 512 -> 1 048 576 Gaussians, sh_degree 4, 4 tgt views 512 x 512, MSE, every parameter trains."""
+    import torch
+    from styl3r_amd import dist_utils, vit_ops
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg, GaussianAdapterCfg
+    from styl3r_amd.scenes import make_scene
+    from styl3r_amd.train import TrainStep
+    c4 = config == "c4"
+    torch.manual_seed(0)
+    cfg = EncoderNoPoSplatTokenStyleCfg(stylized=c4)
+    if not c4:
+        cfg.gaussian_adapter = GaussianAdapterCfg(cfg.gaussian_adapter.gaussian_scale_min, cfg.gaussian_adapter.gaussian_scale_max, 4)
+    enc = EncoderNoPoSplatMultiTokenStyle(cfg).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    forced = dist is not None and world == 1
+    if c4:
+        from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+        vgg = VGGEncoder().to(dev)
+        step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), force_collective=forced)
+    else:
+        step = TrainStep(enc, dec, dist=dist, force_collective=forced)
+    b, v_ctx, v_tgt, H = (6, 4, 6, 256) if c4 else (1, 4, 4, 512)
+    g = torch.Generator(dev).manual_seed(1234 + rank)
+    sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
+    ex = lambda t, *shape: t.to(dev)[None].expand(b, *shape).contiguous()
+    batch = dict(
+        context=dict(image=torch.rand(b, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=sc.intrinsics[:1].to(dev).expand(b, v_ctx, 3, 3).contiguous()),
+        target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
+                    intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
+    if c4:
+        batch["style"] = dict(image=torch.rand(b, 3, H, H, device=dev, generator=g))
+    keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
+    steps = 3
+    try:
+        vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = "bf16x3"
+        for _ in range(2):
+            step(batch)
+        dt = dist_utils.timed_steps(lambda: step(batch), steps, lambda: torch.cuda.synchronize(dev), dist, dev)
+    finally:
+        vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
+        vit_ops._x6()
+    out = {"metric": f"{H}x{H} rendered views/sec, full train step, " + ("C4 style stage (VGG style loss + identity pass, backbone frozen)" if c4 else
+                                                                       "C5 stress shapes (1 048 576 Gaussians/scene, sh_degree 4)"),
+           "value": round(dist_utils.aggregate_throughput(b * v_tgt, steps, world, dt), 3), "unit": "views/s", "ms_per_step": round(1e3 * dt / steps, 2),
+           "steps": steps, "warmup": 2, "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
+           "trainable_params": sum(p.numel() for p in enc.parameters() if p.requires_grad), "linear_arithmetic": "bf16x3", "dtype": "f32",
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "n_gpus": world, "data": "synthetic, random-init weights (VGG included)"}
+    del step, enc, dec, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def infer_leg(args, dev):
     """C2 (BASELINE.json configs[1]): inference latency, 2 context views 256 x 256 -> 131 072 Gaussians on the full-size encoder
     (random init: re10k_2v.ckpt is absent), 3 target views rendered forward only, `no_grad`, bf16x6 arithmetic (the mode of the 1e-4 RGB
@@ -510,6 +567,14 @@ def main():
             res["train_step"]["n_gpus"] = world
         except Exception as e:   # the headline line must survive a failure of the secondary leg; it is reported, not hidden
             res["train_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    if not args.no_stage_legs and not args.no_train_leg and not args.dry_cpu and not args.train_tiny:
+        import gc
+        for key, config in (("style_stage_step", "c4"), ("stress_512_step", "c5")):
+            gc.collect(); torch.cuda.empty_cache()
+            try:
+                res[key] = stage_leg(args, rank, world, dev, dist, config)
+            except Exception as e:
+                res[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if rank == 0 and not args.no_infer_leg and not args.dry_cpu:
         try:
             res["infer"] = infer_leg(args, dev)
