@@ -914,9 +914,13 @@ _RING_SHAPES = {
     "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
                (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
 }
-# 2048 <= M < 4096 (the dual decoders' 2 570-row launches): only the wide layers still fill the chip with 128 x 128 tiles (three products,
-# M = 2 570: decoder qkv 155 -> 198, fc1 167 -> 252; the N = 768 layers LOSE there: 118 -> 89)
-_RING_SHAPES_MID = {"bf16x3": {(2304, 768): 1, (3072, 768): 1}}
+# 2048 <= M < 4096 (the dual decoders' 2 570-row launches, the style encoder's 2 560 rows at C3): only the wide layers still fill the chip
+# (three products, M = 2 570: decoder qkv 155 -> 198, fc1 167 -> 252; the N = 768 layers LOSE there: 118 -> 89, and 1024 x 1024 is a tie).
+# Style-encoder shapes at M = 2 560 (tools/probes/gemm_lab.py, r03): three products fc1 209 -> 252 (cfg 3), qkv 179 -> 271, fc2 152 -> 165,
+# qkv dX 140 -> 159 (cfg 1); six products (forward only) fc1 154 -> 173 (cfg 3), qkv 139 -> 177 (cfg 1).  tools/probes/linear_shapes.py: these
+# four shapes are 20 % of the Linear forward + dX FLOPs of a C3 step.
+_RING_SHAPES_MID = {"bf16x3": {(2304, 768): 1, (3072, 768): 1, (4096, 1024): 3, (1024, 4096): 1, (3072, 1024): 1, (1024, 3072): 1},
+                    "bf16x6": {(4096, 1024): 3, (3072, 1024): 1}}
 RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
 
