@@ -203,6 +203,8 @@ class AsymmetricCroCoMulti(CrocoTrunk):
             out.append(torch.cat([x[:, j] for j in range(v) if j != i], dim=1))
         return torch.stack(out, dim=1)
 
+    branch_streams = False   # inference option (set by the encoder's `head_streams`): decoder 2 on its own HIP stream
+
     def _decoder_split(self, feat: Tensor, pos: Tensor):
         """The dual decoders (:147-188) with view 0 and views 1.. kept as SEPARATE tensors from start to end:
         returns a list of 13 pairs (first (b,l,c), rest (b*(v-1),l,c)).  The reference -- and round 1 of this build --
@@ -228,9 +230,24 @@ class AsymmetricCroCoMulti(CrocoTrunk):
             return torch.stack(parts, dim=1).reshape(b * (v - 1), (v - 1) * l, width)
 
         pm2 = mem_of_rest(p1, p2, 2)
+        # Serving (`branch_streams`, no-grad, device tensors): within a layer the two decoders only read each other's PREVIOUS outputs, and
+        # at batch 1 neither fills the chip -- decoder 2 runs on its own stream, forked and joined once per layer (the critical path of a
+        # C2 forward drops from 24 encoder + 24 decoder block-times to 24 + 12).
+        side = None
+        if self.branch_streams and f1.is_cuda and not torch.is_grad_enabled():
+            main = torch.cuda.current_stream(f1.device)
+            side = self.__dict__.setdefault("_dec2_stream", torch.cuda.Stream(f1.device))
         for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
-            n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
-            n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
+            if side is not None:
+                side.wait_stream(main)                                 # both inputs of this layer are complete on `main`
+                with torch.cuda.stream(side):
+                    n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
+                n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
+                main.wait_stream(side)
+                n2.record_stream(main)                                 # allocated on the side stream, consumed on `main` from here on
+            else:
+                n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
+                n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
             f1, f2 = n1, n2
             outs.append((f1, f2))
         outs[-1] = (self.dec_norm(f1), self.dec_norm(f2))
@@ -641,6 +658,7 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
                 visualization_dump: Optional[dict] = None) -> Gaussians:
         b, v, _, h, w = context["image"].shape
         images = context["image"]
+        self.backbone.branch_streams = bool(self.head_streams)
         if self.head_streams and images.is_cuda and not torch.is_grad_enabled():
             # Serving: the style image's 24 encoder blocks do not depend on the content views, and the stylizer's decoder only
             # needs the backbone's ENCODER features -- at batch 1 none of these kernels fills the chip, so the style branch
@@ -648,6 +666,8 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
             cur = torch.cuda.current_stream(images.device)
             side = self.__dict__.setdefault("_style_stream", torch.cuda.Stream(images.device))
             side.wait_stream(cur)
+            # (the host needs ~17 ms to enqueue a forward the GPU finishes ~3 ms later; enqueueing the backbone before the style encoder
+            # instead was measured: no difference beyond the run-to-run noise)
             with torch.cuda.stream(side):
                 encoded = self.token_stylizer.encode_style(style)
             enc_feat, enc_pos = self.backbone.encode(context)
