@@ -458,12 +458,36 @@ def infer_leg(args, dev):
                         t_enc += ev[0].elapsed_time(ev[1]); t_ras += ev[1].elapsed_time(ev[2])
         finally:
             vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
-        return {"encoder_ms": round(t_enc / steps, 3), "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3),
-                "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1])}
+        rec = {"encoder_ms": round(t_enc / steps, 3), "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3),
+               "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1])}
+        # the same forward as one hipGraph per stream segment (styl3r_amd.graphs.StreamGraphedEncoder): no host launch cost, the GPU-side limit
+        try:
+            keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
+            vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = mode
+            from styl3r_amd.graphs import StreamGraphedEncoder
+            genc = StreamGraphedEncoder(enc, ctx, style)
+            t_g = 0.0
+            with torch.no_grad():
+                for i in range(warm + steps):
+                    ev[0].record()
+                    gs = genc(ctx, style)
+                    dec.forward(gs, *cams, (H, H))
+                    ev[2].record()
+                    torch.cuda.synchronize(dev)
+                    if i >= warm:
+                        t_g += ev[0].elapsed_time(ev[2])
+            rec["stream_graphs_total_ms"] = round(t_g / steps, 3)
+            del genc
+        except Exception as e:
+            rec["stream_graphs_total_ms"] = f"{type(e).__name__}: {e}"[:200]
+        finally:
+            vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
+            vit_ops._x6()
+        return rec
 
     # bf16x6 = the arithmetic of the 1e-4 RGB statement against fp32; bf16x3 = the TF32-class mode the train leg's headline uses (tests/test_e2e_parity.py bounds both)
     out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("bf16x6"), "steps": steps,
-           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "encoder_launch": "eager, heads + style branch on side streams",
+           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "encoder_launch": "eager, style branch + decoder 2 + heads on side streams (total_ms); stream_graphs_total_ms: one hipGraph per stream segment",
            "dtype": "f32", "data": "synthetic, random-init weights"}
     del enc, dec
     torch.cuda.empty_cache()

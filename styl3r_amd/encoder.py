@@ -213,45 +213,64 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         view 0's cross-attention, "all other views in view order", IS the rest tensor viewed as (b, (v-1) l, c); at v = 2
         the memory of the other decoder is the first tensor itself, so the C2 / C3 path copies nothing at all.  For
         v > 2 the memory of view i >= 1 (view 0 followed by the other rest views) is gathered once per layer."""
-        b, v, l, c = feat.shape
-        cur = _linear(self.decoder_embed, feat)
-        f1, f2 = cur[:, 0].contiguous(), cur[:, 1:].reshape(b * (v - 1), l, -1)
-        p1 = pos[:, 0].contiguous()
-        p2 = pos[:, 1:].reshape(b * (v - 1), l, 2)
-        pm1 = pos[:, 1:].reshape(b, (v - 1) * l, 2)                    # memory positions of view 0
-        outs = [(feat[:, 0], feat[:, 1:].reshape(b * (v - 1), l, c))]
-
-        def mem_of_rest(first, rest, width):                           # (b(v-1), (v-1) l, width): for view i, view 0 then the others
-            if v == 2:
-                return first
-            r = rest.view(b, v - 1, l, width)
-            parts = [torch.cat([first.unsqueeze(1)] + [r[:, j:j + 1] for j in range(v - 1) if j != i - 1], dim=1).reshape(b, (v - 1) * l, width)
-                     for i in range(1, v)]
-            return torch.stack(parts, dim=1).reshape(b * (v - 1), (v - 1) * l, width)
-
-        pm2 = mem_of_rest(p1, p2, 2)
+        st = self._decoder_begin(feat, pos)
         # Serving (`branch_streams`, no-grad, device tensors): within a layer the two decoders only read each other's PREVIOUS outputs, and
         # at batch 1 neither fills the chip -- decoder 2 runs on its own stream, forked and joined once per layer (the critical path of a
         # C2 forward drops from 24 encoder + 24 decoder block-times to 24 + 12).
         side = None
-        if self.branch_streams and f1.is_cuda and not torch.is_grad_enabled():
-            main = torch.cuda.current_stream(f1.device)
-            side = self.__dict__.setdefault("_dec2_stream", torch.cuda.Stream(f1.device))
-        for blk1, blk2 in zip(self.dec_blocks, self.dec_blocks2):
+        if self.branch_streams and st.f1.is_cuda and not torch.is_grad_enabled():
+            main = torch.cuda.current_stream(st.f1.device)
+            side = self.__dict__.setdefault("_dec2_stream", torch.cuda.Stream(st.f1.device))
+        for i in range(len(self.dec_blocks)):
             if side is not None:
                 side.wait_stream(main)                                 # both inputs of this layer are complete on `main`
                 with torch.cuda.stream(side):
-                    n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
-                n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
+                    n2 = self._decoder_layer(st, i, 2)
+                n1 = self._decoder_layer(st, i, 1)
                 main.wait_stream(side)
                 n2.record_stream(main)                                 # allocated on the side stream, consumed on `main` from here on
             else:
-                n1, _ = blk1(f1, f2.view(b, (v - 1) * l, -1), p1, pm1)
-                n2, _ = blk2(f2, mem_of_rest(f1, f2, f1.shape[-1]), p2, pm2)
-            f1, f2 = n1, n2
-            outs.append((f1, f2))
-        outs[-1] = (self.dec_norm(f1), self.dec_norm(f2))
-        return outs
+                n1 = self._decoder_layer(st, i, 1)
+                n2 = self._decoder_layer(st, i, 2)
+            self._decoder_advance(st, n1, n2)
+        return self._decoder_end(st)
+
+    # The pieces of `_decoder_split`, also driven one by one by graphs.StreamGraphedEncoder (one hipGraph per piece and stream)
+    def _decoder_begin(self, feat: Tensor, pos: Tensor):
+        from types import SimpleNamespace
+        b, v, l, c = feat.shape
+        cur = _linear(self.decoder_embed, feat)
+        st = SimpleNamespace(b=b, v=v, l=l, f1=cur[:, 0].contiguous(), f2=cur[:, 1:].reshape(b * (v - 1), l, -1),
+                             p1=pos[:, 0].contiguous(), p2=pos[:, 1:].reshape(b * (v - 1), l, 2),
+                             pm1=pos[:, 1:].reshape(b, (v - 1) * l, 2),                    # memory positions of view 0
+                             outs=[(feat[:, 0], feat[:, 1:].reshape(b * (v - 1), l, c))])
+        st.pm2 = self._mem_of_rest(st, st.p1, st.p2, 2)
+        return st
+
+    @staticmethod
+    def _mem_of_rest(st, first, rest, width):                          # (b(v-1), (v-1) l, width): for view i, view 0 then the others
+        b, v, l = st.b, st.v, st.l
+        if v == 2:
+            return first
+        r = rest.view(b, v - 1, l, width)
+        parts = [torch.cat([first.unsqueeze(1)] + [r[:, j:j + 1] for j in range(v - 1) if j != i - 1], dim=1).reshape(b, (v - 1) * l, width)
+                 for i in range(1, v)]
+        return torch.stack(parts, dim=1).reshape(b * (v - 1), (v - 1) * l, width)
+
+    def _decoder_layer(self, st, i: int, which: int) -> Tensor:
+        """layer i of decoder 1 (view 0) or decoder 2 (views 1..): reads the previous layer's st.f1 / st.f2, returns the new features"""
+        if which == 1:
+            return self.dec_blocks[i](st.f1, st.f2.view(st.b, (st.v - 1) * st.l, -1), st.p1, st.pm1)[0]
+        return self.dec_blocks2[i](st.f2, self._mem_of_rest(st, st.f1, st.f2, st.f1.shape[-1]), st.p2, st.pm2)[0]
+
+    @staticmethod
+    def _decoder_advance(st, n1: Tensor, n2: Tensor):
+        st.f1, st.f2 = n1, n2
+        st.outs.append((n1, n2))
+
+    def _decoder_end(self, st):
+        st.outs[-1] = (self.dec_norm(st.f1), self.dec_norm(st.f2))
+        return st.outs
 
     def _decoder(self, feat: Tensor, pos: Tensor):
         """list[13] of (b, v, l, c): the reference's return layout, assembled from the split form"""
@@ -683,33 +702,50 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
             dec_feat = self.backbone.decode_split(enc_feat, enc_pos)
             sty_feat = self.token_stylizer(style, enc_feat, enc_pos)
 
+        return self._heads_and_adapter(images, dec_feat, sty_feat, global_step, visualization_dump, self._run_heads)
+
+    def _opacity_exponent(self, global_step: int) -> float:
         x_op = self.cfg.opacity_mapping
-        exponent = 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
+        return 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
+
+    def _head_jobs(self, images: Tensor, dec_feat, sty_feat):
+        """The head calls as a list of closures (they only depend on the trunk outputs).  The reference calls a head once per view
+        (encoder_noposplat_multi_token_style.py:152-177: head1 for view 0, head2 for every other view, the appearance head for each view).
+        The heads act on every sample independently, so the views that share a head go through it as ONE batch of b * (#views) samples:
+        same results, a third of the launches at v = 4, and small-resolution layers that fill more of the chip."""
+        b, v, _, h, w = images.shape
         fused = self.fused_adapter and images.is_cuda and w >= h
+        if fused:
+            mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
+        else:
+            mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
+        rest_images = images[:, 1:].reshape(b * (v - 1), *images.shape[2:]) if v > 1 else None
+        jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat]),
+                lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3]),
+                lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
+        if v > 1:
+            jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat]),
+                     lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest_images[:, :3])]
+        return jobs
+
+    def _heads_and_adapter(self, images: Tensor, dec_feat, sty_feat, global_step: int, visualization_dump, run_heads) -> Gaussians:
+        b, v, _, h, w = images.shape
         with torch.autocast("cuda", enabled=False):
-            # The reference calls a head once per view (encoder_noposplat_multi_token_style.py:152-177: head1 for view 0,
-            # head2 for every other view, the appearance head for each view).  The heads act on every sample independently,
-            # so the views that share a head go through it as ONE batch of b * (#views) samples: same results, a third of
-            # the launches at v = 4, and small-resolution layers that fill more of the chip.
-            def rest(t):                                   # (b, v, ...) -> (b * (v - 1), ...), views 1..v-1
-                return t[:, 1:].reshape(b * (v - 1), *t.shape[2:])
+            res = run_heads(self._head_jobs(images, dec_feat, sty_feat), images)
+            return self._adapter(images, res, global_step, visualization_dump)
 
-            def per_view(first, others):                   # -> (b, v, ...)
-                if others is None:
-                    return first.unsqueeze(1)
-                return torch.cat((first.unsqueeze(1), others.reshape(b, v - 1, *others.shape[1:])), dim=1)
+    def _adapter(self, images: Tensor, res, global_step: int, visualization_dump) -> Gaussians:
+        """E10-E12: head outputs -> Gaussians"""
+        b, v, _, h, w = images.shape
+        exponent = self._opacity_exponent(global_step)
+        fused = self.fused_adapter and images.is_cuda and w >= h
 
-            if fused:
-                mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
-            else:
-                mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
-            jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat]),
-                    lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3]),
-                    lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
-            if v > 1:
-                jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat]),
-                         lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest(images)[:, :3])]
-            res = self._run_heads(jobs, images)
+        def per_view(first, others):                   # -> (b, v, ...)
+            if others is None:
+                return first.unsqueeze(1)
+            return torch.cat((first.unsqueeze(1), others.reshape(b, v - 1, *others.shape[1:])), dim=1)
+
+        with torch.autocast("cuda", enabled=False):
             pts_0, par_0, app = res[:3]
             if fused:
                 # E10-E12 in one kernel each way: head outputs (NCHW) -> Gaussians in the rasterizer's layout

@@ -36,3 +36,99 @@ class GraphedEncoder:
             v.copy_(style[k])
         self.graph.replay()
         return self.out
+
+
+class StreamGraphedEncoder:
+    """Serving replay of the style-token encoder as ONE hipGraph PER STREAM SEGMENT.
+
+    At batch 1 the eager forward with `head_streams` is host-bound: Python needs 17 - 19 ms to enqueue ~1 700 launches that the GPU, with the
+    independent parts on their own streams, finishes ~3 ms later (tools/probes/infer_host_time.py).  A single captured graph removes the host
+    cost but replays in order (29.8 ms), and a single graph with internal fork / join replays slower still (34 ms, r02).  Here every piece that
+    runs on one stream between two cross-stream dependencies is its own graph -- backbone encoder | style encoder | stylizer decoder |
+    decoder prologue | decoder 1 layer i | decoder 2 layer i | decoder epilogue | five head calls | adapter -- and `__call__` replays them on
+    the streams of the eager serving path with the same fork / join waits: ~45 graph launches instead of ~1 700 kernel launches.
+    Shapes and the arithmetic mode are fixed at capture time; the weights are read in place (one eager pass first warms the split caches)."""
+
+    def __init__(self, encoder: nn.Module, context: dict, style: dict, global_step: int = 0, warmup: int = 2):
+        enc = self.encoder = encoder.eval()
+        dev = context["image"].device
+        self.ctx = {k: v.clone() for k, v in context.items() if torch.is_tensor(v)}
+        self.style = {k: v.clone() for k, v in style.items() if torch.is_tensor(v)}
+        keep = enc.head_streams
+        enc.head_streams = False                              # the pieces are captured in order; the streams are this class's business
+        enc.backbone.branch_streams = False
+        warm = torch.cuda.Stream(dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(warm), torch.no_grad():
+            for _ in range(warmup):
+                enc(self.ctx, self.style, global_step)
+        torch.cuda.current_stream(dev).wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.s_style, self.s_dec2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        self.s_heads = [torch.cuda.Stream(dev) for _ in range(5)]
+        cap = torch.cuda.Stream(dev)                          # every piece is captured on this stream, replayed wherever it belongs
+        self._keep = []
+
+        def capture(fn):
+            g = torch.cuda.CUDAGraph()
+            box = {}
+            with torch.no_grad(), torch.cuda.graph(g, stream=cap):
+                box["out"] = fn()
+            self._keep.append(box)
+            return g, box["out"]
+
+        bb, ts = enc.backbone, enc.token_stylizer
+        images = self.ctx["image"]
+        self.g_be, (enc_feat, enc_pos) = capture(lambda: bb.encode(self.ctx))
+        self.g_se, encoded = capture(lambda: ts.encode_style(self.style))
+        self.g_sd, sty_feat = capture(lambda: ts(self.style, enc_feat, enc_pos, encoded=encoded))
+        self.g_dpre, st = capture(lambda: bb._decoder_begin(enc_feat, enc_pos))
+        self.g_d1, self.g_d2 = [], []
+        for i in range(len(bb.dec_blocks)):
+            g1, n1 = capture(lambda: bb._decoder_layer(st, i, 1))
+            g2, n2 = capture(lambda: bb._decoder_layer(st, i, 2))
+            bb._decoder_advance(st, n1, n2)
+            self.g_d1.append(g1); self.g_d2.append(g2)
+        self.g_dpost, dec_feat = capture(lambda: [(a[:, :-1], r[:, :-1]) for a, r in bb._decoder_end(st)])
+        jobs = enc._head_jobs(images, dec_feat, sty_feat)
+        assert len(jobs) <= len(self.s_heads)
+        self.g_heads, res = [], []
+        for job in jobs:
+            with torch.autocast("cuda", enabled=False):
+                g, r = capture(job)
+            self.g_heads.append(g); res.append(r)
+        self.g_fin, self.out = capture(lambda: enc._adapter(images, res, global_step, None))
+        enc.head_streams = keep
+        torch.cuda.synchronize(dev)
+
+    @torch.no_grad()
+    def __call__(self, context: dict, style: dict) -> Gaussians:
+        for k, v in self.ctx.items():
+            v.copy_(context[k])
+        for k, v in self.style.items():
+            v.copy_(style[k])
+        main = torch.cuda.current_stream(self.ctx["image"].device)
+        self.s_style.wait_stream(main)
+        with torch.cuda.stream(self.s_style):
+            self.g_se.replay()
+        self.g_be.replay()
+        self.s_style.wait_stream(main)                        # the stylizer's decoder reads the backbone's encoder features
+        with torch.cuda.stream(self.s_style):
+            self.g_sd.replay()
+        self.g_dpre.replay()
+        for g1, g2 in zip(self.g_d1, self.g_d2):
+            self.s_dec2.wait_stream(main)                     # decoder 2, layer i reads decoder 1's layer i-1 (and its own)
+            with torch.cuda.stream(self.s_dec2):
+                g2.replay()
+            g1.replay()
+            main.wait_stream(self.s_dec2)                     # decoder 1, layer i+1 reads decoder 2's layer i
+        self.g_dpost.replay()
+        main.wait_stream(self.s_style)
+        for s, g in zip(self.s_heads, self.g_heads):
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                g.replay()
+        for s in self.s_heads[:len(self.g_heads)]:
+            main.wait_stream(s)
+        self.g_fin.replay()
+        return self.out

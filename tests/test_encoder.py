@@ -147,6 +147,34 @@ def test_hipgraph_replay_of_the_encoder_matches_eager():
 
 
 @pytest.mark.gpu
+def test_per_stream_hipgraph_replay_of_the_serving_forward_matches_eager():
+    """styl3r_amd.graphs.StreamGraphedEncoder: one hipGraph per stream segment (backbone encoder | style encoder | stylizer decoder | each layer of
+    decoder 1 / decoder 2 | five head calls | adapter) replayed on the serving streams with the eager path's fork / join waits; new inputs, repeated
+    replays, results equal the eager forward"""
+    from styl3r_amd.graphs import StreamGraphedEncoder
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    m = deterministic_init_(_build(0)).to(dev)
+    T = lambda k: torch.tensor(G[f"sh0_{k}"], device=dev)
+    ctx, style = dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style"))
+    genc = StreamGraphedEncoder(m, ctx, style)
+    assert len(genc.g_d1) == len(m.backbone.dec_blocks) and len(genc.g_heads) == 5
+    ctx2 = dict(image=(ctx["image"] * 0.7 + 0.1).contiguous(), intrinsics=ctx["intrinsics"])
+    with torch.no_grad():
+        want, old = m(ctx2, style, 0), m(ctx, style, 0)
+    for rep in range(3):
+        got = genc(ctx2, style)
+        torch.cuda.synchronize()
+        for name in ("means", "covariances", "harmonics", "opacities"):
+            a, b = getattr(got, name).cpu().numpy(), getattr(want, name).cpu().numpy()
+            assert_close_rel(a, b, 1e-4, name)                      # (split-contraction atomics: the summation order is not fixed)
+            assert abs(a - getattr(old, name).cpu().numpy()).max() > 1e-2 * abs(b).max()   # and it really used the new inputs
+    got = genc(ctx, style)                                            # back to the first inputs
+    torch.cuda.synchronize()
+    assert_close_rel(got.means.cpu().numpy(), old.means.cpu().numpy(), 1e-4, "means, first inputs again")
+
+
+@pytest.mark.gpu
 def test_bf16x6_and_f32_paths_agree_through_the_whole_encoder():
     """Large enough images for the bf16x6 convolution kernels (Conv2dX6, >= 200 output tiles) and split-K Linear paths to
     run inside the real graph: Gaussians and input gradients must match the exact-f32 MFMA Linear + MIOpen convolution

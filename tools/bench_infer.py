@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--streams", action="store_true", help="run the five head calls on their own streams (encoder.head_streams)")
+ap.add_argument("--stream-graphs", action="store_true", help="one hipGraph per stream segment, replayed on the serving streams (styl3r_amd.graphs.StreamGraphedEncoder)")
 ap.add_argument("--graph", action="store_true", help="replay the encoder forward as one hipGraph (styl3r_amd.graphs.GraphedEncoder)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -30,7 +31,17 @@ g = torch.Generator(dev).manual_seed(1234)
 ctx = dict(image=torch.rand(1, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=sc.intrinsics[:1].to(dev).expand(1, v_ctx, 3, 3).contiguous())
 style = dict(image=ctx["image"][:, 0])
 ex = lambda t: t.to(dev)[None].contiguous()
-if args.graph:
+if args.stream_graphs:
+    from styl3r_amd.graphs import StreamGraphedEncoder
+    with torch.no_grad():
+        ref = enc(ctx, style, 0)
+    genc = StreamGraphedEncoder(enc, ctx, style)
+    got = genc(ctx, style)
+    torch.cuda.synchronize()
+    assert torch.allclose(got.means, ref.means, rtol=1e-4, atol=1e-5) and torch.allclose(got.covariances, ref.covariances, rtol=1e-3, atol=1e-8), \
+        (float((got.means - ref.means).abs().max()), float((got.covariances - ref.covariances).abs().max()))
+    run_enc = lambda: genc(ctx, style)
+elif args.graph:
     from styl3r_amd.graphs import GraphedEncoder
     with torch.no_grad():
         ref = enc(ctx, style, 0)
@@ -57,4 +68,4 @@ print(json.dumps({"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, 
                   "rasterizer_ms": round(t_ras / n, 3), "total_ms": round((t_enc + t_ras) / n, 3),
                   "views_per_s": round(v_tgt * 1e3 * n / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1]),
                   "encoder_fwd_TFLOPs_per_s": round(1.3146 / (t_enc / n) * 1e3 / 1e0, 1) if not args.tiny else None,
-                  "encoder_launch": "hipGraph replay" if args.graph else ("eager, heads on 5 streams" if args.streams else "eager"), "dtype": "f32", "data": "synthetic, random-init weights"}))
+                  "encoder_launch": "hipGraph per stream segment" if args.stream_graphs else "hipGraph replay" if args.graph else ("eager, heads on 5 streams" if args.streams else "eager"), "dtype": "f32", "data": "synthetic, random-init weights"}))

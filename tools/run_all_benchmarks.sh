@@ -20,6 +20,7 @@ run python tools/bench_train.py --config c4 --scenes 6 --steps 3 --warmup 2 --li
 run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1      # 512^2 / sh 4 stress step
 run python tools/bench_train.py --config c5 --scenes 1 --steps 2 --warmup 1 --linear-mode bf16x3
 run python tools/bench_infer.py                                                  # C2 inference
-run python tools/bench_infer.py --streams                                        # C2 inference, style branch + heads on side streams
+run python tools/bench_infer.py --streams                                        # C2 inference, style branch + decoder 2 + heads on side streams
+run python tools/bench_infer.py --stream-graphs                                  # C2 inference, one hipGraph per stream segment
 run python tools/bench_vit.py                                                    # kernel microbenchmarks
 echo "results: $OUT/all.jsonl"
