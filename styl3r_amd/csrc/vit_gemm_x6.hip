@@ -66,6 +66,23 @@ __device__ inline void tile_of_block(int bid, int tiles_m, int tiles_n, int &tm,
     tn = in_group / gsz;
 }
 
+// Zero fill of a split-contraction output.  (Not hipMemsetAsync: its graph node is not replayed faithfully by this runtime -- captured
+// into a hipGraph, the second and later replays leave half of the words untouched -- so the serving graphs of styl3r_amd/graphs.py
+// would accumulate into stale sums; a kernel node replays as launched.  tools/probes/graph_memset_replay.py is the reproducer.)
+__global__ void __launch_bounds__(256) k_zero_words(uint32_t *__restrict__ p, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        uint4 *p4 = reinterpret_cast<uint4 *>(p);
+        const size_t n4 = n >> 2;
+        for (size_t j = i; j < n4; j += stride) p4[j] = make_uint4(0, 0, 0, 0);
+        for (size_t j = (n4 << 2) + i; j < n; j += stride) p[j] = 0;
+    } else {
+        for (; i < n; i += stride) p[i] = 0;
+    }
+}
+
 __device__ inline float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 // d/dx of the exact GELU: Phi(x) + x phi(x)   (aten's GeluBackward, approximate = "none")
 __device__ inline float gelu_grad_exact(float x)
@@ -813,6 +830,16 @@ int split_weight(const float *w, void *packed, int rows, int cols, int transpose
     return VIT_OK;
 }
 
+static bool zero_fill(void *p, size_t bytes, hipStream_t stream)
+{
+    const size_t n = bytes / 4;
+    if (n == 0) return true;
+    const size_t groups = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(x6::k_zero_words, dim3((unsigned)(groups < 1 ? 1 : (groups > 2048 ? 2048 : groups))), dim3(256), 0, stream,
+                       static_cast<uint32_t *>(p), n);
+    return hipGetLastError() == hipSuccess;
+}
+
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream)
 {
@@ -831,7 +858,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
         while (S < 8 && tiles * S * 2 <= 768 && nk / (S * 2) >= 8) S *= 2;
     }
     if (S > 1) {
-        if (hipMemsetAsync(out, 0, (size_t)M * N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        if (!zero_fill(out, (size_t)M * N * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
 #define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
         if (three) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
         else { if (narrow) VIT_LAUNCH_X6S(1, 6); else VIT_LAUNCH_X6S(2, 6); }
@@ -917,7 +944,7 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     int S = 1;
     const int nslab = ksize * ksize * Ci / x6::BK;
     if (tiles < 256) { S = (int)(512 / tiles); while (S > 1 && nslab / S < 8) --S; if (S < 1) S = 1; if (S > 16) S = 16; }
-    if (S > 1 && hipMemsetAsync(out, 0, (size_t)NP * Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+    if (S > 1 && !zero_fill(out, (size_t)NP * Co * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
 #define VIT_LAUNCH_C6(KS, RL)                                                                                                                                   \
     do {                                                                                                                                                        \
         if (three) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 3>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate); \

@@ -134,7 +134,8 @@ def test_hipgraph_replay_of_the_encoder_matches_eager():
     ctx, style = dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style"))
     genc = GraphedEncoder(m, ctx, style)
     ctx2 = dict(image=(ctx["image"] * 0.7 + 0.1).contiguous(), intrinsics=ctx["intrinsics"])
-    got = genc(ctx2, style)
+    for _ in range(3):                  # (several replays: a non-idempotent node -- r03: hipMemsetAsync's graph node -- only shows from the second on)
+        got = genc(ctx2, style)
     with torch.no_grad():
         want = m(ctx2, style, 0)
     from tests.gpu_utils import assert_close_rel
