@@ -137,6 +137,9 @@ size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits);
 int vit_linear_x6c_choose_splits(int M, int N, int K);
 int vit_linear_x6c_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                        int M, int N, int K, int act, int splits, void *workspace, size_t workspace_bytes, void *stream);
+/* hipGraph capture: every FORWARD entry point of this header only enqueues kernels on `stream` (the zero fill in front of a split-contraction
+ * launch is a kernel, not hipMemsetAsync -- that call's graph node does not replay faithfully on this runtime), so a serving forward can be
+ * captured and replayed (styl3r_amd/graphs.py).  The backward entry points still use hipMemsetAsync for their accumulators: eager only. */
 /* act: 0 = none, 1 = exact GELU (optionally storing the pre-activation in `pre`), 2 = out = (x . W^T) * gelu'(residual): the
  * input-gradient GEMM of the layer behind a GELU with the GELU's backward in its epilogue (`residual` = the saved pre-activation of the
  * GELU, no bias, `pre` must be NULL) -- the separate GeluBackward pass over the (M, 4 dim) hidden gradient disappears. */
