@@ -719,13 +719,14 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
             mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
         else:
             mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
-        rest_images = images[:, 1:].reshape(b * (v - 1), *images.shape[2:]) if v > 1 else None
+        # (evaluated inside the job: at b > 1 this slice is a copy, and a job may be captured once and replayed on new images)
+        rest_images = lambda: images[:, 1:].reshape(b * (v - 1), *images.shape[2:])
         jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat]),
                 lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3]),
                 lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
         if v > 1:
             jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat]),
-                     lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest_images[:, :3])]
+                     lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest_images()[:, :3])]
         return jobs
 
     def _heads_and_adapter(self, images: Tensor, dec_feat, sty_feat, global_step: int, visualization_dump, run_heads) -> Gaussians:

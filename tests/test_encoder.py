@@ -173,6 +173,19 @@ def test_per_stream_hipgraph_replay_of_the_serving_forward_matches_eager():
     got = genc(ctx, style)                                            # back to the first inputs
     torch.cuda.synchronize()
     assert_close_rel(got.means.cpu().numpy(), old.means.cpu().numpy(), 1e-4, "means, first inputs again")
+    # two scenes per call: the per-view-group slices of the images are copies there and must be taken inside the captured pieces
+    cat = lambda a, b_: torch.cat((a, b_), dim=0).contiguous()
+    ctx_b2 = dict(image=cat(ctx["image"], ctx2["image"]), intrinsics=cat(ctx["intrinsics"], ctx["intrinsics"]))
+    style_b2 = dict(image=cat(style["image"], style["image"] * 0.5))
+    genc2 = StreamGraphedEncoder(m, ctx_b2, style_b2)
+    ctx_b2n = dict(image=cat(ctx2["image"], ctx["image"] * 0.9), intrinsics=ctx_b2["intrinsics"])
+    with torch.no_grad():
+        want2 = m(ctx_b2n, style_b2, 0)
+    for rep in range(2):
+        got2 = genc2(ctx_b2n, style_b2)
+        torch.cuda.synchronize()
+        for name in ("means", "covariances", "harmonics", "opacities"):
+            assert_close_rel(getattr(got2, name).cpu().numpy(), getattr(want2, name).cpu().numpy(), 1e-4, "b = 2: " + name)
 
 
 @pytest.mark.gpu
