@@ -59,8 +59,8 @@ def parse(argv=None):
     ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
     ap.add_argument("--no-stage-legs", action="store_true", help="skip the C4 style-stage and C5 stress train steps")
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
-    ap.add_argument("--train-steps", type=int, default=3)
-    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-warmup", type=int, default=3)
     ap.add_argument("--train-mode", choices=["bf16x3", "bf16x6"], default="bf16x3", help="arithmetic of the GEMM-shaped kernels in the headline train step")
     ap.add_argument("--train-tiny", action="store_true", help="small trunk for the train leg (smoke tests only; flagged in the line)")
     ap.add_argument("--dry-cpu", action="store_true",
@@ -301,7 +301,6 @@ def train_leg(args, rank, world, dev, dist):
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
     # a one-rank group (torch.distributed.run --nproc-per-node 1) still issues every collective: the RCCL path runs on one GPU
     forced = dist is not None and world == 1
-    step = TrainStep(enc, dec, dist=dist, force_collective=forced)
     b, v_ctx, v_tgt, H = args.train_scenes, 2, 4, (32 if args.train_tiny else 256)
     g = torch.Generator(dev).manual_seed(1234 + rank)
     sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
@@ -312,7 +311,14 @@ def train_leg(args, rank, world, dev, dist):
         target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
                     intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
     sync = (lambda: None) if cpu else (lambda: torch.cuda.synchronize(dev))
-    from styl3r_amd import vit_ops
+    from styl3r_amd import rasterizer, vit_ops
+    from styl3r_amd.scenes import recentre_output_heads_
+    # set-up, outside the timed region: a random-init point head throws (nearly) every Gaussian outside every frustum -- the step would render
+    # empty images and every gradient would be zero.  One calibration forward re-centres the five output convolutions
+    # (depth 2..4 in front of context view 0, as tests/golden/make_e2e_fixtures.py does for the reference model); rank 0's result is broadcast
+    if not cpu:
+        recentre_output_heads_(enc, batch["context"], dict(image=batch["context"]["image"][:, 0]))
+    step = TrainStep(enc, dec, dist=dist, force_collective=forced)
     # Arithmetic of the GEMM-shaped kernels in the headline train step: "bf16x3" (three bf16 partial products per fp32 product).  The
     # reference runs these layers in TF32 (croco.py:13 allow_tf32, cudnn's conv default); tests/test_e2e_parity.py measures, against the
     # reference's own chain in float64, that bf16x3 sits INSIDE the reference's TF32 distance on every quantity (Gaussians, rendered RGB,
@@ -327,11 +333,15 @@ def train_leg(args, rank, world, dev, dist):
         dt = dist_utils.timed_steps(lambda: step(batch), args.train_steps, sync, dist, dev)
     finally:
         vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
+    rendered = dict(rasterizer.LAST_STATS)
+    if not cpu:      # the step must render a real scene: more (tile, Gaussian) pairs than Gaussians
+        assert rendered["pairs"] > rendered["gaussians_per_scene"], f"train leg rendered (nearly) nothing: {rendered}"
     grad_bytes = sum(step.reducer.bucket_sizes_bytes())
     out = {"metric": "256x256 rendered views/sec, full C3 train step (encoder + rasterizer fwd+bwd, MSE, DP all-reduce, clip, AdamW)",
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, args.train_steps, world, dt), 3), "unit": "views/s",
            "ms_per_step": round(1e3 * dt / args.train_steps, 2), "steps": args.train_steps, "warmup": args.train_warmup,
            "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
+           "pairs_R": rendered.get("pairs"), "longest_tile_list": rendered.get("longest_tile_list"),
            "params": sum(p.numel() for p in enc.parameters()), "grad_bytes_all_reduced_per_step": grad_bytes if step.reducer.collective else 0,
            "grad_bytes": grad_bytes, "buckets": len(step.reducer.buckets), "bucket_MiB": 64,
            "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward"
@@ -348,11 +358,12 @@ def train_leg(args, rank, world, dev, dist):
             other = "bf16x6" if head_mode == "bf16x3" else "bf16x3"
             try:
                 vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = other
+                n_other = args.train_steps
                 for _ in range(3):          # (the first steps after a switch build the other mode's packed-weight buffers)
                     step(batch)
-                dt3 = dist_utils.timed_steps(lambda: step(batch), 3, sync, dist, dev)
-                out[other] = {"ms_per_step": round(1e3 * dt3 / 3, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, 3, world, dt3), 3),
-                              "unit": "views/s", "steps": 3, "products_per_launch": vit_ops.load().vit_x6_products(),
+                dt3 = dist_utils.timed_steps(lambda: step(batch), n_other, sync, dist, dev)
+                out[other] = {"ms_per_step": round(1e3 * dt3 / n_other, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n_other, world, dt3), 3),
+                              "unit": "views/s", "steps": n_other, "products_per_launch": vit_ops.load().vit_x6_products(),
                               "note": "the same step in the other arithmetic mode" + (" (fp32 round-off accuracy; mode of the 1e-4 parity tests)" if other == "bf16x6" else "")}
             finally:
                 vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
@@ -380,12 +391,6 @@ def stage_leg(args, rank, world, dev, dist, config):
     enc = EncoderNoPoSplatMultiTokenStyle(cfg).to(dev)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
     forced = dist is not None and world == 1
-    if c4:
-        from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
-        vgg = VGGEncoder().to(dev)
-        step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), force_collective=forced)
-    else:
-        step = TrainStep(enc, dec, dist=dist, force_collective=forced)
     b, v_ctx, v_tgt, H = (6, 4, 6, 256) if c4 else (1, 4, 4, 512)
     g = torch.Generator(dev).manual_seed(1234 + rank)
     sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
@@ -396,20 +401,33 @@ def stage_leg(args, rank, world, dev, dist, config):
                     intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
     if c4:
         batch["style"] = dict(image=torch.rand(b, 3, H, H, device=dev, generator=g))
+    from styl3r_amd import rasterizer
+    from styl3r_amd.scenes import recentre_output_heads_
+    # set-up (untimed): re-centre the random-init output heads so that the step renders a real scene (see train_leg)
+    recentre_output_heads_(enc, batch["context"], dict(image=(batch["style"]["image"] - 0.5) / 0.5) if c4 else dict(image=batch["context"]["image"][:, 0]))
+    if c4:
+        from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+        vgg = VGGEncoder().to(dev)
+        step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), force_collective=forced)
+    else:
+        step = TrainStep(enc, dec, dist=dist, force_collective=forced)
     keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
-    steps = 3
+    steps = 10
     try:
         vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = "bf16x3"
-        for _ in range(2):
+        for _ in range(3):
             step(batch)
         dt = dist_utils.timed_steps(lambda: step(batch), steps, lambda: torch.cuda.synchronize(dev), dist, dev)
     finally:
         vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
         vit_ops._x6()
+    rendered = dict(rasterizer.LAST_STATS)
+    assert rendered["pairs"] > rendered["gaussians_per_scene"], f"{config} leg rendered (nearly) nothing: {rendered}"
     out = {"metric": f"{H}x{H} rendered views/sec, full train step, " + ("C4 style stage (VGG style loss + identity pass, backbone frozen)" if c4 else
                                                                        "C5 stress shapes (1 048 576 Gaussians/scene, sh_degree 4)"),
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, steps, world, dt), 3), "unit": "views/s", "ms_per_step": round(1e3 * dt / steps, 2),
-           "steps": steps, "warmup": 2, "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
+           "steps": steps, "warmup": 3, "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
+           "pairs_R": rendered.get("pairs"), "longest_tile_list": rendered.get("longest_tile_list"),
            "trainable_params": sum(p.numel() for p in enc.parameters() if p.requires_grad), "linear_arithmetic": "bf16x3", "dtype": "f32",
            "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "n_gpus": world, "data": "synthetic, random-init weights (VGG included)"}
     del step, enc, dec, batch

@@ -123,8 +123,10 @@ __global__ void __launch_bounds__(256) k_upsample2x_bwd(const float *__restrict_
             const float *row = dout + (pl * OH + oy) * OW;
             float r = 0.f;
 #pragma unroll
-            for (int e = 0; e < 6; ++e)      // branch-free: columns outside the row carry weight 0 and read a clamped address
-                r += wx[e] * row[min(max(ox0 + e, 0), OW - 1)];
+            for (int e = 0; e < 6; ++e) {    // branch-free: columns outside the row read a clamped address and are SELECTED away
+                const float t = wx[e] * row[min(max(ox0 + e, 0), OW - 1)];   // (v_cndmask, not a multiply by 0: 0 * Inf of an overflowed border gradient would be NaN)
+                r += wx[e] != 0.f ? t : 0.f;
+            }
             acc += wy * r;
         }
         din[idx] = acc;

@@ -19,7 +19,10 @@ a single rank recomputes its map only when its own arrival set changes.
 
 Contract: exactly ONE backward between `prepare()` and `finish()`.  Buckets are launched strictly in index order (a complete
 bucket waits for its predecessors; whatever is left goes out in `finish()`), so the collective sequence is the same on every rank
-whatever the local gradient-arrival order or set.  A second backward after a bucket was launched would race with the collective and
+whatever the local gradient-arrival order or set.  "Complete" = every parameter the previous step's AGREED map calls used has its
+gradient: the never-used ones (`mask_token` sits ahead of the heads and the whole backbone in reverse registration order) are not waited
+for, so the overlap with the backward survives them; if one of them does receive a gradient (a data-dependent branch), it travels in one
+extra "straggler" collective that every rank enters together, decided from the MAX-reduced map of this step.  A second backward after a bucket was launched would race with the collective and
 is refused with a RuntimeError.
 """
 from __future__ import annotations
@@ -66,25 +69,52 @@ def broadcast_module_state(module: nn.Module, dist, src: int = 0, chunk_bytes: i
 
 
 class BucketedGradReducer:
+    """mode "all_reduce" (default): one all-reduce per bucket, every rank clips and steps the whole model.
+    mode "rs_ag" ("bucketed direct reduce-scatter + all-gather using all 7 links"): one REDUCE-SCATTER per bucket -- rank r
+    ends up with the summed gradient of elements [r n/w, (r+1) n/w) of every bucket (buckets are padded to a multiple of the world
+    size) -- the clip norm is evaluated on the owned shards (+ one scalar all-reduce), the optimizer updates the owned element ranges
+    only (`owned_range`; optim.AdamWHIP(owner=reducer): 1/world of the 28 B x 1.05 G optimizer traffic), and `gather_params()` all-gathers
+    the updated parameters bucket by bucket, asynchronously, `wait_params()` fencing the next forward.  For that the parameters of a
+    bucket live in ONE flat buffer (`p.data` is re-pointed at construction), so both collectives run in place on whole buckets; over the
+    xGMI mesh each of them moves (w-1)/w of a bucket per rank over all 7 links at once, where a ring all-reduce is bound by one link.
+    After finish() in this mode `p.grad` is meaningful on the owned range only.  `groups`: parameter lists that must not share a
+    bucket (optimizer groups: a shard then never straddles two learning rates)."""
+
     def __init__(self, params: Iterable[nn.Parameter], dist=None, bucket_bytes: int = 64 << 20, inplace_grads: bool = True,
-                 force_collective: bool = False):
+                 force_collective: bool = False, mode: str = "all_reduce", groups: Optional[List[List[nn.Parameter]]] = None):
+        if mode not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"BucketedGradReducer: mode {mode!r}: expected 'all_reduce' or 'rs_ag'")
         self.dist = dist
+        self.mode = mode
         self.inplace_grads = inplace_grads
         self.world = dist.get_world_size() if dist is not None else 1
+        self.rank = dist.get_rank() if dist is not None else 0
         # `force_collective`: issue every collective even in a one-rank group (sum over one rank = identity), so that the stream
         # ordering between the in-place bucket writers, the pack copy and RCCL's stream is exercised on a single GPU
         self.collective = dist is not None and (self.world > 1 or force_collective)
         self.params: List[nn.Parameter] = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))
+        group_of = {id(p): gi for gi, g in enumerate(groups or []) for p in g}
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
         for p in order:
             nb = p.numel() * 4
-            if cur and cur_bytes + nb > bucket_bytes:
+            if cur and (cur_bytes + nb > bucket_bytes or group_of.get(id(p)) != group_of.get(id(cur[-1]))):
                 self.buckets.append(self._make_bucket(cur)); cur, cur_bytes = [], 0
             cur.append(p); cur_bytes += nb
         if cur:
             self.buckets.append(self._make_bucket(cur))
+        self._range: dict = {}            # id(p) -> (lo, hi) element range of p this rank owns ("rs_ag"), absent = none
+        self._gathers: list = []
+        if mode == "rs_ag":
+            for b in self.buckets:
+                lo, hi = b["shard"]
+                off = 0
+                for p in b["params"]:
+                    a, z = max(lo - off, 0), min(hi - off, p.numel())
+                    if a < z:
+                        self._range[id(p)] = (a, z)
+                    off += p.numel()
         self._handles: list = []
         self._armed = False
         self._index = {id(p): i for i, p in enumerate(self.params)}
@@ -92,31 +122,68 @@ class BucketedGradReducer:
         self._arrived_key = None        # the local arrival set the cached map was computed for
         self._next = 0                  # index of the next bucket to launch
         self._unused: List[nn.Parameter] = []
+        self._skipped: list = []
         self._hooks = []
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
-    @staticmethod
-    def _make_bucket(params):
+    def _make_bucket(self, params):
         dev, n = params[0].device, sum(p.numel() for p in params)
-        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        padded = n if self.mode == "all_reduce" else -(-n // self.world) * self.world
+        flat = torch.zeros(padded, dtype=torch.float32, device=dev)
         views, off = [], 0
         for p in params:
             views.append(flat[off:off + p.numel()].view_as(p)); off += p.numel()
-        return dict(params=list(params), flat=flat, views=views, pending=len(params), launched=False)
+        b = dict(params=list(params), flat=flat, views=views, pending=len(params), launched=False, expect={id(p) for p in params}, n=n)
+        if self.mode == "rs_ag":
+            per = padded // self.world
+            b["shard"] = (self.rank * per, (self.rank + 1) * per)
+            # the parameters of the bucket move into one flat buffer (values kept), so the all-gather of the updated shards runs in place
+            pflat = torch.zeros(padded, dtype=torch.float32, device=dev)
+            off = 0
+            with torch.no_grad():
+                for p in params:
+                    if p.dtype != torch.float32:
+                        raise NotImplementedError("BucketedGradReducer(mode='rs_ag'): fp32 parameters only")
+                    dst = pflat[off:off + p.numel()].view_as(p)
+                    dst.copy_(p.data); p.data = dst; off += p.numel()
+            b["pflat"] = pflat
+        return b
+
+    def owned_range(self, p) -> Optional[tuple]:
+        """(lo, hi): the flat element range of `p` whose reduced gradient this rank holds and whose update it owns; None if it owns
+        nothing of `p`.  Mode "all_reduce": everything."""
+        if self.mode != "rs_ag":
+            return (0, p.numel())
+        return self._range.get(id(p))
+
+    def gather_params(self):
+        """after the optimizer step ("rs_ag"): all-gather the updated shards, bucket by bucket, asynchronously on the collective's own
+        stream; `wait_params()` before anything reads the parameters."""
+        if self.mode != "rs_ag" or not self.collective:
+            return
+        for b in self.buckets:
+            lo, hi = b["shard"]
+            self._gathers.append(self.dist.all_gather_into_tensor(b["pflat"], b["pflat"][lo:hi], async_op=True))
+
+    def wait_params(self):
+        for h in self._gathers:
+            h.wait()
+        self._gathers.clear()
 
     def _make_hook(self, bi):
         def hook(p):
             if not self._armed:                 # a backward outside prepare()/finish() is left alone
                 return
             b = self.buckets[bi]
-            if b["launched"]:
+            if b["launched"] and id(p) in b["expect"]:
                 raise RuntimeError("BucketedGradReducer: a gradient arrived for a bucket that was already all-reduced -- "
                                    "only ONE backward is allowed between prepare() and finish() (no gradient accumulation / "
                                    "retain_graph re-runs through the reducer)")
             self._arrived.add(self._index[id(p)])
-            b["pending"] -= 1
+            if id(p) in b["expect"]:            # (a parameter the agreed map calls unused may still show up: counted as arrived, never waited for)
+                b["pending"] -= 1
             # buckets are launched strictly in index order, so that every rank issues the same collective sequence even
             # when a gradient arrives in a different order (or not at all) on some rank
             while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
@@ -125,14 +192,20 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         b["launched"] = True
-        # (gradients the kernels already produced in place -- vit_ops._FusedLinear with `_grad_slot` -- need no copy)
-        have = [(p, v) for p, v in zip(b["params"], b["views"]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        # (gradients the kernels already produced in place -- vit_ops._FusedLinear with `_grad_slot` -- need no copy).  Parameters of the
+        # agreed unused map are NOT part of the bucket's payload (their slice stays zero): see `finish()`
+        live = [(p, v) for p, v in zip(b["params"], b["views"]) if id(p) in b["expect"]]
+        have = [(p, v) for p, v in live if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([v for _, v in have], [p.grad for p, _ in have])
-        for p, v in zip(b["params"], b["views"]):
+        for p, v in live:
             p.grad = v
         if self.collective:
-            self._handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
+            if self.mode == "rs_ag":
+                lo, hi = b["shard"]
+                self._handles.append(self.dist.reduce_scatter_tensor(b["flat"][lo:hi], b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
+            else:
+                self._handles.append(self.dist.all_reduce(b["flat"], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def prepare(self):
         """call before backward: zero the buckets (parameters without a gradient reduce as zeros) and drop old grads."""
@@ -141,13 +214,28 @@ class BucketedGradReducer:
         self._arrived = set()
         self._next = 0
         torch._foreach_zero_([b["flat"] for b in self.buckets])
+        # a bucket is complete when every parameter that is EXPECTED to receive a gradient has one.  Parameters of the agreed unused
+        # map of the previous step (MAX-reduced over the ranks in finish(): identical everywhere; e.g. `mask_token`, which sits in reverse
+        # registration order AHEAD of the heads and the whole backbone) are not waited for -- otherwise their bucket, and with the
+        # in-order launch rule every later one, would only go out in finish(), with no overlap with the backward.  Should such a
+        # parameter receive a gradient after its bucket went out, the hook refuses it (RuntimeError) as any late arrival.
+        skip = {id(p) for p in self._unused}
+        self._skipped = []                  # (index, parameter, bucket view) of the parameters nobody waits for, in index order
         for b in self.buckets:
-            b["pending"], b["launched"] = len(b["params"]), False
+            b["expect"] = {id(p) for p in b["params"]} - skip
+            b["pending"], b["launched"] = len(b["expect"]), False
             for p, v in zip(b["params"], b["views"]):
                 p.grad = None
+                if id(p) in skip:
+                    # should it receive a gradient after all (a data-dependent branch), the gradient must not land in a slice that may
+                    # already be inside a collective: it stays a tensor of its own and goes out with the stragglers in finish()
+                    p._grad_slot = None
+                    self._skipped.append((self._index[id(p)], p, v))
+                    continue
                 # in-place gradient slot: layers that can (the bf16x6 Linear) accumulate dW / db straight into this zeroed
                 # slice of the bucket and hand it to autograd as the gradient (no per-layer memset, no pack copy)
                 p._grad_slot = {"view": v, "used": False} if self.inplace_grads else None
+        self._skipped.sort(key=lambda t: t[0])
 
     def finish(self):
         """call after backward: reduce the buckets whose gradients never all arrived, wait, average."""
@@ -168,14 +256,30 @@ class BucketedGradReducer:
         for b in self.buckets:
             for p in b["params"]:
                 p._grad_slot = None            # a backward outside prepare()/finish() must not write into the buckets
-        if self.world > 1:
-            torch._foreach_mul_([b["flat"] for b in self.buckets], 1.0 / self.world)
         # parameters no rank produced a gradient for: grad = None (the optimizer skips them), as DDP(find_unused_parameters)
         if used is not None:
             flags = used.cpu().tolist()            # 4 B per parameter; the optimizer step that follows needs the host anyway
-            self._unused = [p for p, u in zip(self.params, flags) if not u]
+            used_now = {i for i, u in enumerate(flags) if u}
         else:
-            key = frozenset(self._arrived)         # one rank: nothing to exchange, the map changes only with the local set
+            used_now = self._arrived               # one rank: nothing to exchange
+        # stragglers: parameters the previous step's map called unused that some rank DID use in this one.  The set comes from the
+        # MAX-reduced map, so every rank takes this branch together and issues the same (single) extra collective
+        late = [(i, p, v) for i, p, v in self._skipped if i in used_now]
+        if late:
+            parts = [(p.grad if (i in self._arrived and p.grad is not None) else torch.zeros_like(v)).reshape(-1).float() for i, p, v in late]
+            flat = torch.cat(parts)
+            if self.collective:
+                self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+            off = 0
+            for _, p, v in late:
+                v.copy_(flat[off:off + v.numel()].view_as(v)); off += v.numel()
+                p.grad = v
+        if self.world > 1:
+            torch._foreach_mul_(self._reduced_flats(), 1.0 / self.world)
+        if used is not None:
+            self._unused = [p for i, p in enumerate(self.params) if i not in used_now]
+        else:
+            key = frozenset(self._arrived)         # the map changes only with the local set
             if key != self._arrived_key:
                 self._unused = [p for i, p in enumerate(self.params) if i not in key]
                 self._arrived_key = key
@@ -188,17 +292,30 @@ class BucketedGradReducer:
         `defer_to`: a FUSED Adam / AdamW whose next step() applies the coefficient itself -- its kernel divides every gradient by
         `optimizer.grad_scale` while it reads it (the hook torch.amp's GradScaler uses), so the separate read-modify-write pass over
         the 4.2 GB of gradients disappears; the stored gradients are then scaled by that step, not by this call."""
-        flats = [b["flat"] for b in self.buckets]
+        flats = self._reduced_flats()
         total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(flats)))
+        if self.mode == "rs_ag" and self.collective:        # the shards partition the gradient: ||g||^2 = sum over ranks of the local squares
+            sq = total * total
+            self.dist.all_reduce(sq, op=self.dist.ReduceOp.SUM)
+            total = sq.sqrt()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         if defer_to is not None and defer_to.defaults.get("fused"):
-            defer_to.grad_scale = (1.0 / coef).float()                     # 0-dim; g / grad_scale == g * coef
+            # 0-dim; g / grad_scale == g * coef.  A non-finite norm must stay visible: g / inf would turn an overflowed step into a silent
+            # zero update, so the scale becomes NaN and the step poisons the parameters as the in-place g * coef path does.  The optimizer
+            # drops the attribute after its step (one coefficient per step); the STORED gradients stay unclipped on this path.
+            defer_to.grad_scale = torch.where(torch.isfinite(total), 1.0 / coef, torch.full_like(total, float("nan"))).float()
         else:
             torch._foreach_mul_(flats, coef)
         return total
 
+    def _reduced_flats(self) -> List[torch.Tensor]:
+        """the part of every bucket that holds reduced gradients on this rank"""
+        if self.mode == "rs_ag" and self.collective:
+            return [b["flat"][b["shard"][0]:b["shard"][1]] for b in self.buckets]
+        return [b["flat"] for b in self.buckets]
+
     def bucket_sizes_bytes(self) -> List[int]:
-        return [b["flat"].numel() * 4 for b in self.buckets]
+        return [b["n"] * 4 for b in self.buckets]
 
     def close(self):
         for h in self._hooks:

@@ -20,13 +20,22 @@ _CHUNK = 16384
 _CHUNK_DTYPE = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("step", "u8"), ("n", "i4"), ("vec", "i4")])   # VitAdamChunk
 
 
+def _lib():
+    lib = vit_ops.load()
+    lib.vit_adamw_step.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    lib.vit_adamw_step.restype = C.c_int
+    return lib
+
+
 class AdamWHIP(torch.optim.AdamW):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    """`owner`: optional object with `owned_range(p) -> (lo, hi) | None` (ddp.BucketedGradReducer in "rs_ag" mode): only that element range
+    of every parameter is updated by this rank (the rest arrives with the parameter all-gather); None = everything."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, owner=None):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
         self._tables, self._step_flat = {}, {}
-        lib = vit_ops.load()
-        lib.vit_adamw_step.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
-        lib.vit_adamw_step.restype = C.c_int
+        self._owner = owner
+        _lib()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -36,7 +45,7 @@ class AdamWHIP(torch.optim.AdamW):
         """step += 1 for every parameter with a gradient.  The counters of a group are 0-dim views of ONE flat tensor (packed here on
         first use and after load_state_dict), so the usual case -- every parameter of the group has a gradient -- is one launch; the
         framework's _foreach_add_ over ~600 scalar tensors is 75 launches / 0.6 ms."""
-        everyone = [p for p in self.param_groups[gi]["params"] if len(self.state[p])]
+        everyone = [p for p in self.param_groups[gi]["params"] if self.state.get(p)]       # .get: indexing the defaultdict would plant {} entries that state_dict() then carries
         flat = self._step_flat.get(gi)
         if flat is None or flat.numel() != len(everyone) or any(self.state[p]["step"].data_ptr() != flat.data_ptr() + 4 * i for i, p in enumerate(everyone)):
             flat = torch.stack([self.state[p]["step"].to(params[0].device, torch.float32).reshape(()) for p in everyone])
@@ -61,13 +70,23 @@ class AdamWHIP(torch.optim.AdamW):
             for t, what in ((p, "parameter"), (g, "gradient"), (m, "exp_avg"), (v, "exp_avg_sq")):
                 if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.device == p.device and not t.is_sparse):
                     raise NotImplementedError(f"AdamWHIP: {what} of shape {tuple(t.shape)} must be a contiguous fp32 tensor on the parameter's GPU")
-            ptrs = [t.data_ptr() for t in (p, g, m, v)]
+            lo, hi = 0, p.numel()
+            if self._owner is not None:
+                rng = self._owner.owned_range(p)
+                if rng is None:
+                    continue
+                lo, hi = rng
+            ptrs = [t.data_ptr() + 4 * lo for t in (p, g, m, v)]
             vec = int(all(a % 16 == 0 for a in ptrs))
-            n = p.numel()
+            n = hi - lo
             for off in range(0, n, _CHUNK):
                 rows.append((ptrs[0] + 4 * off, ptrs[1] + 4 * off, ptrs[2] + 4 * off, ptrs[3] + 4 * off, st["step"].data_ptr(), min(_CHUNK, n - off), vec))
-        host = np.array(rows, dtype=_CHUNK_DTYPE)
-        dev = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(params[0].device)
+        host = np.array(rows, dtype=_CHUNK_DTYPE) if rows else np.zeros(0, dtype=_CHUNK_DTYPE)
+        if not rows:
+            self._tables[gi] = (key, torch.empty(0, dtype=torch.uint8, device=params[0].device), 0)
+            return self._tables[gi][1], 0
+        # (rebuilt only when a parameter / gradient pointer changes: with the reducer's stable bucket views that is once per run)
+        dev = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).pin_memory().to(params[0].device, non_blocking=True)
         self._tables[gi] = (key, dev, len(rows))
         return dev, len(rows)
 
@@ -77,7 +96,7 @@ class AdamWHIP(torch.optim.AdamW):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = vit_ops.load()
+        lib = _lib()
         gs = getattr(self, "grad_scale", None)
         if getattr(self, "found_inf", None) is not None:
             raise NotImplementedError("AdamWHIP: found_inf (torch.amp.GradScaler) is not supported; the hot path trains in fp32")
@@ -88,7 +107,7 @@ class AdamWHIP(torch.optim.AdamW):
             if not params:
                 continue
             for p in params:
-                st = self.state[p]
+                st = self.state[p]                             # (a parameter WITH a gradient gets its state here, as in torch)
                 if len(st) == 0:                               # torch.optim.AdamW._init_group, fused flavour
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
@@ -101,8 +120,59 @@ class AdamWHIP(torch.optim.AdamW):
             if gs is not None and not (gs.is_cuda and gs.device == dev and gs.dtype == torch.float32 and gs.numel() == 1):
                 raise ValueError("AdamWHIP: grad_scale must be a one-element fp32 tensor on the parameters' device")
             b1, b2 = group["betas"]
-            rc = lib.vit_adamw_step(table.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                    float(group["weight_decay"]), gs.data_ptr() if gs is not None else None,
-                                    torch.cuda.current_stream(dev).cuda_stream)
-            vit_ops._check(rc, "vit_adamw_step")
+            if n_chunks:
+                rc = lib.vit_adamw_step(table.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                        float(group["weight_decay"]), gs.data_ptr() if gs is not None else None,
+                                        torch.cuda.current_stream(dev).cuda_stream)
+                vit_ops._check(rc, "vit_adamw_step")
+            # the kernel wrote the parameters through raw pointers: tell autograd (and every cache keyed on `_version` -- the pre-split
+            # bf16 weight images of vit_ops._SPLIT_CACHE) that they changed, exactly as an in-place torch op would
+            torch.autograd.graph.increment_version(params)
+        # the coefficient belongs to THIS step's gradients (ddp.BucketedGradReducer.clip_grad_norm_(defer_to=...)); a later step without a
+        # fresh clip must not reuse it
+        self.grad_scale = None
         return loss
+
+
+class ShardedAdamWTorch(torch.optim.AdamW):
+    """The same owned-range AdamW in plain torch ops, for parameters that do not live on a GPU (the world-size-2 gloo tests of the
+    "rs_ag" exchange): identical arithmetic and state layout (fused flavour: `step` is a float32 tensor), one Python loop over the owned
+    slices.  Not a product path -- on the GPU `AdamWHIP(owner=reducer)` runs the owned ranges through csrc/vit_optim.hip."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, owner=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=False)
+        self._owner = owner
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        gs = getattr(self, "grad_scale", None)
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            lr, wd, eps = group["lr"], group["weight_decay"], group["eps"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p); st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1                                  # on every rank, owner or not: the counters stay identical
+                rng = (0, p.numel()) if self._owner is None else self._owner.owned_range(p)
+                if rng is None:
+                    continue
+                lo, hi = rng
+                t = float(st["step"])
+                P, G = p.data.reshape(-1)[lo:hi], p.grad.reshape(-1)[lo:hi]
+                M, V = st["exp_avg"].reshape(-1)[lo:hi], st["exp_avg_sq"].reshape(-1)[lo:hi]
+                if gs is not None:
+                    G = G / gs
+                P.mul_(1 - lr * wd)
+                M.lerp_(G, 1 - b1)
+                V.mul_(b2).addcmul_(G, G, value=1 - b2)
+                denom = (V.sqrt() / (1 - b2 ** t) ** 0.5).add_(eps)
+                P.addcdiv_(M, denom, value=-lr / (1 - b1 ** t))
+            touched = [p for p in group["params"] if p.grad is not None]
+            if touched:
+                torch.autograd.graph.increment_version(touched)
+        self.grad_scale = None
+        return None

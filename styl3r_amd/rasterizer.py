@@ -51,6 +51,7 @@ def _status_host(dev):
 # parity tests set KEEP_DEBUG to inspect the workspace (sorted lists, ranges, n_contrib) of the last forward
 KEEP_DEBUG = False
 LAST_DEBUG: dict = {}
+LAST_STATS: dict = {}      # pairs (tile, Gaussian) R, views V and Gaussians per scene G of the most recent forward on this process
 # bench.py sets PROFILE to a _lib.StageProfile to time every stage with hipEvents on the launch stream
 PROFILE = None
 
@@ -160,6 +161,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.mark_non_differentiable(radii, n_touched)
         ctx.set_materialize_grads(False)   # unused outputs (depth, opacity) arrive as None instead of zero-filled tensors
         ctx.num_pairs = R
+        LAST_STATS.update(pairs=R, views=V, gaussians_per_scene=G, longest_tile_list=int(st[2]))     # what the last forward rendered (benchmarks assert on it)
         if KEEP_DEBUG:
             LAST_DEBUG.update(ws=ws, layout=L, dims=dims, cap=cap, num_pairs=R, status=st)
         return image, radii, depth, opacity, n_touched

@@ -93,3 +93,49 @@ def make_scene(n_ctx: int = 1, grid_hw: tuple = (256, 256), n_views: int = 3, im
     K = torch.tensor([[FX, 0, 0.5], [0, FX, 0.5], [0, 0, 1.0]]).repeat(n_views, 1, 1)
     return Scene(torch.cat(means).float(), torch.cat(covs).float(), torch.cat(shs).float(), torch.cat(ops).float(),
                  ext, K, torch.full((n_views,), near), torch.full((n_views,), far), tuple(image_hw))
+
+
+# Target statistics (mean, std per output channel) of the five 1x1 output convolutions of the encoder's DPT heads after re-centring:
+# xyz of the point heads (depth expm1(|xyz|) ~ 2..4, inside a tan(fov/2) = 0.58 frustum), (opacity logit, 3 log-scales, 4 quaternion)
+# of the gs heads, SH DC of the appearance head.  A RANDOM-INIT encoder emits expm1 of a heavy-tailed norm (|means| up to 1e4, nearly
+# everything outside every frustum): benchmarks and fixtures that must render a real scene call `recentre_output_heads_` once.
+HEAD_TARGETS = {
+    "downstream_head1": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
+    "downstream_head2": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
+    "gaussian_param_head": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
+    "gaussian_param_head2": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
+    "gaussian_appearance_head": ([0.0, 0.0, 0.0], [1.2, 1.2, 1.2]),
+}
+
+
+@torch.no_grad()
+def recentre_output_heads_(encoder, context: dict, style: dict, targets: dict = None) -> dict:
+    """One calibration forward (no gradients), then an affine re-parametrisation of each head's last 1x1 convolution so that its output
+    channels have the target mean / std on this batch: set-up work for benchmarks on random-init weights (checkpoints are absent here),
+    the same calibration tests/golden/make_e2e_fixtures.py applies to the reference model.  Returns {head: (mean, std) before}."""
+    targets = targets or HEAD_TARGETS
+    heads = [k for k in targets if hasattr(encoder, k)]
+    stats, hooks = {}, []
+    for k in heads:
+        hooks.append(getattr(encoder, k).dpt.register_forward_hook(
+            lambda m, i, o, k=k: stats.setdefault(k, []).append(o.detach().transpose(0, 1).reshape(o.shape[1], -1).double())))
+    was_training = encoder.training
+    encoder.eval()
+    try:
+        encoder(context, style, 0)
+    finally:
+        for h in hooks:
+            h.remove()
+        encoder.train(was_training)
+    before = {}
+    for k in heads:
+        o = torch.cat(stats[k], 1)
+        mean, std = o.mean(1), o.std(1)
+        t_mean, t_std = (torch.tensor(x, dtype=torch.float64, device=o.device) for x in targets[k])
+        conv = getattr(encoder, k).dpt.head[4]
+        gain = t_std / std
+        conv.weight.copy_((conv.weight.double() * gain[:, None, None, None]).float())
+        conv.bias.copy_(((conv.bias.double() - mean) * gain + t_mean).float())
+        torch.autograd.graph.increment_version([conv.weight, conv.bias])
+        before[k] = (mean.tolist(), std.tolist())
+    return before

@@ -47,19 +47,40 @@ def select_trainable(encoder: nn.Module) -> Tuple[List[nn.Parameter], List[nn.Pa
 OPTIMIZER_IMPL = os.environ.get("STYL3R_OPTIMIZER", "hip")      # "hip": styl3r_amd.optim.AdamWHIP (one launch per group) | "torch": torch.optim.AdamW(fused=True); CPU parameters always take torch's
 
 
+DP_MODE = os.environ.get("STYL3R_DP_MODE", "all_reduce")       # "all_reduce" | "rs_ag" (reduce-scatter + sharded AdamW + parameter all-gather, ddp.py)
+
+
 def make_optimizer(new: Sequence[nn.Parameter], pre: Sequence[nn.Parameter], lr: float = 2e-4,
-                   backbone_lr_multiplier: float = 0.1) -> torch.optim.Optimizer:
+                   backbone_lr_multiplier: float = 0.1, owner=None) -> torch.optim.Optimizer:
     """AdamW(param_dicts, lr, weight_decay=0.05, betas=(0.9, 0.95)) of `:885-895`; on a GPU the single-pass optimizer kernel
     (csrc/vit_optim.hip through optim.AdamWHIP, state-compatible with the framework's fused AdamW; the foreach implementation makes
     ~10 passes over the 4.2 GB of parameter / moment state per step)."""
     groups = [g for g in ({"params": list(new), "lr": lr}, {"params": list(pre), "lr": lr * backbone_lr_multiplier})
               if g["params"]]
     on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+    if owner is not None and getattr(owner, "mode", "all_reduce") == "rs_ag":
+        # sharded step: this rank updates only the element ranges whose reduced gradient it holds (`owner.owned_range`)
+        from .optim import AdamWHIP, ShardedAdamWTorch
+        cls = AdamWHIP if on_gpu else ShardedAdamWTorch
+        return cls(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95), owner=owner)
     if on_gpu and OPTIMIZER_IMPL == "hip" and all(p.dtype == torch.float32 for g in groups for p in g["params"]):
         from .optim import AdamWHIP
         return AdamWHIP(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95))
     fused = any(p.is_cuda for g in groups for p in g["params"])
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95), fused=fused)
+    opt = torch.optim.AdamW(groups, lr=lr, weight_decay=0.05, betas=(0.9, 0.95), fused=fused)
+    opt.register_step_post_hook(_after_step)
+    return opt
+
+
+def _after_step(optimizer, args, kwargs):
+    """The framework's FUSED AdamW does not always bump `Tensor._version` of the parameters it rewrites (torch 2.10: stays 0), and
+    everything keyed on the version counter -- vit_ops._SPLIT_CACHE's pre-split weight images -- would keep serving the old weights.
+    Bump it for every parameter the step touched, and drop the one-step clip coefficient."""
+    touched = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    if touched:
+        torch.autograd.graph.increment_version(touched)
+    if getattr(optimizer, "grad_scale", None) is not None:
+        optimizer.grad_scale = None
 
 
 def make_lr_scheduler(optimizer, warm_up_steps: int, max_steps: int, lr: float):
@@ -77,18 +98,20 @@ class TrainStep:
     def __init__(self, encoder: nn.Module, decoder: nn.Module, lr: float = 2e-4, dist=None, bucket_bytes: int = 64 << 20,
                  clip: Optional[float] = 0.5, losses: Optional[Sequence[nn.Module]] = None,
                  identity_loss: Optional[nn.Module] = None, backbone_lr_multiplier: float = 0.1,
-                 warm_up_steps: Optional[int] = None, max_steps: int = 100_000, force_collective: bool = False):
+                 warm_up_steps: Optional[int] = None, max_steps: int = 100_000, force_collective: bool = False,
+                 dp_mode: Optional[str] = None):
         self.encoder, self.decoder, self.clip = encoder, decoder, clip
         self.losses, self.identity_loss = (list(losses) if losses is not None else None), identity_loss
         # identical replicas before anything else looks at the parameters (DDP semantics: rank 0's state wins)
         self.synced_bytes = broadcast_module_state(encoder, dist, force_collective=force_collective)
         new, pre, self.frozen_names = select_trainable(encoder)
-        self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier)
-        self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
         # bucket order = reverse registration order of the trainable parameters (autograd readiness)
         trainable = {id(p) for p in list(new) + list(pre)}
+        self.dp_mode = dp_mode or DP_MODE
         self.reducer = BucketedGradReducer([p for p in encoder.parameters() if id(p) in trainable], dist, bucket_bytes,
-                                           force_collective=force_collective)
+                                           force_collective=force_collective, mode=self.dp_mode, groups=[list(new), list(pre)])
+        self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier, owner=self.reducer if self.dp_mode == "rs_ag" else None)
+        self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
         self.global_step = 0
 
     def _render(self, ctx, style, tgt):
@@ -102,6 +125,7 @@ class TrainStep:
             style = {"image": (batch["style"]["image"] - 0.5) / 0.5}     # (0,1) -> (-1,1), `:151-155`
         else:
             style = {"image": ctx["image"][:, 0]}                         # stylized=False: style := context view 0 (`:149-150`)
+        self.reducer.wait_params()                                        # "rs_ag": the previous step's parameter all-gather must have landed
         self.reducer.prepare()
         g, out = self._render(ctx, style, tgt)
         if self.losses is None:
@@ -116,6 +140,7 @@ class TrainStep:
         if self.clip is not None:                                         # Trainer(gradient_clip_val=0.5), main_style.py:110
             self.reducer.clip_grad_norm_(self.clip, defer_to=self.optimizer)    # the fused AdamW applies the coefficient while it reads the gradients
         self.optimizer.step()
+        self.reducer.gather_params()                                      # "rs_ag": asynchronous; fenced at the top of the next step
         if self.scheduler is not None:
             self.scheduler.step()
         self.global_step += 1

@@ -59,7 +59,30 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_PATH.parent.mkdir(exist_ok=True)
     hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-    real = [hipcc, *cmd[1:-2], "-o", str(LIB_PATH)]
+    # one object per source, compiled in parallel and kept (keyed by the digest of the source, the headers and the flags) under build/obj/:
+    # editing one kernel file recompiles that file only; the link step is a second
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = _PKG.parent / "build" / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+    headers = sorted(_CSRC.glob("*.h")) + [(_PKG.parent / "include" / "vit_ops.h")]
+    hdig = hashlib.sha256(b"".join(h.read_bytes() for h in headers) + " ".join(flags).encode()).hexdigest()
+
+    def compile_one(name):
+        dig = hashlib.sha256((_CSRC / name).read_bytes() + hdig.encode()).hexdigest()[:16]
+        obj = objdir / f"{Path(name).stem}.{dig}.o"
+        if not obj.exists() or force:
+            for stale in objdir.glob(f"{Path(name).stem}.*.o"):
+                stale.unlink()
+            c = [hipcc, *flags, "-c", name, "-o", str(obj)]
+            if verbose:
+                print(" ".join(c), flush=True)
+            subprocess.run(c, check=True, cwd=str(_CSRC))
+        return str(obj)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, names))
+    real = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB_PATH)]
     if verbose:
         print(" ".join(real))
     subprocess.run(real, check=True, cwd=str(_CSRC))

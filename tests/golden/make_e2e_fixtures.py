@@ -11,12 +11,15 @@ Three runs of the same chain:
   rtf   float64, but every Linear / Conv2d / ConvTranspose2d product takes operands rounded to TF32 (10-bit mantissa), forward and
         backward, as on the GPUs the reference was developed on (croco.py:13 `allow_tf32 = True`; cudnn's conv TF32 default)
                                                             -> `tf32noise:*`  = its distance to r64
-Tags:  c3 = 1 scene, 2 context views 256 x 256, 2 target views (NVS-pretrain shapes);
+Tags:  full = the STOCK model of every README command (ViTLarge_BaseDecoder: 24 ViT-L blocks in the backbone encoder and 24 in the style
+              encoder, 12 + 12 + 12 decoder blocks; 1 049 635 033 parameters; backbone_croco_multiview.py:21-32, token_stylizer.py:36-48), 1 scene,
+              2 context views 256 x 256, 2 target views;  the two tags below use the 2-block trunk:
+       c3 = 1 scene, 2 context views 256 x 256, 2 target views (NVS-pretrain shapes);
        c4 = 1 scene, 4 context views 128 x 160, 2 target views (the 4-view style-stage structure: dec_blocks2 on 3 views, stylizer on 4).
 Trunk: decoder width 768 / 12 heads, 2 ViT-L encoder blocks, 12 decoder blocks (as encoder_mid.npz).  Weights are regenerated on both
 sides from the parameter names; only the five 1x1 output convolutions (`*.dpt.head.4`), re-centred so that the random-init model
 emits a usable scene (depth 2..4 inside the frustum instead of expm1 of a heavy-tailed norm), are stored.
-    python tests/golden/make_e2e_fixtures.py c3 ;  python tests/golden/make_e2e_fixtures.py c4
+    python tests/golden/make_e2e_fixtures.py c3 ;  python tests/golden/make_e2e_fixtures.py c4 ;  python tests/golden/make_e2e_fixtures.py full
 """
 import sys
 import time
@@ -36,7 +39,7 @@ from tests.golden.ref_stubs import install, style_encoder_cfg
 from tests.helpers import (closed_form_image, deterministic_init_, e2e_cameras, e2e_fragile_mask, E2E_HEAD_TARGETS)
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "c3"
-SHAPES = dict(c3=dict(v=2, H=256, W=256), c4=dict(v=4, H=128, W=160))[TAG]
+SHAPES = dict(c3=dict(v=2, H=256, W=256), c4=dict(v=4, H=128, W=160), full=dict(v=2, H=256, W=256))[TAG]
 MID = dict(enc_depth=2, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=768, enc_num_heads=16, dec_num_heads=12,
            pos_embed="RoPE100", img_size=(512, 512))
 NTHREADS = 8
@@ -86,8 +89,9 @@ dgr.GaussianRasterizer = GaussianRasterizer
 sys.modules["diff_gaussian_rasterization"] = dgr
 
 mods = install()
-mods.bm.croco_params["ViTLarge_BaseDecoder"] = dict(MID)
-mods.ts.croco_params["ViTLarge_BaseDecoder"] = dict(MID)
+if TAG != "full":                                                  # `full`: the stock ViTLarge_BaseDecoder (24 + 24 ViT-L blocks, 12 + 12 + 12 decoder blocks)
+    mods.bm.croco_params["ViTLarge_BaseDecoder"] = dict(MID)
+    mods.ts.croco_params["ViTLarge_BaseDecoder"] = dict(MID)
 enc_mod, cfg = style_encoder_cfg(mods, sh_degree=0)
 import importlib
 dsc = importlib.import_module("src.model.decoder.decoder_splatting_cuda")
@@ -135,6 +139,17 @@ GRADS = (("backbone.enc_blocks.0.attn.qkv.weight", 64), ("backbone.enc_blocks.1.
          ("gaussian_param_head.dpt.input_merger.0.weight", 16), ("gaussian_appearance_head.dpt.act_postprocess.0.1.weight", 8),
          ("backbone.patch_embed.proj.weight", 8), ("backbone.intrinsic_encoder.weight", None))
 
+
+if TAG == "full":                                                  # the model every README command runs: gradient slices across the real depth
+    GRADS = (("backbone.enc_blocks.0.attn.qkv.weight", 64), ("backbone.enc_blocks.12.mlp.fc1.weight", 64), ("backbone.enc_blocks.23.attn.proj.weight", 64),
+             ("backbone.enc_blocks.23.mlp.fc2.weight", 64), ("token_stylizer.enc_blocks.0.attn.qkv.weight", 64), ("token_stylizer.enc_blocks.23.mlp.fc1.weight", 64),
+             ("token_stylizer.enc_blocks.12.norm1.weight", None),
+             ("backbone.dec_blocks.5.cross_attn.projk.weight", 64), ("backbone.dec_blocks2.11.mlp.fc2.weight", 64),
+             ("token_stylizer.dec_blocks.3.cross_attn.projk.weight", 64), ("backbone.dec_norm.weight", None), ("backbone.enc_norm.weight", None),
+             ("downstream_head1.dpt.scratch.refinenet4.resConfUnit2.conv1.weight", 8), ("downstream_head2.dpt.scratch.layer1_rn.weight", 8),
+             ("gaussian_param_head.dpt.head.0.weight", 8), ("gaussian_param_head.dpt.input_merger.0.weight", 16),
+             ("gaussian_appearance_head.dpt.act_postprocess.0.1.weight", 8), ("backbone.patch_embed.proj.weight", 8),
+             ("backbone.intrinsic_encoder.weight", None))
 
 OK_MASK = None          # (b, v_t, 1, H, W) bool: pixels that enter the loss (set after the preliminary float64 forward below)
 

@@ -95,13 +95,7 @@ def deterministic_vgg_(module):
 # Target statistics (mean, std per output channel) of the five 1x1 output convolutions after re-centring: xyz of the point heads
 # (depth expm1(|xyz|) ~ 2..4, inside a tan(fov/2) = 0.58 frustum), (opacity logit, 3 log-scales, 4 quaternion) of the gs heads,
 # SH DC of the appearance head.
-E2E_HEAD_TARGETS = {
-    "downstream_head1": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
-    "downstream_head2": ([0.0, 0.0, 1.25], [0.30, 0.30, 0.12]),
-    "gaussian_param_head": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
-    "gaussian_param_head2": ([0.5, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, 0.0], [1.2, 1.5, 1.5, 1.5, 1.0, 1.0, 1.0, 1.0]),
-    "gaussian_appearance_head": ([0.0, 0.0, 0.0], [1.2, 1.2, 1.2]),
-}
+from styl3r_amd.scenes import HEAD_TARGETS as E2E_HEAD_TARGETS      # (one source: the benchmarks re-centre random-init heads the same way)
 
 
 def e2e_cameras(b=1):

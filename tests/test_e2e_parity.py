@@ -25,11 +25,14 @@ from tests.helpers import E2E_HEAD_TARGETS, closed_form_image, deterministic_ini
 MID = dict(enc_depth=2, dec_depth=12, enc_embed_dim=1024, dec_embed_dim=768, enc_num_heads=16, dec_num_heads=12,
            pos_embed="RoPE100", img_size=(512, 512))
 GOLD = Path(__file__).resolve().parent / "golden"
-SHAPES = dict(c3=(2, 256, 256), c4=(4, 128, 160))
+SHAPES = dict(c3=(2, 256, 256), c4=(4, 128, 160), full=(2, 256, 256))
+TAGS = ["c3", "c4", "full"]       # `full`: the stock ViTLarge_BaseDecoder trunk (24 + 24 ViT-L blocks, 12 + 12 + 12 decoder blocks, 1 049 635 033 parameters)
 
 
-def _mid():
+def _mid(tag="c3"):
     from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    if tag == "full":
+        return EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg()).eval()
     return EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(), trunk_params=MID).eval()
 
 
@@ -41,7 +44,7 @@ def _load_heads(m, G):
     return m
 
 
-@pytest.mark.parametrize("tag", ["c3", "c4"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_e2e_fixture_is_usable(tag):
     G = np.load(GOLD / f"e2e_{tag}.npz")
     v, H, W = SHAPES[tag]
@@ -50,8 +53,11 @@ def test_e2e_fixture_is_usable(tag):
     assert frag.mean() < 0.15, frag.mean()                       # the mask must not hide the comparison
     assert G["color"].max() > 0.5 and (G["color"].reshape(2, 3, -1).max(2) > 0.3).all()     # a real image, not a black frame
     with torch.device("meta"):
-        m = _mid()
+        m = _mid(tag)
     assert sum(p.numel() for p in m.parameters()) == int(G["nparams"])
+    if tag == "full":
+        assert int(G["nparams"]) == 1_049_635_033 and len(m.backbone.enc_blocks) == 24 and len(m.token_stylizer.enc_blocks) == 24
+        assert "g:backbone.enc_blocks.23.mlp.fc2.weight" in G.files and "g:token_stylizer.enc_blocks.23.mlp.fc1.weight" in G.files
     for k in ("means", "color", "gimage", "loss", "g:backbone.enc_blocks.0.attn.qkv.weight"):
         assert f"fp32noise:{k}" in G.files and f"tf32noise:{k}" in G.files
     # TF32 -- the reference's real Linear / Conv arithmetic -- is two orders noisier than fp32 on every quantity
@@ -68,7 +74,7 @@ def _rel(a, e, mask=None):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
-@pytest.mark.parametrize("tag", ["c3", "c4"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, monkeypatch):
     from styl3r_amd import vit_ops
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
@@ -77,7 +83,7 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     dev = "cuda:0"
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
     monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", mode)          # the three-product mode covers the attention contractions, too
-    m = _load_heads(deterministic_init_(_mid()), G).to(dev)
+    m = _load_heads(deterministic_init_(_mid(tag)), G).to(dev)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
     T = lambda k: torch.tensor(G[k], device=dev)
     before = dict(vit_ops.CALLS)

@@ -179,7 +179,8 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
     import torch.distributed as dist
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
     from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
-    from styl3r_amd.scenes import make_scene
+    from styl3r_amd import rasterizer
+    from styl3r_amd.scenes import make_scene, recentre_output_heads_
     from styl3r_amd.train import TrainStep
     dev = torch.device("cuda:0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
@@ -195,15 +196,21 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
                                  intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)))
         dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
 
-        def run(group, force):
+        def run(group, force, dp_mode="all_reduce"):
             torch.manual_seed(0); torch.cuda.manual_seed(0)
             with torch.device(dev):
                 enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=False)).eval()   # eval: no dropout RNG in the comparison
-            step = TrainStep(enc, dec, dist=group, force_collective=force)
-            assert step.reducer.collective == force
+            # a random-init point head puts (nearly) every Gaussian outside every frustum: the render is the background and EVERY gradient is
+            # exactly zero (r03 ran this test on zeros).  Re-centre the five output convolutions so that the step renders a real scene
+            recentre_output_heads_(enc, batch["context"], dict(image=batch["context"]["image"][:, 0]))
+            step = TrainStep(enc, dec, dist=group, force_collective=force, dp_mode=dp_mode)
+            assert step.reducer.collective == force and step.reducer.mode == dp_mode
             losses = [float(step(batch)) for _ in range(2)]
-            flats = [bk["flat"].detach().clone() for bk in step.reducer.buckets]
-            info = dict(synced=step.synced_bytes, buckets=len(flats), unused=len(step.reducer._unused), losses=losses)
+            assert rasterizer.LAST_STATS["pairs"] > rasterizer.LAST_STATS["gaussians_per_scene"], rasterizer.LAST_STATS
+            step.reducer.wait_params()
+            flats = [bk["flat"][:bk["n"]].detach().clone() for bk in step.reducer.buckets]
+            info = dict(synced=step.synced_bytes, buckets=len(flats), unused=len(step.reducer._unused), losses=losses,
+                        probe=enc.backbone.enc_blocks[3].mlp.fc1.weight.detach()[:8].clone(), flat_params=all("pflat" in bk for bk in step.reducer.buckets))
             step.reducer.close()
             del step, enc
             torch.cuda.empty_cache()
@@ -215,6 +222,7 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
         assert ic["buckets"] == ia["buckets"] >= 60 and ic["unused"] == ia["unused"] >= 1     # mask_token: unused on "every" rank
         assert all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(ia["losses"], ic["losses"])), (ia, ic)
         worst = 0.0
+        assert min(float(x.abs().max()) for x in a) > 0.0, "a bucket of all-zero gradients: the step rendered nothing"
         for i, (x, x2, y) in enumerate(zip(a, a2, c)):
             assert torch.isfinite(y).all(), f"bucket {i}"
             scale = float(x.abs().max())
@@ -223,6 +231,18 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
             worst = max(worst, err / max(scale, 1e-30))
             assert err <= 4 * noise + 1e-6 * scale, (i, err, noise, scale)
         print(f"  one-rank RCCL vs local: {len(a)} buckets, worst bucket deviation {worst:.2e} of the bucket scale")
+        # SURVEY 8e's collective behind the switch: reduce-scatter per bucket + owned-range AdamW + parameter all-gather, all of them
+        # issued on RCCL with one rank (every rank-r shard is the whole bucket): same losses, same gradients, same updated weights
+        r, ir = run(dist, True, "rs_ag")
+        assert ir["flat_params"] and not ic["flat_params"]
+        assert all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(ia["losses"], ir["losses"])), (ia, ir)
+        # (bucket boundaries differ -- optimizer groups never share a bucket in this mode -- so compare the concatenation)
+        ca, ca2, cr = (torch.cat([t.reshape(-1) for t in fl]) for fl in (a, a2, r))
+        assert ca.numel() == cr.numel()
+        scale, noise = float(ca.abs().max()), float((ca - ca2).abs().max())
+        assert float((ca - cr).abs().max()) <= 4 * noise + 1e-6 * scale
+        assert float((ir["probe"] - ic["probe"]).abs().max()) <= 1e-6 * float(ic["probe"].abs().max()) + 4e-7
+        print(f"  rs_ag mode on one RCCL rank: gradients within {float((ca - cr).abs().max()) / scale:.2e} of the local path")
     finally:
         dist.destroy_process_group()
 
@@ -309,3 +329,125 @@ def test_hip_adamw_pass_equals_the_frameworks_fused_adamw_and_shares_its_state_l
     for k in range(12, 16):
         step(k)
     compare("after swapping the state dicts")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", ["hip", "torch"])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_forward_sees_the_weights_the_optimizer_just_wrote(impl, mode, monkeypatch):
+    """the kernels read PRE-SPLIT bf16 images of every Linear / convolution weight, cached on `Tensor._version`
+    (vit_ops._SPLIT_CACHE).  An optimizer that writes parameters through raw pointers (optim.AdamWHIP) -- or the framework's fused AdamW,
+    which does not bump the counter either -- must invalidate them, or the model keeps computing with its initial weights.  After every
+    step the fused Linear (default kernel, ring kernel, input-gradient image) and the bf16x6 convolution must match the plain fp64
+    product with the UPDATED fp32 weights, and differ from the product with the old ones."""
+    from styl3r_amd import train, vit_ops
+    dev = "cuda:0"
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    monkeypatch.setattr(train, "OPTIMIZER_IMPL", impl)
+    g = torch.Generator(dev).manual_seed(5)
+    lin_small = torch.nn.Parameter(torch.randn(256, 192, device=dev, generator=g) * 0.05)          # default kernel
+    lin_ring = torch.nn.Parameter(torch.randn(3072, 1024, device=dev, generator=g) * 0.03)          # LDS-DMA ring kernel at M >= 4096
+    conv = vit_ops.Conv2dX6(128, 128, 3, padding=1).to(dev)
+    xs = torch.randn(300, 192, device=dev, generator=g)
+    xr = torch.randn(4224, 1024, device=dev, generator=g)
+    xc = torch.randn(2, 128, 64, 64, device=dev, generator=g)
+    opt = train.make_optimizer([lin_small, lin_ring], list(conv.parameters()), lr=5e-2)
+    tol = 2e-4 if mode == "bf16x3" else 2e-5
+    rel = lambda a, e: float((a.double() - e).abs().max() / e.abs().max())
+
+    def products():
+        xs_ = xs.clone().requires_grad_(True)
+        ys = vit_ops.fused_linear(xs_, lin_small)
+        yr = vit_ops.fused_linear(xr, lin_ring)
+        yc = conv(xc)
+        (ys.sum() + yr.mean() + yc.mean()).backward()
+        return ys.detach(), yr.detach(), yc.detach(), xs_.grad.detach()
+
+    def exact():
+        return (xs.double() @ lin_small.detach().double().t(), xr.double() @ lin_ring.detach().double().t(),
+                torch.nn.functional.conv2d(xc.double(), conv.weight.detach().double(), conv.bias.detach().double(), padding=1),
+                torch.ones(300, 256, device=dev, dtype=torch.float64) @ lin_small.detach().double())
+
+    before = dict(vit_ops.CALLS)
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        got, want = products(), exact()
+        for name, a, e in zip(("linear", "ring linear", "conv", "linear dX"), got, want):
+            assert rel(a, e) <= tol, (impl, mode, step, name, rel(a, e))
+        old = want
+        opt.step()
+        new = exact()
+        assert all(rel(n.float(), o) > 1e-2 for n, o in zip(new, old)), "the step must move the weights for this test to mean anything"
+    assert vit_ops.CALLS["conv_x6_fwd"] > before["conv_x6_fwd"]
+    # and the last update is visible, too
+    for name, a, e in zip(("linear", "ring linear", "conv", "linear dX"), products(), exact()):
+        assert rel(a, e) <= tol, (impl, mode, "final", name, rel(a, e))
+
+
+@pytest.mark.gpu
+def test_full_size_style_stage_step_trains_only_the_stylizer_and_accumulates_both_passes_in_place():
+    """VERDICT r03 missing #3: ONE C4 step on the FULL-SIZE stylized encoder (b = 1, 4 context / 6 target views 256 x 256, VGG style
+    loss + identity pass: two encoder + decoder passes share every weight, model_wrapper_style.py:189,211-231) with the in-place bucket
+    slots, against the same step with `inplace_grads=False` (autograd accumulates the two passes itself, the reducer copies):
+      * only `token_stylizer.*` and `gaussian_appearance_head.*` receive gradients; everything else is frozen (`:854-868`);
+      * the in-place slots hold the SUM of both passes (equal to the copy path's gradients to within the weight-gradient kernels'
+        atomics noise), i.e. the second pass accumulated into the first one's slot instead of overwriting it;
+      * the loss is finite and the step renders a real scene."""
+    from styl3r_amd import rasterizer, vit_ops
+    from styl3r_amd.ddp import BucketedGradReducer
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, get_decoder
+    from styl3r_amd.encoder import EncoderNoPoSplatMultiTokenStyle, EncoderNoPoSplatTokenStyleCfg
+    from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+    from styl3r_amd.scenes import make_scene, recentre_output_heads_
+    from styl3r_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    b, v_ctx, v_tgt, H = 1, 4, 6, 256
+    sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=21)
+    g = torch.Generator(dev).manual_seed(9)
+    ex = lambda t, *shape: t.to(dev)[None].expand(b, *shape).contiguous()
+    batch = dict(context=dict(image=torch.rand(b, v_ctx, 3, H, H, device=dev, generator=g) * 2 - 1, intrinsics=sc.intrinsics[:1].to(dev).expand(b, v_ctx, 3, 3).contiguous()),
+                 target=dict(image=torch.rand(b, v_tgt, 3, H, H, device=dev, generator=g), extrinsics=ex(sc.extrinsics, -1, -1, -1),
+                             intrinsics=ex(sc.intrinsics, -1, -1, -1), near=ex(sc.near, -1), far=ex(sc.far, -1)),
+                 style=dict(image=torch.rand(b, 3, H, H, device=dev, generator=g)))
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+
+    def run(inplace):
+        torch.manual_seed(0); torch.cuda.manual_seed(0)
+        with torch.device(dev):
+            enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=True)).eval()      # eval: no dropout RNG in the comparison
+            vgg = VGGEncoder()
+        recentre_output_heads_(enc, batch["context"], dict(image=(batch["style"]["image"] - 0.5) / 0.5))
+        step = TrainStep(enc, dec, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
+        if not inplace:
+            step.reducer.close()
+            step.reducer = BucketedGradReducer([p for p in enc.parameters() if p.requires_grad], None, 64 << 20, inplace_grads=False)
+        before = dict(vit_ops.CALLS)
+        loss = float(step(batch))
+        grads = {n: (p.grad.detach().clone() if p.grad is not None else None) for n, p in enc.named_parameters()}
+        adopted = sum(1 for bk in step.reducer.buckets for p, v in zip(bk["params"], bk["views"]) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+        pairs = dict(rasterizer.LAST_STATS)
+        step.reducer.close()
+        del step, enc, vgg
+        torch.cuda.empty_cache()
+        return loss, grads, adopted, pairs, {k: vit_ops.CALLS[k] - before[k] for k in before}
+
+    l_in, g_in, adopted, pairs, took = run(True)
+    l_cp, g_cp, _, _, _ = run(False)
+    l_cp2, g_cp2, _, _, _ = run(False)                        # the copy path's own run-to-run noise (fp32 atomics)
+    assert all(map(lambda x: x == x and abs(x) < 1e30, (l_in, l_cp))) and abs(l_in - l_cp) <= 1e-4 * abs(l_cp), (l_in, l_cp)
+    assert pairs["pairs"] > pairs["gaussians_per_scene"], pairs
+    assert adopted > 100, adopted                             # the Linear weights' gradients live in the bucket slots
+    assert took["layernorm_framework"] == 0 and took["conv_x6_fwd"] > 0, took
+    with_grad = {n for n, t in g_in.items() if t is not None}
+    assert with_grad and all(n.startswith("token_stylizer.") or n.startswith("gaussian_appearance_head.") for n in with_grad), sorted(with_grad)[:5]
+    assert any(n.startswith("token_stylizer.enc_blocks.23.") for n in with_grad) and any(n.startswith("gaussian_appearance_head.") for n in with_grad)
+    assert {n for n, t in g_cp.items() if t is not None} == with_grad
+    worst = 0.0
+    for n in sorted(with_grad):
+        scale = float(g_cp[n].abs().max())
+        noise = float((g_cp2[n] - g_cp[n]).abs().max())
+        err = float((g_in[n] - g_cp[n]).abs().max())
+        worst = max(worst, err / max(scale, 1e-30))
+        # a slot that kept only ONE of the two passes would be off by O(scale)
+        assert err <= 5e-4 * scale + 4 * noise + 1e-9, (n, err, noise, scale)
+    print(f"  full-size C4 step: {len(with_grad)} trained tensors, in-place vs copy path worst deviation {worst:.2e} of the tensor scale; loss {l_in:.5f}; pairs {pairs}")

@@ -48,12 +48,6 @@ if c5:
 enc = EncoderNoPoSplatMultiTokenStyle(cfg, trunk_params=tiny).to(dev)
 # the reference's xavier init gives scales ~1e-3 softplus(0): keep default torch init (random weights, data=synthetic)
 dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
-if c4:
-    from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
-    vgg = VGGEncoder().to(dev)
-    step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
-else:
-    step = TrainStep(enc, dec, dist=dist)
 b, v_ctx, v_tgt, H = args.scenes, (4 if (c4 or c5) else 2), (6 if c4 else 4), (512 if c5 else 256)
 g = torch.Generator(dev).manual_seed(1234 + rank)
 sc = make_scene(n_ctx=v_ctx, grid_hw=(8, 8), n_views=v_tgt, image_hw=(H, H), seed=1234 + rank)
@@ -65,8 +59,19 @@ batch = dict(
                 far=sc.far.to(dev)[None].expand(b, -1).contiguous()))
 if c4:
     batch["style"] = dict(image=torch.rand(b, 3, H, H, device=dev, generator=g))
+# set-up (untimed): a random-init point head throws the Gaussians outside every frustum; re-centre the five output convolutions so the step renders a real scene
+from styl3r_amd import rasterizer
+from styl3r_amd.scenes import recentre_output_heads_
+recentre_output_heads_(enc, batch["context"], dict(image=(batch["style"]["image"] - 0.5) / 0.5) if c4 else dict(image=batch["context"]["image"][:, 0]))
+if c4:
+    from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
+    vgg = VGGEncoder().to(dev)
+    step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
+else:
+    step = TrainStep(enc, dec, dist=dist)
 for _ in range(args.warmup):
     step(batch)
+assert rasterizer.LAST_STATS["pairs"] > rasterizer.LAST_STATS["gaussians_per_scene"], rasterizer.LAST_STATS
 dt = dist_utils.timed_steps(lambda: step(batch), args.steps, lambda: torch.cuda.synchronize(dev), dist, dev)
 if rank == 0:
     nparam = sum(p.numel() for p in enc.parameters())
