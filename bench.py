@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--train-warmup", type=int, default=3)
-    ap.add_argument("--train-mode", choices=["bf16x3", "bf16x6"], default="bf16x3", help="arithmetic of the GEMM-shaped kernels in the headline train step")
+    ap.add_argument("--train-mode", choices=["bf16x3", "bf16x6", "f16x3"], default="f16x3", help="arithmetic of the GEMM-shaped kernels in the headline train step")
     ap.add_argument("--train-tiny", action="store_true", help="small trunk for the train leg (smoke tests only; flagged in the line)")
     ap.add_argument("--dry-cpu", action="store_true",
                     help="launch-path test mode: gloo on CPU, no kernels, no oracle -- checks spawning / sharding / the JSON line")
@@ -81,6 +81,16 @@ def respawn_under_torchrun(args) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", STYL3R_BENCH_SPAWNED="1")
     return subprocess.run(cmd, env=env).returncode
+
+
+ARITH_NOTES = {
+    "f16x3": ("two fp16 pieces per operand x per-tensor power-of-two scale, three products on the f16 MFMA with fp32 accumulation (attention: six bf16 products): "
+              "fp32 round-off accuracy -- Gaussians <= 1e-5 of the float64 reference at the model's full depth (tests/test_e2e_parity.py[full-f16x3], "
+              "tests/golden/e2e_full.npz) -- at the MFMA count of bf16x3"),
+    "bf16x6": "bf16x6 split products (six bf16 MFMAs per fp32 product): fp32 round-off accuracy, the library default",
+    "bf16x3": ("three bf16 products per fp32 product: inside the reference's own TF32 distance on every quantity (worst ratio 0.13 .. 0.21) but covariances at "
+               "1.3e-4 of float64 at full depth -- above north_star's 1e-4, hence not the headline mode"),
+}
 
 
 # ------------------------------------------------------------------ raster leg
@@ -318,14 +328,13 @@ def train_leg(args, rank, world, dev, dist):
     # (depth 2..4 in front of context view 0, as tests/golden/make_e2e_fixtures.py does for the reference model); rank 0's result is broadcast
     if not cpu:
         recentre_output_heads_(enc, batch["context"], dict(image=batch["context"]["image"][:, 0]))
-    step = TrainStep(enc, dec, dist=dist, force_collective=forced)
-    # Arithmetic of the GEMM-shaped kernels in the headline train step: "bf16x3" (three bf16 partial products per fp32 product).  The
-    # reference runs these layers in TF32 (croco.py:13 allow_tf32, cudnn's conv default); tests/test_e2e_parity.py measures, against the
-    # reference's own chain in float64, that bf16x3 sits INSIDE the reference's TF32 distance on every quantity (Gaussians, rendered RGB,
-    # loss, every gradient: worst ratio 0.1 .. 0.84, gradients 20 - 60 x closer) -- VERDICT r02 #2's rule.  "bf16x6" (fp32 round-off
-    # accuracy, the library default and the mode of every 1e-4 parity statement) is timed beside it.
+    step = TrainStep(enc, dec, dist=dist, force_collective=forced, warm_up_steps=2000)    # config/main.yaml:37 (LinearLR from lr / 2000): the first steps of a run do not throw the scene away
+    # Arithmetic of the GEMM-shaped kernels in the headline train step (ARITH_NOTES): "f16x3" -- the mode that meets north_star's 1e-4 on the
+    # Gaussians at the model's FULL depth (tests/test_e2e_parity.py[full-*], tests/golden/e2e_full.npz: 24 + 24 ViT-L blocks) at the MFMA
+    # count of bf16x3.  bf16x3 sits inside the reference's own TF32 distance (croco.py:13 allow_tf32) on every quantity but puts the
+    # covariances at 1.3e-4 of float64 at full depth, so it no longer carries the headline; it and bf16x6 are timed beside it.
     keep_mode, keep_attn = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
-    head_mode = "bf16x6" if (cpu or args.train_tiny or args.train_mode == "bf16x6") else "bf16x3"
+    head_mode = "bf16x6" if (cpu or args.train_tiny) else args.train_mode
     try:
         vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = head_mode        # Linear / conv / attention contractions: one mode
         for _ in range(args.train_warmup):
@@ -347,27 +356,25 @@ def train_leg(args, rank, world, dev, dist):
            "collective": ("all_reduce(SUM) per bucket on the backend's stream, overlapped with the backward"
                           + (" (ONE-rank group: collectives issued, identity result)" if forced else "") if step.reducer.collective else "none (1 rank, no process group)"),
            "linear_arithmetic": head_mode, "dtype": "f32",
-           "arithmetic_note": ("bf16x3 split products on the bf16 MFMA with fp32 accumulation: inside the reference's own TF32 distance on every quantity "
-                               "(tests/test_e2e_parity.py, tests/golden/e2e_c3.npz / e2e_c4.npz: tf32noise vs measured)" if head_mode == "bf16x3" else
-                               "bf16x6 split products: fp32 round-off accuracy"),
+           "arithmetic_note": ARITH_NOTES[head_mode],
            "data": "synthetic, random-init weights",
            "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
     if not cpu:
         out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
         if not args.train_tiny:
-            other = "bf16x6" if head_mode == "bf16x3" else "bf16x3"
-            try:
-                vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = other
-                n_other = args.train_steps
-                for _ in range(3):          # (the first steps after a switch build the other mode's packed-weight buffers)
-                    step(batch)
-                dt3 = dist_utils.timed_steps(lambda: step(batch), n_other, sync, dist, dev)
-                out[other] = {"ms_per_step": round(1e3 * dt3 / n_other, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n_other, world, dt3), 3),
-                              "unit": "views/s", "steps": n_other, "products_per_launch": vit_ops.load().vit_x6_products(),
-                              "note": "the same step in the other arithmetic mode" + (" (fp32 round-off accuracy; mode of the 1e-4 parity tests)" if other == "bf16x6" else "")}
-            finally:
-                vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
-                vit_ops._x6()
+            for other in [m for m in ("f16x3", "bf16x6", "bf16x3") if m != head_mode]:
+                try:
+                    vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = other
+                    n_other = args.train_steps
+                    for _ in range(3):          # (the first steps after a switch build the other mode's packed-weight buffers)
+                        step(batch)
+                    dt3 = dist_utils.timed_steps(lambda: step(batch), n_other, sync, dist, dev)
+                    out[other] = {"ms_per_step": round(1e3 * dt3 / n_other, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n_other, world, dt3), 3),
+                                  "unit": "views/s", "steps": n_other, "products_per_launch": vit_ops.load().vit_x6_products(),
+                                  "note": "the same step in another arithmetic mode: " + ARITH_NOTES[other]}
+                finally:
+                    vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
+                    vit_ops._x6()
             out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
     return out
 
@@ -408,13 +415,13 @@ def stage_leg(args, rank, world, dev, dist, config):
     if c4:
         from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
         vgg = VGGEncoder().to(dev)
-        step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), force_collective=forced)
+        step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), force_collective=forced, warm_up_steps=2000)
     else:
-        step = TrainStep(enc, dec, dist=dist, force_collective=forced)
+        step = TrainStep(enc, dec, dist=dist, force_collective=forced, warm_up_steps=2000)
     keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
     steps = 10
     try:
-        vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = "bf16x3"
+        vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = args.train_mode
         for _ in range(3):
             step(batch)
         dt = dist_utils.timed_steps(lambda: step(batch), steps, lambda: torch.cuda.synchronize(dev), dist, dev)
@@ -428,7 +435,7 @@ def stage_leg(args, rank, world, dev, dist, config):
            "value": round(dist_utils.aggregate_throughput(b * v_tgt, steps, world, dt), 3), "unit": "views/s", "ms_per_step": round(1e3 * dt / steps, 2),
            "steps": steps, "warmup": 3, "scenes_per_gpu": b, "ctx_views": v_ctx, "tgt_views": v_tgt, "gaussians_per_scene": v_ctx * H * H,
            "pairs_R": rendered.get("pairs"), "longest_tile_list": rendered.get("longest_tile_list"),
-           "trainable_params": sum(p.numel() for p in enc.parameters() if p.requires_grad), "linear_arithmetic": "bf16x3", "dtype": "f32",
+           "trainable_params": sum(p.numel() for p in enc.parameters() if p.requires_grad), "linear_arithmetic": args.train_mode, "dtype": "f32",
            "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "n_gpus": world, "data": "synthetic, random-init weights (VGG included)"}
     del step, enc, dec, batch
     torch.cuda.empty_cache()
@@ -522,7 +529,7 @@ def linear_roofline(dev, M):
     res = {}
     keep = vit_ops.LINEAR_MODE
     try:
-        for mode, nprod in (("bf16x6", 6), ("bf16x3", 3)):
+        for mode, nprod in (("bf16x6", 6), ("bf16x3", 3), ("f16x3", 3)):
             vit_ops.LINEAR_MODE = mode
             before = vit_ops.CALLS["linear_x6r"]
             with torch.no_grad():
@@ -537,7 +544,7 @@ def linear_roofline(dev, M):
             ms = e0.elapsed_time(e1) / 50
             tf = 2.0 * M * N * K / ms / 1e9
             ring = vit_ops.CALLS["linear_x6r"] > before
-            res[mode] = {"kernel": ("vit::x6r::k_linear_x6c (256 x 256 tiles, ping-pong wave pairs, LDS-DMA ring)" if ring else "vit::x6::k_linear_x6"),
+            res[mode] = {"kernel": ("vit::x6r::k_linear_x6c (256 x 256 tiles, ping-pong wave pairs, LDS-DMA ring)" if ring else "vit::x6::k_linear_x6" + (" + vit::x6::k_amax" if mode == "f16x3" else "")),
                          "ms": round(ms, 4), "achieved": round(tf, 1), "unit": "TFLOP/s (fp32-accurate product rate)", "bound": "mfma",
                          "peak": round(2500.0 / nprod, 1), "frac": round(tf / (2500.0 / nprod), 3), "mfma_TFLOPs_bf16": round(nprod * tf, 1)}
     finally:
@@ -545,7 +552,7 @@ def linear_roofline(dev, M):
         vit_ops._x6()
     head = res["bf16x6"]
     return {"kernel": head["kernel"] + " (encoder qkv Linear)", "shape_MNK": [M, N, K], "ms": head["ms"], "achieved": head["achieved"], "unit": head["unit"],
-            "bound": "mfma", "peak": head["peak"], "frac": head["frac"], "mfma_TFLOPs_bf16": head["mfma_TFLOPs_bf16"], "bf16x3": res["bf16x3"],
+            "bound": "mfma", "peak": head["peak"], "frac": head["frac"], "mfma_TFLOPs_bf16": head["mfma_TFLOPs_bf16"], "bf16x3": res["bf16x3"], "f16x3": res["f16x3"],
             "note": "power-limited on random operands: DESIGN.md 9.2"}
 
 

@@ -102,7 +102,8 @@ int vit_linear_fwd(const float *x, const float *w, const float *bias, const floa
  *   transpose = 0: w (rows = N, cols = K)  ->  packed weight for  out = x . w^T       (the forward, nn.Linear)
  *   transpose = 1: w (rows = N, cols = K)  ->  packed w^T for     dX  = dY . w        (the input gradient):
  *                  call vit_linear_x6_fwd(dY, packed, NULL, NULL, dX, NULL, M, K, N, 0)
- * `packed` holds vit_split_weight_bytes(rows, cols) = 6 bytes per element, layout [out_row][k/8][piece][8] bf16.
+ * `packed` holds vit_split_weight_bytes(rows, cols) = 6 bytes per element (+ 256: the 32-bit word right behind the pieces carries the
+ * weight's |max| bit pattern in the f16x3 mode), layout [out_row][k/8][piece][8] bf16.
  * The contraction length must be a multiple of 16.
  */
 size_t vit_split_weight_bytes(int rows, int cols);
@@ -111,9 +112,21 @@ size_t vit_split_weight_bytes(int rows, int cols);
  * (default); 3 = "bf16x3", a0 b0 + a0 b1 + a1 b0 only: ~3.5e-6 of the output scale per GEMM (two orders tighter than the TF32 the
  * reference enables, croco.py:13) for half the MFMA work.  Per calling thread (thread_local), read when that thread launches a kernel.  Returns VIT_EINVAL for
  * any other n.
+ *
+ * n = 2 selects "f16x3": every operand is split into TWO fp16 pieces (11-bit significands) of value * s, s = the power of two that puts
+ * the operand TENSOR's absolute maximum into [2^14, 2^15), and the three products h h' + h l' + l h' run on v_mfma_f32_32x32x16_f16:
+ * 2^-22 per product (bf16x3: 2^-16; bf16x6: 2^-24) at the MFMA count and data path of bf16x3.  The kernels then need the |max| of their
+ * ACTIVATION operands: compute it with vit_amax (an exact integer max over the fp32 bit patterns of |x|; `out_word` must hold 0 before the
+ * launch; several launches may accumulate into one word) and announce the device addresses with vit_x6_set_operand_amax right before the
+ * launch they belong to, on the launching thread: a = x for vit_linear_x6_fwd / vit_conv_x6_fwd (forward and input-gradient uses alike),
+ * a = dY, b = x for vit_linear_x6_wgrad / vit_linear_x6_wgrad_acc / vit_conv_x6_wgrad.  The pair is consumed by that launch; a launch in
+ * this mode without it returns VIT_EINVAL (no guessed scale, no fallback).  Weights get their scale inside vit_split_weight (called in
+ * this mode).  Scales are powers of two, so applying and removing them is exact; fp16 range is the only reason they exist.
  */
 int vit_x6_set_products(int n);
 int vit_x6_products(void);
+int vit_x6_set_operand_amax(const void *a_word, const void *b_word);
+int vit_amax(const float *x, int64_t n, void *out_word, void *stream);
 int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
 /*
  * The same Linear with an LDS-DMA operand ring (csrc/vit_gemm_x6r.hip).  Its weight operand is the BLOCK layout

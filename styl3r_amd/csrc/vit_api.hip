@@ -49,6 +49,8 @@ int adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, 
                const float *grad_scale, hipStream_t stream);
 int x6_set_products(int n);
 int x6_products();
+int x6_set_operand_amax(const void *a, const void *b);
+int amax(const float *x, int64_t n, void *out, hipStream_t stream);
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                    int K, int act, int cfg, hipStream_t stream);
@@ -87,7 +89,8 @@ VIT_EXPORT int vit_linear_fwd(const float *x, const float *w, const float *bias,
     return vit::linear_fwd(x, w, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
 
-VIT_EXPORT size_t vit_split_weight_bytes(int rows, int cols) { return (size_t)rows * (size_t)cols * 6; }
+// (+ 256: the word right behind the pieces carries the weight's |max| in the f16x3 mode, vit_x6_set_products(2))
+VIT_EXPORT size_t vit_split_weight_bytes(int rows, int cols) { return (size_t)rows * (size_t)cols * 6 + 256; }
 
 VIT_EXPORT int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
 {
@@ -109,6 +112,8 @@ VIT_EXPORT int vit_adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr
 }
 VIT_EXPORT int vit_x6_set_products(int n) { return vit::x6_set_products(n); }
 VIT_EXPORT int vit_x6_products(void) { return vit::x6_products(); }
+VIT_EXPORT int vit_x6_set_operand_amax(const void *a, const void *b) { return vit::x6_set_operand_amax(a, b); }
+VIT_EXPORT int vit_amax(const float *x, int64_t n, void *out_word, void *stream) { return vit::amax(x, n, out_word, static_cast<hipStream_t>(stream)); }
 
 VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose)
 {

@@ -34,6 +34,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace x6 {
 constexpr int BM = 128, BK = 16, ROWQ = 6;   // LDS row = 6 x 16-B slots (2 k-groups x 3 pieces), no padding
@@ -110,15 +112,95 @@ __device__ inline void split8(const float4 &lo, const float4 &hi, uint4 &q0, uin
     split2(hi.z, hi.w, q0.w, q1.w, q2.w);
 }
 
+// ---- "f16x3" (NPROD == 2): two fp16 pieces per fp32 value, three products on v_mfma_f32_32x32x16_f16 -------------------------------
+// An fp32 value scaled by a power of two splits into two fp16 pieces, a s = h + l + O(2^-22 |a s|) (h = round-to-nearest fp16, 11-bit
+// significand; l = fp16 of the exact residual), and h h' + (h l' + l h') reproduces the product to 2^-22 -- 64 x tighter than the three
+// bf16 products of "bf16x3" (2^-16) at the SAME three MFMAs per k-step and the same two-piece data path.  What fp16 lacks is range
+// (2^-24 .. 65 504), so every operand TENSOR carries a power-of-two scale taken from its own absolute maximum (`k_amax`, an exact integer
+// max over the fp32 bit patterns): 2^14 <= amax s < 2^15.  Elements down to 2^-17 amax keep all 22 bits, smaller ones an absolute error of
+// 2^-39 amax -- below the fp32 rounding of any sum they enter.  Scales are powers of two, so scaling and un-scaling are exact; the epilogue
+// multiplies the fp32 accumulator by the two inverse scales.
+__device__ inline float f16_scale(uint32_t amax_bits)
+{
+    const int e = (int)((amax_bits >> 23) & 0xff);
+    if (e == 0 || e == 255) return 1.f;        // all-zero / denormal tensor; Inf / NaN inside (those propagate on their own)
+    const int se = min(max(127 + 14 - (e - 127), 27), 227);       // s in [2^-100, 2^100]
+    return __builtin_bit_cast(float, (uint32_t)se << 23);
+}
+
+// two (scaled) fp32 values -> their two fp16 pieces, each packed (lo = first value)
+__device__ inline void split2h(float a, float b, uint32_t &p0, uint32_t &p1)
+{
+    f32x2 f = {a, b};
+    const f16x2 h = __builtin_convertvector(f, f16x2);
+    const f32x2 r = f - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    p0 = __builtin_bit_cast(uint32_t, h); p1 = __builtin_bit_cast(uint32_t, l);
+}
+
+// NPROD == 6 / 3: three bf16 pieces (the third unused by 3); NPROD == 2: two fp16 pieces of s * value (q2 is left alone)
+template <int NPROD> __device__ inline void split8s(const float4 &lo, const float4 &hi, float s, uint4 &q0, uint4 &q1, uint4 &q2)
+{
+    if (NPROD == 2) {
+        split2h(lo.x * s, lo.y * s, q0.x, q1.x);
+        split2h(lo.z * s, lo.w * s, q0.y, q1.y);
+        split2h(hi.x * s, hi.y * s, q0.z, q1.z);
+        split2h(hi.z * s, hi.w * s, q0.w, q1.w);
+    } else {
+        split8(lo, hi, q0, q1, q2);
+    }
+}
+
+template <int NPROD> __device__ inline f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f32x16 &c)
+{
+    if (NPROD == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// absolute maximum of a tensor as the bit pattern of |x| (monotone for non-negative floats; a NaN wins, so it stays visible): one
+// atomicMax per workgroup into a pre-zeroed word
+__global__ void __launch_bounds__(256) k_amax(const float *__restrict__ x, int64_t n, uint32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    uint32_t m = 0;
+    auto fold = [&](const uint4 &v) { m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu)); };
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+        const int64_t n4 = n >> 2;
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per lane
+            const uint4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+            fold(v0); fold(v1); fold(v2); fold(v3);
+        }
+        for (; i < n4; i += stride) fold(x4[i]);
+        for (int64_t j = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = max(m, __builtin_bit_cast(uint32_t, x[j]) & 0x7fffffffu);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = max(m, __builtin_bit_cast(uint32_t, x[i]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bm = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (bm) atomicMax(out, bm);
+    }
+}
+
 // SPLITK: gridDim.y workgroups share one output tile, each contracting its own range of K slabs and adding its partial
 // sums into a pre-zeroed `out` with fp32 atomics (bias / residual enter through split 0; no activation).  Used when the
 // tile count alone cannot fill the chip: the 257..514-row GEMMs of batch-1 inference give 48-160 tiles for 256 CUs.
 template <int ACT, int TN, bool SPLITK, int NPROD>
 __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                       const float *__restrict__ bias, const float *__restrict__ residual,
-                                                      float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+                                                      float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
+                                                      const uint32_t *__restrict__ amax_x, const uint32_t *__restrict__ amax_w)
 {
     constexpr int BN = 64 * TN;
+    // f16x3: scale of the activation tensor (applied while it is split) and the two inverse scales of the epilogue
+    float sx = 1.f, ix = 1.f, iw = 1.f;
+    if (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
     // (the 64-row B tile is allocated at the 128-row size: keeps the narrow variant at three workgroups per CU; four
     // thrash the L2 on the N = 1024 layers: measured -5 %)
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][128 * ROWQ];
@@ -148,7 +230,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     const uint4 *wb = wp + ((int64_t)min(n0 + brow, N - 1) * KG + bkg) * 3;
     // two register stages: the global loads of slab k+2 are in flight while slab k feeds the MFMAs (one slab of MFMA work,
     // ~0.35 us, is shorter than the L2/HBM latency, so a single stage leaves the wave waiting at every LDS store)
-#define X6_SPLIT8(lo, hi, q0, q1, q2) split8(lo, hi, q0, q1, q2)
+#define X6_SPLIT8(lo, hi, q0, q1, q2) split8s<NPROD>(lo, hi, sx, q0, q1, q2)
     struct Stage { float4 a0, a1; uint4 b0, b1, b2; };
     Stage st0, st1;
     st0.b0 = st0.b1 = st0.b2 = st1.b0 = st1.b1 = st1.b2 = make_uint4(0, 0, 0, 0);
@@ -196,13 +278,13 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
             for (int j = 0; j < TN; ++j) {
                 f32x16 c = acc[i][j];
                 if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                    c = mma<NPROD>(fa[i][2], fb[j][0], c);
+                    c = mma<NPROD>(fa[i][1], fb[j][1], c);
+                    c = mma<NPROD>(fa[i][0], fb[j][2], c);
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                c = mma<NPROD>(fa[i][1], fb[j][0], c);
+                c = mma<NPROD>(fa[i][0], fb[j][1], c);
+                c = mma<NPROD>(fa[i][0], fb[j][0], c);
                 acc[i][j] = c;
             }
     };
@@ -251,7 +333,9 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
                 const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
-                float t = acc[i][j][r] + bv;
+                float t = acc[i][j][r];
+                if (NPROD == 2) t = t * ix * iw;
+                t += bv;
                 if (SPLITK) {
                     if (residual && first) t += residual[o];
                     atomicAdd(out + o, t);
@@ -280,9 +364,11 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
 template <int NPROD>
 __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ x,
                                                      float *__restrict__ dw, float *__restrict__ dbias, int M, int N, int K,
-                                                     int accumulate)
+                                                     int accumulate, const uint32_t *__restrict__ amax_dy, const uint32_t *__restrict__ amax_x)
 {
     constexpr int TN = 2, BN = 128;
+    float sa = 1.f, sb = 1.f, ia = 1.f, ib = 1.f;          // f16x3: tensor scales of dY and X, their inverses for the epilogue
+    if (NPROD == 2) { sa = f16_scale(*amax_dy); sb = f16_scale(*amax_x); ia = 1.f / sa; ib = 1.f / sb; }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -328,10 +414,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
             _Pragma("unroll") for (int r = 0; r < 8; ++r) bsum = fmaf(keep_, S_.a[r], bsum);                           \
         }                                                                                                             \
         uint4 q0_, q1_, q2_;                                                                                          \
-        split8(make_float4(S_.a[0], S_.a[1], S_.a[2], S_.a[3]), make_float4(S_.a[4], S_.a[5], S_.a[6], S_.a[7]), q0_, q1_, q2_); \
+        split8s<NPROD>(make_float4(S_.a[0], S_.a[1], S_.a[2], S_.a[3]), make_float4(S_.a[4], S_.a[5], S_.a[6], S_.a[7]), sa, q0_, q1_, q2_); \
         uint4 *p_ = sA[buf] + c * ROWQ;                                                                               \
         p_[swz_t(c, g * 3 + 0)] = q0_; p_[swz_t(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz_t(c, g * 3 + 2)] = q2_;                        \
-        split8(make_float4(S_.b[0], S_.b[1], S_.b[2], S_.b[3]), make_float4(S_.b[4], S_.b[5], S_.b[6], S_.b[7]), q0_, q1_, q2_); \
+        split8s<NPROD>(make_float4(S_.b[0], S_.b[1], S_.b[2], S_.b[3]), make_float4(S_.b[4], S_.b[5], S_.b[6], S_.b[7]), sb, q0_, q1_, q2_); \
         p_ = sB[buf] + c * ROWQ;                                                                                      \
         p_[swz_t(c, g * 3 + 0)] = q0_; p_[swz_t(c, g * 3 + 1)] = q1_; if (NPROD == 6) p_[swz_t(c, g * 3 + 2)] = q2_;                        \
     } while (0)
@@ -359,13 +445,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
                 if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                    cc = mma<NPROD>(fa[i][2], fb[j][0], cc);
+                    cc = mma<NPROD>(fa[i][1], fb[j][1], cc);
+                    cc = mma<NPROD>(fa[i][0], fb[j][2], cc);
                 }
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                cc = mma<NPROD>(fa[i][1], fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][1], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][0], cc);
                 acc[i][j] = cc;
             }
     };
@@ -423,9 +509,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
                 const int n = n0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (n >= N) continue;
                 float *o = dw + (int64_t)n * K + k;
-                if (!single) atomicAdd(o, acc[i][j][r]);
-                else if (accumulate) *o += acc[i][j][r];     // one workgroup owns the tile: plain read-add-write
-                else *o = acc[i][j][r];
+                const float t = NPROD == 2 ? acc[i][j][r] * ia * ib : acc[i][j][r];
+                if (!single) atomicAdd(o, t);
+                else if (accumulate) *o += t;     // one workgroup owns the tile: plain read-add-write
+                else *o = t;
             }
         }
     }
@@ -451,9 +538,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
 template <int KS, bool RELU_IN, int NPROD>
 __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in, const uint4 *__restrict__ wp,
                                                     const float *__restrict__ bias, const float *__restrict__ residual,
-                                                    float *__restrict__ out, int B, int Ci, int Co, int H, int W, int gate)
+                                                    float *__restrict__ out, int B, int Ci, int Co, int H, int W, int gate,
+                                                    const uint32_t *__restrict__ amax_w, const uint32_t *__restrict__ amax_in)
 {
     constexpr int TN = 2, BN = 128, TAPS = KS * KS;
+    float sb = 1.f, ia = 1.f, ib = 1.f;                     // f16x3: activation scale (rides in the border mask), inverse scales
+    if (NPROD == 2) { sb = f16_scale(*amax_in); ib = 1.f / sb; ia = 1.f / f16_scale(*amax_w); }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -494,7 +584,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
         const int tap = sl_ / spt, ci = (sl_ - tap * spt) * BK;                                                       \
         const int ky_ = KS == 3 ? (tap * 11) >> 5 : 0, kx_ = KS == 3 ? tap - 3 * ky_ : 0;                             \
         const int ys = py + (KS == 3 ? ky_ - 1 : 0), xs = px + (KS == 3 ? kx_ - 1 : 0);                               \
-        m_##T = (ys >= 0 && ys < H && xs >= 0 && xs < W) ? 1.f : 0.f;                                                 \
+        m_##T = (ys >= 0 && ys < H && xs >= 0 && xs < W) ? sb : 0.f;                                                  \
         const float *s_ = in_g + (int64_t)ci * HW64 + (min(max(ys, 0), H - 1) * W + min(max(xs, 0), W - 1));         \
         b0_##T = s_[0]; b1_##T = s_[HW64]; b2_##T = s_[2 * HW64]; b3_##T = s_[3 * HW64];                              \
         b4_##T = s_[4 * HW64]; b5_##T = s_[5 * HW64]; b6_##T = s_[6 * HW64]; b7_##T = s_[7 * HW64];                   \
@@ -505,9 +595,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
         pa_[swz(lrow, kg * 3 + 0)] = a0_##T; pa_[swz(lrow, kg * 3 + 1)] = a1_##T; if (NPROD == 6) pa_[swz(lrow, kg * 3 + 2)] = a2_##T; \
         const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = m_##T;   /* border taps contribute zero (clamped loads) */    \
         uint4 q0_, q1_, q2_;                                                                                          \
-        split8(make_float4(fmaxf(b0_##T, lo_) * mm_, fmaxf(b1_##T, lo_) * mm_, fmaxf(b2_##T, lo_) * mm_, fmaxf(b3_##T, lo_) * mm_), \
+        split8s<NPROD>(make_float4(fmaxf(b0_##T, lo_) * mm_, fmaxf(b1_##T, lo_) * mm_, fmaxf(b2_##T, lo_) * mm_, fmaxf(b3_##T, lo_) * mm_), \
                make_float4(fmaxf(b4_##T, lo_) * mm_, fmaxf(b5_##T, lo_) * mm_, fmaxf(b6_##T, lo_) * mm_, fmaxf(b7_##T, lo_) * mm_), \
-               q0_, q1_, q2_);                                                                                        \
+               1.f, q0_, q1_, q2_);                                                                                   \
         uint4 *pb_ = sB[buf] + c * ROWQ;                                                                              \
         pb_[swz(c, g * 3 + 0)] = q0_; pb_[swz(c, g * 3 + 1)] = q1_; if (NPROD == 6) pb_[swz(c, g * 3 + 2)] = q2_;                     \
     } while (0)
@@ -535,13 +625,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
                 if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                    cc = mma<NPROD>(fa[i][2], fb[j][0], cc);
+                    cc = mma<NPROD>(fa[i][1], fb[j][1], cc);
+                    cc = mma<NPROD>(fa[i][0], fb[j][2], cc);
                 }
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                cc = mma<NPROD>(fa[i][1], fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][1], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][0], cc);
                 acc[i][j] = cc;
             }
     };
@@ -581,7 +671,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
                 if (co >= Co) continue;
                 const int64_t o = obase + (int64_t)co * HW;
                 const bool first = blockIdx.y == 0;
-                float t = acc[i][j][r] + ((bias && first) ? bias[co] : 0.f);
+                float t = (NPROD == 2 ? acc[i][j][r] * ia * ib : acc[i][j][r]) + ((bias && first) ? bias[co] : 0.f);
                 // gate: `residual` is the forward input of a ReLU-fused convolution and this launch computes its input
                 // gradient: dX = (x > 0) ? conv^T(dY) : 0 (every K split gates its own partial sum)
                 if (residual) { const float rv = residual[o]; if (gate) t = rv > 0.f ? t : 0.f; else if (first) t += rv; }
@@ -602,9 +692,12 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16-by
 template <int KS, bool RELU_IN, int NPROD>
 __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restrict__ dy, const float *__restrict__ in,
                                                           float *__restrict__ dw, float *__restrict__ dbias, int B, int Ci,
-                                                          int Co, int H, int W)
+                                                          int Co, int H, int W, const uint32_t *__restrict__ amax_dy,
+                                                          const uint32_t *__restrict__ amax_in)
 {
     constexpr int TN = 2, BN = 128, TAPS = KS * KS;
+    float sa = 1.f, sb = 1.f, ia = 1.f, ib = 1.f;          // f16x3: tensor scales of dY and the input (the latter rides in the row mask)
+    if (NPROD == 2) { sa = f16_scale(*amax_dy); sb = f16_scale(*amax_in); ia = 1.f / sa; ib = 1.f / sb; }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -638,7 +731,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
         const float *pa_ = dy + ((int64_t)b_ * Co + co) * HW + q_;                                                    \
         a0_##T = *reinterpret_cast<const float4 *>(pa_); a1_##T = *reinterpret_cast<const float4 *>(pa_ + 4);         \
         const int y_ = q_ / W, xx_ = q_ - y_ * W;                                                                     \
-        my_##T = (y_ + ky >= 0 && y_ + ky < H) ? 1.f : 0.f;                                                           \
+        my_##T = (y_ + ky >= 0 && y_ + ky < H) ? sb : 0.f;                                                            \
         x0_##T = xx_ + kx;                                                                                            \
         int64_t o_ = ((int64_t)b_ * Ci + ci) * HW + q_ + ky * W + kx;                                                 \
         /* the +-1 tap shift can start one element before / end one element after the tensor: load the clamped run and  \
@@ -658,14 +751,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
         const float4 va1 = make_float4(a1_##T.x * live_, a1_##T.y * live_, a1_##T.z * live_, a1_##T.w * live_);       \
         bsum += (va0.x + va0.y) + (va0.z + va0.w) + (va1.x + va1.y) + (va1.z + va1.w);                                 \
         uint4 q0_, q1_, q2_;                                                                                          \
-        split8(va0, va1, q0_, q1_, q2_);                                                                              \
+        split8s<NPROD>(va0, va1, sa, q0_, q1_, q2_);                                                                  \
         uint4 *pa2_ = sA[buf] + lrow * ROWQ;                                                                          \
         pa2_[swz(lrow, kg * 3 + 0)] = q0_; pa2_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pa2_[swz(lrow, kg * 3 + 2)] = q2_;      \
         const float lo_ = RELU_IN ? 0.f : -3.0e38f, mm_ = my_##T;                                                     \
         const float m0_ = (x0_##T >= 0) ? mm_ : 0.f, m7_ = (x0_##T + 7 < W) ? mm_ : 0.f;   /* only the ends can leave the row */ \
-        split8(make_float4(fmaxf(b0_##T.x, lo_) * m0_, fmaxf(b0_##T.y, lo_) * mm_, fmaxf(b0_##T.z, lo_) * mm_, fmaxf(b0_##T.w, lo_) * mm_), \
+        split8s<NPROD>(make_float4(fmaxf(b0_##T.x, lo_) * m0_, fmaxf(b0_##T.y, lo_) * mm_, fmaxf(b0_##T.z, lo_) * mm_, fmaxf(b0_##T.w, lo_) * mm_), \
                make_float4(fmaxf(b1_##T.x, lo_) * mm_, fmaxf(b1_##T.y, lo_) * mm_, fmaxf(b1_##T.z, lo_) * mm_, fmaxf(b1_##T.w, lo_) * m7_), \
-               q0_, q1_, q2_);                                                                                        \
+               1.f, q0_, q1_, q2_);                                                                                   \
         uint4 *pb2_ = sB[buf] + lrow * ROWQ;                                                                          \
         pb2_[swz(lrow, kg * 3 + 0)] = q0_; pb2_[swz(lrow, kg * 3 + 1)] = q1_; if (NPROD == 6) pb2_[swz(lrow, kg * 3 + 2)] = q2_;      \
     } while (0)
@@ -693,13 +786,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
             for (int j = 0; j < TN; ++j) {
                 f32x16 cc = acc[i][j];
                 if (NPROD == 6) {   // the three 2^-16-level products; NPROD == 3 ("bf16x3") leaves them out
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], cc, 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], cc, 0, 0, 0);
+                    cc = mma<NPROD>(fa[i][2], fb[j][0], cc);
+                    cc = mma<NPROD>(fa[i][1], fb[j][1], cc);
+                    cc = mma<NPROD>(fa[i][0], fb[j][2], cc);
                 }
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], cc, 0, 0, 0);
-                cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], cc, 0, 0, 0);
+                cc = mma<NPROD>(fa[i][1], fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][1], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][0], cc);
                 acc[i][j] = cc;
             }
     };
@@ -739,7 +832,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
             for (int q = 0; q < 16; ++q) {
                 const int co_ = co0 + wm * 64 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * half;
                 if (co_ >= Co) continue;
-                atomicAdd(o + (int64_t)co_ * Ci * TAPS, acc[i][j][q]);
+                atomicAdd(o + (int64_t)co_ * Ci * TAPS, NPROD == 2 ? acc[i][j][q] * ia * ib : acc[i][j][q]);
             }
         }
     }
@@ -749,19 +842,25 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
 // w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
 // transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
 // reads and the writes stay coalesced).
-__global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ w, uint4 *__restrict__ packed, int64_t groups)
+// NPROD == 2 ("f16x3"): two fp16 pieces of w * f16_scale(*amax) in slots 0 / 1 (slot 2 is never read in that mode)
+template <int NPROD>
+__global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ w, uint4 *__restrict__ packed, int64_t groups,
+                                                    const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-wide k group per thread
+    if (NPROD == 2 && g == 0) *tail = *amax;                            // the scale the kernels that read this image must undo
     if (g >= groups) return;
     const float4 lo = reinterpret_cast<const float4 *>(w)[g * 2], hi = reinterpret_cast<const float4 *>(w)[g * 2 + 1];
-    uint4 q0, q1, q2;
-    split8(lo, hi, q0, q1, q2);
-    packed[g * 3 + 0] = q0; packed[g * 3 + 1] = q1; packed[g * 3 + 2] = q2;
+    uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
+    split8s<NPROD>(lo, hi, NPROD == 2 ? f16_scale(*amax) : 1.f, q0, q1, q2);
+    packed[g * 3 + 0] = q0; packed[g * 3 + 1] = q1; if (NPROD != 2) packed[g * 3 + 2] = q2;
 }
 
+template <int NPROD>
 __global__ void __launch_bounds__(256) k_split_transposed(const float *__restrict__ w, uint4 *__restrict__ packed, int rows,
-                                                          int cols)
+                                                          int cols, const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tail = *amax;
     // tile: 64 source rows (-> k of the output) x 32 source columns (-> output rows)
     __shared__ float s[64][33];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
@@ -774,10 +873,10 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
     if (c0 + c >= cols || r0 + kg * 8 >= rows) return;
     float4 lo = make_float4(s[kg * 8 + 0][c], s[kg * 8 + 1][c], s[kg * 8 + 2][c], s[kg * 8 + 3][c]);
     float4 hi = make_float4(s[kg * 8 + 4][c], s[kg * 8 + 5][c], s[kg * 8 + 6][c], s[kg * 8 + 7][c]);
-    uint4 q0, q1, q2;
-    split8(lo, hi, q0, q1, q2);
+    uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
+    split8s<NPROD>(lo, hi, NPROD == 2 ? f16_scale(*amax) : 1.f, q0, q1, q2);
     uint4 *o = packed + ((int64_t)(c0 + c) * (rows >> 3) + (r0 >> 3) + kg) * 3;
-    o[0] = q0; o[1] = q1; o[2] = q2;
+    o[0] = q0; o[1] = q1; if (NPROD != 2) o[2] = q2;
 }
 }  // namespace x6
 
@@ -785,14 +884,42 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
 // good to 2^-18 -- ~3.5e-6 of the output scale per GEMM, two orders tighter than the TF32 the reference enables, croco.py:13).
 // Per HOST THREAD (thread_local) and read at launch time on the launching thread: a thread's set + launch pair cannot be
 // interleaved with another thread's choice (a serving thread in bf16x3 beside a training thread in bf16x6).
+// n == 2 selects "f16x3": TWO fp16 pieces per operand and the same three products on v_mfma_f32_32x32x16_f16 -- 2^-22 instead of 2^-16
+// per product at the price of bf16x3; every operand tensor then needs its absolute maximum (vit_amax + vit_x6_set_operand_amax for
+// activations; the weight's rides behind its packed image, see split_weight).
 static thread_local int g_x6_products = 6;
+static thread_local const uint32_t *g_amax_a = nullptr, *g_amax_b = nullptr;
 int x6_set_products(int n)
 {
-    if (n != 3 && n != 6) return VIT_EINVAL;
+    if (n != 2 && n != 3 && n != 6) return VIT_EINVAL;
     g_x6_products = n;
     return VIT_OK;
 }
 int x6_products() { return g_x6_products; }
+// Device addresses of the |max| words (k_amax) of the ACTIVATION operands of the NEXT x6 launch on this host thread: a = x (Linear / conv
+// forward and input-gradient launches), or a = dY, b = x (weight-gradient launches).  Consumed by that launch.
+int x6_set_operand_amax(const void *a, const void *b)
+{
+    g_amax_a = static_cast<const uint32_t *>(a); g_amax_b = static_cast<const uint32_t *>(b);
+    return VIT_OK;
+}
+static void take_amax(const uint32_t *&a, const uint32_t *&b) { a = g_amax_a; b = g_amax_b; g_amax_a = g_amax_b = nullptr; }
+// the weight's |max| word lives right behind its rows x cols x 6 bytes of pieces (vit_split_weight_bytes leaves room)
+static const uint32_t *weight_amax(const void *packed, int rows, int cols)
+{
+    return reinterpret_cast<const uint32_t *>(static_cast<const char *>(packed) + (size_t)rows * (size_t)cols * 6);
+}
+static bool zero_fill(void *p, size_t bytes, hipStream_t stream);
+int amax(const float *x, int64_t n, void *out, hipStream_t stream)     // *out must be zero before the launch
+{
+    if (!x || !out || n <= 0) return VIT_EINVAL;
+    (void)hipGetLastError();
+    const int64_t blocks = (n / 16 + 255) / 256;            // ~four 16-byte loads per lane; 2048 workgroups = 8 per CU at most
+    hipLaunchKernelGGL(x6::k_amax, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))), dim3(256), 0, stream, x, n, static_cast<uint32_t *>(out));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
 
 // number of contraction splits for the weight-gradient kernels (2 resident workgroups per CU): one full round of 512
 // workgroups when the tiles alone are fewer, otherwise whole multiples are left to the tile count; >= min_slabs per split
@@ -817,13 +944,25 @@ int split_weight(const float *w, void *packed, int rows, int cols, int transpose
     if (!w || !packed || rows <= 0 || cols <= 0) return VIT_EINVAL;
     if ((transpose ? rows : cols) % 8 != 0) return VIT_EINVAL;
     (void)hipGetLastError();
+    const bool f16 = x6_products() == 2;
+    uint32_t *tail = const_cast<uint32_t *>(weight_amax(packed, rows, cols));
+    // f16x3: the weight's own scale.  The caller may announce the weight's |max| word (vit_x6_set_operand_amax(word, NULL): one vit_amax pass
+    // then serves both images of a weight, forward and transposed); otherwise it is computed here into the word behind the pieces
+    const uint32_t *am, *unused;
+    take_amax(am, unused);
+    if (f16 && !am) {
+        if (!zero_fill(tail, 4, stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        const int rc = amax(w, (int64_t)rows * cols, tail, stream);
+        if (rc != VIT_OK) return rc;
+        am = tail;
+    }
     if (!transpose) {
         const int64_t groups = (int64_t)rows * cols / 8;
-        hipLaunchKernelGGL(x6::k_split_rows, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, w,
-                           static_cast<uint4 *>(packed), groups);
+        if (f16) hipLaunchKernelGGL(x6::k_split_rows<2>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), groups, am, tail);
+        else hipLaunchKernelGGL(x6::k_split_rows<6>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), groups, am, tail);
     } else {
-        hipLaunchKernelGGL(x6::k_split_transposed, dim3((cols + 31) / 32, (rows + 63) / 64), dim3(256), 0, stream, w,
-                           static_cast<uint4 *>(packed), rows, cols);
+        if (f16) hipLaunchKernelGGL(x6::k_split_transposed<2>, dim3((cols + 31) / 32, (rows + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), rows, cols, am, tail);
+        else hipLaunchKernelGGL(x6::k_split_transposed<6>, dim3((cols + 31) / 32, (rows + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), rows, cols, am, tail);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
@@ -849,7 +988,10 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     const bool narrow = tm * ((N + 127) / 128) < 640;
     const int tiles = tm * (narrow ? (N + 63) / 64 : (N + 127) / 128);
     const uint4 *w4 = static_cast<const uint4 *>(wp);
-    const bool three = x6_products() == 3;
+    const int np = x6_products();
+    const uint32_t *am_x, *am_unused, *am_w = weight_amax(wp, N, K);
+    take_amax(am_x, am_unused);
+    if (np == 2 && !am_x) return VIT_EINVAL;      // f16x3 without the activation's |max|: refuse, never guess a scale
     (void)hipGetLastError();
     // split-K when the tiles cannot fill the 256 CUs x 3 resident workgroups: S = 2 / 4 / 8 ranges of >= 8 slabs each
     int S = 1;
@@ -859,15 +1001,17 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     }
     if (S > 1) {
         if (!zero_fill(out, (size_t)M * N * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-#define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K)
-        if (three) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
+#define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w)
+        if (np == 3) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
+        else if (np == 2) { if (narrow) VIT_LAUNCH_X6S(1, 2); else VIT_LAUNCH_X6S(2, 2); }
         else { if (narrow) VIT_LAUNCH_X6S(1, 6); else VIT_LAUNCH_X6S(2, 6); }
 #undef VIT_LAUNCH_X6S
     } else {
 #define VIT_LAUNCH_X6(ACT, TN)                                                                                                                          \
     do {                                                                                                                                                \
-        if (three) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 3>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K); \
-        else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K);      \
+        if (np == 3) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 3>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w); \
+        else if (np == 2) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 2>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w); \
+        else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w);      \
     } while (0)
         if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
         else if (act == 2) { if (narrow) VIT_LAUNCH_X6(2, 1); else VIT_LAUNCH_X6(2, 2); }
@@ -909,7 +1053,11 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
     const int tiles = ((N + x6::BM - 1) / x6::BM) * ((K + 127) / 128);
     const int nslab = (M + x6::BK - 1) / x6::BK;
     // split M so that tiles x S fills the 512 resident workgroups (256 CUs x 2) ONCE: 1.1 rounds cost as much as 2
-    int S = wgrad_splits(tiles, nslab, x6_products());
+    const int np = x6_products();
+    const uint32_t *am_dy, *am_x;
+    take_amax(am_dy, am_x);
+    if (np == 2 && (!am_dy || !am_x)) return VIT_EINVAL;
+    int S = wgrad_splits(tiles, nslab, np == 6 ? 6 : 3);
     { static const char *force = getenv("VIT_WGRAD_S"); if (force) S = atoi(force); }   // (tools/probes/wgrad_lab.py sweeps)
     // the kernel addresses a split's rows with 32-bit byte offsets from the split's first row (+ 4 slabs of prefetch)
     while (((int64_t)(nslab / S) + 6) * x6::BK * (int64_t)(N > K ? N : K) * 4 >= 0x7fffffffLL && S < 65535) ++S;
@@ -921,8 +1069,9 @@ int linear_x6_wgrad(const float *dy, const float *x, float *dw, float *dbias, in
         if (S > 1 && hipMemsetAsync(dw, 0, ((size_t)N * K + (joined ? N : 0)) * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
         if (dbias && !(S > 1 && joined) && hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     }
-    if (x6_products() == 3) hipLaunchKernelGGL(x6::k_wgrad_x6<3>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
-    else hipLaunchKernelGGL(x6::k_wgrad_x6<6>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate);
+    if (np == 3) hipLaunchKernelGGL(x6::k_wgrad_x6<3>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate, am_dy, am_x);
+    else if (np == 2) hipLaunchKernelGGL(x6::k_wgrad_x6<2>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate, am_dy, am_x);
+    else hipLaunchKernelGGL(x6::k_wgrad_x6<6>, dim3(tiles, S), dim3(256), 0, stream, dy, x, dw, dbias, M, N, K, accumulate, am_dy, am_x);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
@@ -938,7 +1087,10 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     const int64_t tiles = (int64_t)((Co + x6::BM - 1) / x6::BM) * ((NP + 127) / 128);
     if (tiles > 0x7fffffff) return VIT_EINVAL;
     const uint4 *w4 = static_cast<const uint4 *>(wp);
-    const bool three = x6_products() == 3;
+    const int np = x6_products();
+    const uint32_t *am_in, *am_unused, *am_w = weight_amax(wp, Co, ksize * ksize * Ci);
+    take_amax(am_in, am_unused);
+    if (np == 2 && !am_in) return VIT_EINVAL;
     (void)hipGetLastError();
     // few output tiles: split the K slabs so that tiles x S fills the 512 resident workgroups, >= 8 slabs per split
     int S = 1;
@@ -947,8 +1099,9 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     if (S > 1 && !zero_fill(out, (size_t)NP * Co * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
 #define VIT_LAUNCH_C6(KS, RL)                                                                                                                                   \
     do {                                                                                                                                                        \
-        if (three) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 3>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate); \
-        else hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 6>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate);      \
+        if (np == 3) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 3>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in); \
+        else if (np == 2) hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 2>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in); \
+        else hipLaunchKernelGGL((x6::k_conv_x6<KS, RL, 6>), dim3((unsigned)tiles, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in);      \
     } while (0)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_C6(3, true); else VIT_LAUNCH_C6(3, false); }
     else { if (relu_in) VIT_LAUNCH_C6(1, true); else VIT_LAUNCH_C6(1, false); }
@@ -966,14 +1119,18 @@ int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int
     const int tiles = ((Co + x6::BM - 1) / x6::BM) * ((R + 127) / 128);
     const int nslab = B * (H * W / x6::BK);
     int S = split_count(tiles, nslab, 32);   // (r03: 8 / 4 slabs per split measured slower at every DPT shape -- more atomic passes over the tile)
-    const bool three = x6_products() == 3;
+    const int np = x6_products();
+    const uint32_t *am_dy, *am_in;
+    take_amax(am_dy, am_in);
+    if (np == 2 && (!am_dy || !am_in)) return VIT_EINVAL;
     (void)hipGetLastError();
     if (hipMemsetAsync(dw, 0, (size_t)Co * R * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
     if (dbias && hipMemsetAsync(dbias, 0, (size_t)Co * sizeof(float), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
 #define VIT_LAUNCH_G6(KS, RL)                                                                                                                          \
     do {                                                                                                                                               \
-        if (three) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 3>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W);      \
-        else hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 6>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W);            \
+        if (np == 3) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 3>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W, am_dy, am_in);      \
+        else if (np == 2) hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 2>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W, am_dy, am_in);   \
+        else hipLaunchKernelGGL((x6::k_conv_wgrad_x6<KS, RL, 6>), dim3(tiles, S), dim3(256), 0, stream, dy, in, dw, dbias, B, Ci, Co, H, W, am_dy, am_in);            \
     } while (0)
     if (ksize == 3) { if (relu_in) VIT_LAUNCH_G6(3, true); else VIT_LAUNCH_G6(3, false); }
     else { if (relu_in) VIT_LAUNCH_G6(1, true); else VIT_LAUNCH_G6(1, false); }

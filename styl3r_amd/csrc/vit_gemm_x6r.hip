@@ -634,6 +634,7 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre || (cfg != 1 && cfg != 3))) ||
         !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split; act 2: see vit_linear_x6_fwd
     const uint4 *w4 = static_cast<const uint4 *>(wp);
+    if (x6_products() == 2) return VIT_EINVAL;      // f16x3 (two fp16 pieces + tensor scales) is served by vit_linear_x6_fwd
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
     const bool three = x6_products() == 3;
@@ -698,6 +699,7 @@ int linear_x6c_fwd(const float *x, const void *wp, const float *bias, const floa
     if (!x || !wp || !out) return VIT_EINVAL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 1 || splits < 1 || splits > 8 || K / x6r::BK < splits) return VIT_EINVAL;
     if (splits > 1 && (!workspace || workspace_bytes < x6c_workspace_bytes(M, N, splits))) return VIT_EINVAL;
+    if (x6_products() == 2) return VIT_EINVAL;
     const uint4 *w4 = static_cast<const uint4 *>(wp);
     const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
     float4 *slabs = static_cast<float4 *>(workspace);

@@ -39,7 +39,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -137,6 +137,10 @@ def load() -> C.CDLL:
     lib.vit_x6_set_products.restype = C.c_int
     lib.vit_x6_products.argtypes = []
     lib.vit_x6_products.restype = C.c_int
+    lib.vit_x6_set_operand_amax.argtypes = [vp, vp]
+    lib.vit_x6_set_operand_amax.restype = C.c_int
+    lib.vit_amax.argtypes = [vp, i64, vp, vp]
+    lib.vit_amax.restype = C.c_int
     lib.vit_split_weight_block_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.vit_split_weight_block_bytes.restype = C.c_size_t
     lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -304,7 +308,7 @@ def _attn_args(q, k, v, out, scale, rope):
 
 
 ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # attention contractions, forward and backward: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "bf16x3" (three of the six partial products) | "f32" (exact-f32 MFMA)
-_ATTN_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2}
+_ATTN_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "f16x3": 1}     # (the attention kernels have no fp16-split variant: "f16x3" runs their six-product form)
 
 
 def _sync_attention_arith(mode: Optional[str] = None) -> None:
@@ -312,7 +316,7 @@ def _sync_attention_arith(mode: Optional[str] = None) -> None:
     node's forward ran in when its backward calls this from the autograd engine thread"""
     mode = ATTENTION_ARITH if mode is None else mode
     if mode not in _ATTN_MODES:
-        raise ValueError(f"VIT_ATTENTION = {mode!r}: expected f32, bf16x6 or bf16x3")
+        raise ValueError(f"VIT_ATTENTION = {mode!r}: expected f32, bf16x6, bf16x3 or f16x3")
     want = _ATTN_MODES[mode]
     lib = load()
     if lib.vit_attention_arith() != want:
@@ -428,7 +432,12 @@ def memory_efficient_attention(q: Tensor, k: Tensor, v: Tensor, scale: Optional[
 #            with fp32 accumulation (417 TF peak-equivalent); forward and input-gradient GEMMs.  Default: its measured
 #            error against fp64 is equal to or below the f32 path's on every shape tested (split error 2^-27, dropped
 #            cross terms 3 * 2^-26 relative), at 1.5-1.7x the throughput
-LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")      # "bf16x6" (default) | "bf16x3" | "f32"
+#   "bf16x3" the three leading products only (operands good to 2^-16: the reference's TF32 class)
+#   "f16x3"  every operand split into TWO fp16 pieces of value x 2^k (k from the operand tensor's |max|), three products on
+#            v_mfma_f32_32x32x16_f16: 2^-22 per product at the MFMA count and data path of bf16x3 (csrc/vit_gemm_x6.hip).  Needs the
+#            |max| of every activation operand: one `vit_amax` pass per tensor (`_amax_word`), shared by the launches that read it
+LINEAR_MODE = os.environ.get("VIT_LINEAR_MODE", "bf16x6")      # "bf16x6" (default) | "bf16x3" | "f16x3" | "f32"
+_PRODUCTS = {"bf16x6": 6, "bf16x3": 3, "f16x3": 2}
 
 
 def _x6() -> bool:
@@ -436,9 +445,9 @@ def _x6() -> bool:
     LINEAR_MODE (a module global that tests and benchmarks flip at run time)."""
     if LINEAR_MODE == "f32":
         return False
-    if LINEAR_MODE not in ("bf16x6", "bf16x3"):
-        raise ValueError(f"VIT_LINEAR_MODE = {LINEAR_MODE!r}: expected bf16x6, bf16x3 or f32")
-    want = 3 if LINEAR_MODE == "bf16x3" else 6
+    if LINEAR_MODE not in _PRODUCTS:
+        raise ValueError(f"VIT_LINEAR_MODE = {LINEAR_MODE!r}: expected bf16x6, bf16x3, f16x3 or f32")
+    want = _PRODUCTS[LINEAR_MODE]
     lib = load()
     if lib.vit_x6_products() != want:
         _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
@@ -448,14 +457,70 @@ def _pin_products(mode: str) -> None:
     """libvit_hip.so keeps the products-per-launch per HOST THREAD (thread_local): autograd runs a node's backward on its own engine
     thread, so every backward re-states the mode its forward ran in before it launches anything (a step never mixes modes, whatever
     LINEAR_MODE has become in the meantime)."""
-    if mode in ("bf16x6", "bf16x3"):
-        want = 3 if mode == "bf16x3" else 6
+    if mode in _PRODUCTS:
+        want = _PRODUCTS[mode]
         lib = load()
         if lib.vit_x6_products() != want:
             _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
 
 
-_SPLIT_CACHE: dict = {}   # (id(weight), transposed) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
+_SPLIT_CACHE: dict = {}   # (id(weight), layout[, "f16"]) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
+
+
+def _f16() -> bool:
+    return LINEAR_MODE == "f16x3"
+
+
+class _AmaxArena:
+    """zero-initialised 32-bit words for vit_amax results (one per activation tensor per use): handed out in order from a device buffer
+    that is replaced -- one allocation + one fill -- when it runs out; words still referenced (saved for a backward) keep their buffer alive"""
+
+    def __init__(self, words: int = 8192):
+        self.words, self.buf, self.next = words, {}, {}
+
+    def word(self, dev) -> Tensor:
+        i = self.next.get(dev, self.words)
+        if i >= self.words:
+            self.buf[dev] = torch.zeros(self.words, dtype=torch.int32, device=dev)
+            i = 0
+        self.next[dev] = i + 1
+        return self.buf[dev][i:i + 1]
+
+
+_AMAX = _AmaxArena()
+
+
+def _amax_word(t: Tensor) -> Tensor:
+    """|max| of a contiguous fp32 device tensor as the bit pattern of a non-negative float in a 1-element int32 tensor (vit_amax)"""
+    w = _AMAX.word(t.device)
+    _check(load().vit_amax(t.data_ptr(), t.numel(), w.data_ptr(), _stream(t.device)), "vit_amax")
+    return w
+
+
+_WEIGHT_AMAX: dict = {}      # id(weight) -> (weakref, _version, data_ptr, |max| word): one vit_amax pass per weight and optimizer step
+
+
+def _weight_amax_word(weight: Tensor, values: Tensor) -> Tensor:
+    """|max| word of a parameter (`values`: the fp32 tensor whose elements are the parameter's -- any permutation of them), cached like
+    its split images: the forward, transposed and convolution images of one weight share it"""
+    key = id(weight)
+    hit = _WEIGHT_AMAX.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+
+    def drop(ref, key=key):
+        h = _WEIGHT_AMAX.get(key)
+        if h is not None and h[0] is ref:
+            del _WEIGHT_AMAX[key]
+    word = _amax_word(values)
+    _WEIGHT_AMAX[key] = (weakref.ref(weight, drop), weight._version, weight.data_ptr(), word)
+    return word
+
+
+def _announce(a: Optional[Tensor], b: Optional[Tensor] = None) -> None:
+    """f16x3: the |max| words of the activation operand(s) of the NEXT x6 launch on this thread (consumed by it)"""
+    _check(load().vit_x6_set_operand_amax(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None),
+           "vit_x6_set_operand_amax")
 
 
 def _dead_entry_ref(weight: Tensor, key):
@@ -472,6 +537,8 @@ def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
     multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
     key = (id(weight), "block_t" if transposed else "block")
+    if _f16():
+        raise RuntimeError("split_weight_block: the ring kernels have no f16x3 variant")
     hit = _SPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
@@ -507,7 +574,7 @@ def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     the parameter is modified in place (optimizer step, load_state_dict: both bump `_version`) or replaced.  The entry
     holds a weak reference: a new tensor that happens to reuse a dead one's id / address never hits it.  Writes through
     `weight.data` bypass the version counter -- call `invalidate_split_cache()` after such surgery."""
-    key = (id(weight), transposed)
+    key = (id(weight), transposed, "f16") if _f16() else (id(weight), transposed)    # (the f16x3 image differs: two fp16 pieces of the scaled weight)
     hit = _SPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
@@ -517,6 +584,8 @@ def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     nbytes = lib.vit_split_weight_bytes(N, K)
     reuse = hit is not None and hit[0]() is weight and hit[3].numel() == nbytes
     packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    if _f16():
+        _announce(_weight_amax_word(weight, w))
     _check(lib.vit_split_weight(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight")
     _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
@@ -527,7 +596,7 @@ def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
     """bf16x3 split of a conv weight (Co,Ci,k,k) rearranged for vit_conv_x6_fwd: (Co, k*k*Ci) with k index = tap*Ci + ci;
     `for_input_grad`: the spatially flipped, channel-transposed weight (Ci, k*k*Co) whose convolution with dY is dX.
     Cached like `split_weight` (weak reference + version counter of the ORIGINAL parameter)."""
-    key = (id(weight), "conv_dx" if for_input_grad else "conv")
+    key = (id(weight), "conv_dx" if for_input_grad else "conv") + (("f16",) if _f16() else ())
     hit = _SPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
@@ -540,13 +609,15 @@ def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
         w2 = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci).contiguous()
     R, Kc = w2.shape
     packed = torch.empty(lib.vit_split_weight_bytes(R, Kc), dtype=torch.uint8, device=weight.device)
+    if _f16():
+        _announce(_weight_amax_word(weight, w2))
     _check(lib.vit_split_weight(w2.data_ptr(), packed.data_ptr(), R, Kc, 0, _stream(weight.device)), "vit_split_weight")
     _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
     return packed
 
 
 def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-                    relu_in: bool = False, packed: Optional[Tensor] = None) -> Tensor:
+                    relu_in: bool = False, packed: Optional[Tensor] = None, amax: Optional[Tensor] = None) -> Tensor:
     """out = [residual +] bias + conv2d(relu?(x), weight, padding=k//2) on vit_conv_x6_fwd (no autograd)."""
     B, Ci, H, W = x.shape
     Co, _, k, _ = weight.shape
@@ -554,6 +625,8 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
     out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
     wp = packed if packed is not None else split_conv_weight(weight)
     res = residual.contiguous().float() if residual is not None else None
+    if _f16():
+        _announce(amax if amax is not None else _amax_word(x))      # (relu_in: |max| of x bounds |max| of relu(x))
     _check(load().vit_conv_x6_fwd(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                   res.data_ptr() if res is not None else None, out.data_ptr(), B, Ci, Co, H, W, k,
                                   1 if relu_in else 0, _stream(x.device)), "vit_conv_x6_fwd")
@@ -595,13 +668,16 @@ class _ConvX6(torch.autograd.Function):
         ctx.mode = LINEAR_MODE
         _pin_products(ctx.mode)
         CALLS["conv_x6_fwd"] += 1
-        return conv_x6_forward(x, weight, bias, residual, relu_in)
+        ctx.ax = _amax_word(x) if _f16() else None             # f16x3: the input's |max|, shared with the weight-gradient launch
+        return conv_x6_forward(x, weight, bias, residual, relu_in, amax=ctx.ax)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         _pin_products(ctx.mode)
         g = g.contiguous().float()
+        f16 = ctx.mode == "f16x3"
+        ag = _amax_word(g) if f16 else None                    # |max| of dY: one pass, read by the dX and the dW launch
         k = weight.shape[2]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_r = ctx.has_res and ctx.needs_input_grad[3]
@@ -620,7 +696,10 @@ class _ConvX6(torch.autograd.Function):
                 Ci = weight.shape[1]
                 dx = torch.empty((B, Ci, H, W), dtype=torch.float32, device=g.device)
                 CALLS["conv_x6_dx"] += 1
-                _check(load().vit_conv_x6_fwd(g.data_ptr(), split_conv_weight(weight, True).data_ptr(), None,
+                wpt = split_conv_weight(weight, True)
+                if f16:
+                    _announce(ag)
+                _check(load().vit_conv_x6_fwd(g.data_ptr(), wpt.data_ptr(), None,
                                               x.data_ptr() if ctx.relu_in else None, dx.data_ptr(),
                                               B, Co, Ci, H, W, k, 2 if ctx.relu_in else 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
             else:
@@ -636,6 +715,8 @@ class _ConvX6(torch.autograd.Function):
             dw = torch.empty_like(weight, dtype=torch.float32)
             db = torch.empty((weight.shape[0],), dtype=torch.float32, device=g.device) if need_b else None
             CALLS["conv_x6_wgrad"] += 1
+            if f16:
+                _announce(ag, ctx.ax)
             _check(load().vit_conv_x6_wgrad(g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr() if need_b else None,
                                             B_, weight.shape[1], weight.shape[0], H_, W_, k, 1 if ctx.relu_in else 0,
                                             _stream(g.device)), "vit_conv_x6_wgrad")
@@ -653,6 +734,8 @@ class _ConvX6(torch.autograd.Function):
             dwl = buf[:Co * 9 * Ci].view(Co, 9 * Ci)
             db = buf[Co * 9 * Ci:] if need_b else None
             CALLS["conv_wgrad_via_linear"] += 1
+            if f16:
+                _announce(ag, ctx.ax)                          # (gt is a copy of g; |cols| <= |x|)
             _check(load().vit_linear_x6_wgrad(gt.data_ptr(), cols.data_ptr(), dwl.data_ptr(), db.data_ptr() if need_b else None, P, Co, 9 * Ci,
                                               _stream(g.device)), "vit_linear_x6_wgrad (conv)")
             dw = dwl.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
@@ -924,6 +1007,7 @@ def gaussian_adapter_hip(pts0, ptsr, par0, parr, app, sh_mask, exponent: float, 
 
 def invalidate_split_cache() -> None:
     _SPLIT_CACHE.clear()
+    _WEIGHT_AMAX.clear()
 
 
 # (N, K) -> ring configuration of vit_linear_x6r_fwd for launches of M >= 4096 rows, per arithmetic mode (cfg 3: 256 x 256 tiles, one
@@ -975,13 +1059,18 @@ class _FusedLinear(torch.autograd.Function):
         args = (b.data_ptr() if b is not None else None, res2.data_ptr() if res2 is not None else None, out.data_ptr(),
                 pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
         ring = _ring_cfg(M, N, K) if x6 else 0
+        ctx.ax = None
         if ring:
             # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
             # tools/probes/gemm_lab.py measured them faster (per arithmetic mode: _RING_SHAPES)
             CALLS["linear_x6r"] += 1
             _check(load().vit_linear_x6r_fwd(x2.data_ptr(), split_weight_block(weight).data_ptr(), *args[:-1], ring, args[-1]), "vit_linear_x6r_fwd")
         elif x6:
-            _check(load().vit_linear_x6_fwd(x2.data_ptr(), split_weight(weight).data_ptr(), *args), "vit_linear_x6_fwd")
+            wp = split_weight(weight)
+            ctx.ax = _amax_word(x2) if _f16() else None        # f16x3: |max| of the input, shared with the weight-gradient launch
+            if ctx.ax is not None:
+                _announce(ctx.ax)
+            _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), *args), "vit_linear_x6_fwd")
         else:
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
         ctx.save_for_backward(x2, w, pre)
@@ -1010,6 +1099,14 @@ class _FusedLinear(torch.autograd.Function):
         if act == 1 and not (ctx.link is not None and ctx.link.fused):     # (fused: the layer behind already multiplied by GELU')
             g2 = torch.ops.aten.gelu_backward(g2.contiguous(), pre, approximate="none")
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        f16 = ctx.mode == "f16x3" and ctx.weight_ref is not None
+        ag = None                                              # f16x3: |max| of dY, one pass shared by the dX and the dW launch
+
+        def amax_g(t):
+            nonlocal ag
+            if ag is None:
+                ag = _amax_word(t)
+            return ag
         dx = None
         if need_x:
             N, K = w.shape
@@ -1026,7 +1123,10 @@ class _FusedLinear(torch.autograd.Function):
                                                      gelu_pre.data_ptr() if gelu_pre is not None else None, dx.data_ptr(), None,
                                                      g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, ring, _stream(g.device)), "vit_linear_x6r_fwd (dX)")
                 else:
-                    _check(load().vit_linear_x6_fwd(g2c.data_ptr(), split_weight(ctx.weight_ref, True).data_ptr(), None,
+                    wpt = split_weight(ctx.weight_ref, True)
+                    if f16:
+                        _announce(amax_g(g2c))
+                    _check(load().vit_linear_x6_fwd(g2c.data_ptr(), wpt.data_ptr(), None,
                                                     gelu_pre.data_ptr() if gelu_pre is not None else None,
                                                     dx.data_ptr(), None, g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, _stream(g.device)),
                            "vit_linear_x6_fwd (dX)")
@@ -1045,6 +1145,8 @@ class _FusedLinear(torch.autograd.Function):
             g2c = g2.contiguous().float()
             N, K = w.shape
             bslot = getattr(ctx.bias_ref, "_grad_slot", None) if (has_bias and need_b and ctx.bias_ref is not None) else None
+            if f16:
+                _announce(amax_g(g2c), ctx.ax)
             _check(load().vit_linear_x6_wgrad_acc(g2c.data_ptr(), x2.data_ptr(), wslot["view"].data_ptr(),
                                                   bslot["view"].data_ptr() if bslot is not None else None, g2c.shape[0], N, K,
                                                   _stream(g.device)), "vit_linear_x6_wgrad_acc")
@@ -1064,6 +1166,8 @@ class _FusedLinear(torch.autograd.Function):
             buf = torch.empty(N * K + (N if want_b else 0), dtype=torch.float32, device=g.device)   # db right behind dw: one memset
             dw = buf[:N * K].view(N, K)
             db = buf[N * K:] if want_b else None
+            if f16:
+                _announce(amax_g(g2c), ctx.ax)
             _check(load().vit_linear_x6_wgrad(g2c.data_ptr(), x2.data_ptr(), dw.data_ptr(), db.data_ptr() if want_b else None,
                                               g2c.shape[0], N, K, _stream(g.device)), "vit_linear_x6_wgrad")
         else:
@@ -1101,7 +1205,10 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
             res2 = residual.reshape(-1, N)
             if not res2.is_contiguous() or res2.dtype != torch.float32:
                 res2 = res2.contiguous().float()
-        _check(load().vit_linear_x6_fwd(x2.data_ptr(), split_weight(weight).data_ptr(), bias.data_ptr() if bias is not None else None,
+        wp = split_weight(weight)
+        if _f16():
+            _announce(_amax_word(x2))
+        _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
                                         1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
         return out.reshape(*shp[:-1], N)

@@ -73,7 +73,7 @@ def _rel(a, e, mask=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])      # f16x3: the fp16 two-piece split -- the bars of bf16x6 at the MFMA count of bf16x3
 @pytest.mark.parametrize("tag", TAGS)
 def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, monkeypatch):
     from styl3r_amd import vit_ops
@@ -101,7 +101,7 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     loss.backward()
     took = {k: vit_ops.CALLS[k] - before[k] for k in before}
     assert took["conv_x6_fwd"] > 0 and took["conv_x6_wgrad"] > 0 and took["layernorm_hip_fwd"] > 0 and took["layernorm_framework"] == 0, took
-    assert vit_ops.load().vit_x6_products() == (3 if mode == "bf16x3" else 6)
+    assert vit_ops.load().vit_x6_products() == {"bf16x6": 6, "bf16x3": 3, "f16x3": 2}[mode]
 
     idx = torch.tensor(G["idx"], device=dev)
     ok = ~np.unpackbits(G["fragile"])[: 2 * H * W].reshape(1, 2, 1, H, W).astype(bool)

@@ -837,3 +837,123 @@ def test_ring_kernel_dispatch_is_bit_identical_forward_and_input_gradient(N, K, 
     want = (1 if table.get((N, K)) else 0) + (1 if (mode == "bf16x3" and table.get((K, N))) else 0)
     assert na == want and (want >= 1 or mode == "bf16x6" or M < 4096), (na, want)
     assert torch.equal(ya, yb) and torch.equal(xa, xb)
+
+
+# --------------------------------------------------------------------------- f16x3: two fp16 pieces + tensor scales, three products
+def _f16x3_table(monkeypatch, x0, w0, b0, gy, gelu=False):
+    """(fwd, dX, dW, db) max-norm errors vs float64 of the fused Linear in every split-arithmetic mode"""
+    from styl3r_amd import vit_ops
+    xd, wd, bd = x0.double().requires_grad_(True), w0.double().requires_grad_(True), b0.double().requires_grad_(True)
+    ref = torch.nn.functional.linear(xd, wd, bd)
+    ref = torch.nn.functional.gelu(ref) if gelu else ref
+    (ref * gy.double()).sum().backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    errs = {}
+    for mode in ("bf16x3", "f16x3", "bf16x6"):
+        monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+        x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True); b = b0.clone().requires_grad_(True)
+        y = vit_ops.fused_linear(x, w, b, gelu=gelu)
+        (y * gy).sum().backward()
+        errs[mode] = (rel(y.detach(), ref.detach()), rel(x.grad, xd.grad), rel(w.grad, wd.grad), rel(b.grad, bd.grad))
+        assert vit_ops.load().vit_x6_products() == {"bf16x3": 3, "f16x3": 2, "bf16x6": 6}[mode]
+    return errs
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(514, 1024, 1024, False), (300, 192, 4096, True), (1028, 3072, 1024, False), (77, 40, 64, False), (5140, 768, 3072, False)])
+def test_f16x3_linear_has_fp32_class_accuracy_at_the_three_product_price(M, N, K, gelu, monkeypatch):
+    """the fp16 two-term split (value * 2^k = h + l, three products on the f16 MFMA) against float64, forward, dX, dW,
+    db, beside bf16x3 (same MFMA count) and bf16x6 (twice as many): <= 2 x the six-product kernels' error (+ fp32 rounding of the
+    output; measured: equal or below it on every shape -- at long contractions both sit on the fp32 accumulation floor) and well
+    below bf16x3's 3e-6 .. 5e-6."""
+    g = torch.Generator(DEV).manual_seed(M * 7 + N)
+    x0 = torch.randn(M, K, device=DEV, generator=g)
+    w0 = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    b0 = torch.randn(N, device=DEV, generator=g)
+    gy = torch.randn(M, N, device=DEV, generator=g)
+    errs = _f16x3_table(monkeypatch, x0, w0, b0, gy, gelu)
+    print(f"  Linear {M}x{N}x{K} (fwd, dX, dW, db) vs fp64:", {k: tuple(f"{e:.1e}" for e in v) for k, v in errs.items()})
+    for i in range(3):
+        assert errs["f16x3"][i] <= 2.0 * errs["bf16x6"][i] + 3e-7, (i, errs)
+        assert errs["f16x3"][i] * 2.5 <= errs["bf16x3"][i] or errs["f16x3"][i] <= 5e-7, (i, errs)      # (the fp32 accumulation floor is ~1e-6 at K >= 3072)
+    assert errs["f16x3"][3] <= 4e-6
+
+
+@pytest.mark.parametrize("xs,ws,gs", [(1.0, 1.0, 1e-8), (1e-3, 30.0, 1e-2), (400.0, 1e-4, 3e-6), (1.0, 1.0, 1.0)])
+def test_f16x3_linear_range_handling_gradient_magnitude_operands(xs, ws, gs, monkeypatch):
+    """fp16 has 5 exponent bits; the mode lives on per-tensor power-of-two scales from vit_amax.  Operands at the magnitudes a train step
+    really sees -- gradients of 1e-8, activations of 400 with one 30 x outlier row and a block of 1e-6-sized rows, weights of 1e-4 --
+    must keep the accuracy of the unit-scale case (the error is measured against float64, relative to the output's max-norm), and a tensor
+    with a wide spread (outliers 2^15 above the bulk) must not lose the bulk."""
+    g = torch.Generator(DEV).manual_seed(17)
+    M, N, K = 1028, 768, 1024
+    x0 = torch.randn(M, K, device=DEV, generator=g) * xs
+    x0[5] *= 30.0                                             # an outlier row sets the tensor's scale ...
+    x0[100:140] *= 2.0 ** -15                                 # ... and a block of rows sits 2^20 below it
+    w0 = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5 * ws
+    b0 = torch.randn(N, device=DEV, generator=g) * xs * ws
+    gy = torch.randn(M, N, device=DEV, generator=g) * gs
+    gy[:, 7] *= 100.0
+    errs = _f16x3_table(monkeypatch, x0, w0, b0, gy)
+    print(f"  scales x {xs:g} w {ws:g} dY {gs:g} (fwd, dX, dW, db):", {k: tuple(f"{e:.1e}" for e in v) for k, v in errs.items()})
+    for i in range(3):
+        assert errs["f16x3"][i] <= 2.0 * errs["bf16x6"][i] + 3e-7, (i, errs)
+    # the rows 2^20 below the tensor's maximum, judged on THEIR OWN scale: still far better than bf16x3 would be at full scale
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+    y = vit_ops.fused_linear(x0, w0, b0 * 0)
+    ref = x0[100:140].double() @ w0.double().t()
+    small = float((y[100:140].double() - ref).abs().max() / ref.abs().max())
+    print(f"  rows 2^-20 below the tensor maximum, error on their own scale: {small:.1e}")
+    assert small <= 2e-4
+
+
+def test_f16x3_refuses_a_launch_without_operand_maxima(monkeypatch):
+    """no guessed scale, no fallback: in f16x3 mode an x6 launch that was not given the |max| words of its activations is an error"""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+    vit_ops._x6()
+    lib = vit_ops.load()
+    x = torch.randn(64, 64, device=DEV); w = torch.randn(64, 64, device=DEV); out = torch.empty(64, 64, device=DEV)
+    wp = vit_ops.split_weight(w)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, 64, 64, 64, 0, s) == -1
+    assert lib.vit_linear_x6_wgrad(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, 64, 64, 64, s) == -1
+    word = vit_ops._amax_word(x)
+    torch.cuda.synchronize()
+    assert int(word.item()) == int(x.abs().max().view(torch.int32).item())      # the exact bit pattern of the maximum
+    vit_ops._announce(word)
+    assert lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, 64, 64, 64, 0, s) == 0
+    assert lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, 64, 64, 64, 0, s) == -1   # consumed
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
+    vit_ops._x6()
+
+
+def test_f16x3_convolutions_forward_input_and_weight_gradient(monkeypatch):
+    """3x3 (ReLU-fused residual unit included) and 1x1 convolutions of the DPT heads in f16x3: forward, dX, dW against float64,
+    beside the other two modes; small-pixel layers go through vit_im2col3_rows + the Linear weight-gradient kernel"""
+    from styl3r_amd import vit_ops
+    g = torch.Generator(DEV).manual_seed(23)
+    rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+    for (B, Ci, Co, H, W, k) in [(4, 128, 128, 64, 64, 3), (2, 256, 256, 32, 32, 3), (2, 160, 256, 64, 64, 1), (20, 128, 96, 128, 128, 3)]:
+        cx0 = torch.randn(B, Ci, H, W, device=DEV, generator=g) * 0.3
+        conv = vit_ops.Conv2dX6(Ci, Co, k, padding=k // 2).to(DEV)
+        cg = torch.randn(B, Co, H, W, device=DEV, generator=g) * 1e-5
+        cxd = cx0.double().requires_grad_(True); cwd = conv.weight.detach().double().requires_grad_(True)
+        cref = torch.nn.functional.conv2d(torch.relu(cxd), cwd, conv.bias.detach().double(), padding=k // 2) + cxd[:, :1].expand(-1, Co, -1, -1) * 0
+        (cref * cg.double()).sum().backward()
+        cerrs = {}
+        for mode in ("bf16x3", "f16x3", "bf16x6"):
+            monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+            conv.zero_grad()
+            cx = cx0.clone().requires_grad_(True)
+            before = dict(vit_ops.CALLS)
+            y = vit_ops._ConvX6.apply(cx, conv.weight, conv.bias, None, True)
+            (y * cg).sum().backward()
+            assert vit_ops.CALLS["conv_x6_fwd"] == before["conv_x6_fwd"] + 1 and vit_ops.CALLS["conv_x6_dx"] == before["conv_x6_dx"] + 1
+            cerrs[mode] = (rel(y.detach(), cref.detach()), rel(cx.grad, cxd.grad), rel(conv.weight.grad, cwd.grad))
+        print(f"  conv {k}x{k} B{B} {Ci}->{Co} {H}x{W} (fwd, dX, dW):", {m: tuple(f"{e:.1e}" for e in v) for m, v in cerrs.items()})
+        for i in range(3):
+            assert cerrs["f16x3"][i] <= 2.0 * cerrs["bf16x6"][i] + 3e-7, (i, cerrs)
+            assert cerrs["f16x3"][i] * 2.5 <= cerrs["bf16x3"][i] or cerrs["f16x3"][i] <= 5e-7, (i, cerrs)
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
+    vit_ops._x6()

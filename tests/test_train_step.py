@@ -203,7 +203,7 @@ def test_one_rank_rccl_group_runs_every_collective_and_matches_the_local_path():
             # a random-init point head puts (nearly) every Gaussian outside every frustum: the render is the background and EVERY gradient is
             # exactly zero (r03 ran this test on zeros).  Re-centre the five output convolutions so that the step renders a real scene
             recentre_output_heads_(enc, batch["context"], dict(image=batch["context"]["image"][:, 0]))
-            step = TrainStep(enc, dec, dist=group, force_collective=force, dp_mode=dp_mode)
+            step = TrainStep(enc, dec, dist=group, force_collective=force, dp_mode=dp_mode, warm_up_steps=2000)   # config/main.yaml:37: LinearLR from lr / 2000
             assert step.reducer.collective == force and step.reducer.mode == dp_mode
             losses = [float(step(batch)) for _ in range(2)]
             assert rasterizer.LAST_STATS["pairs"] > rasterizer.LAST_STATS["gaussians_per_scene"], rasterizer.LAST_STATS
@@ -417,7 +417,7 @@ def test_full_size_style_stage_step_trains_only_the_stylizer_and_accumulates_bot
             enc = EncoderNoPoSplatMultiTokenStyle(EncoderNoPoSplatTokenStyleCfg(stylized=True)).eval()      # eval: no dropout RNG in the comparison
             vgg = VGGEncoder()
         recentre_output_heads_(enc, batch["context"], dict(image=(batch["style"]["image"] - 0.5) / 0.5))
-        step = TrainStep(enc, dec, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
+        step = TrainStep(enc, dec, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), warm_up_steps=2000)
         if not inplace:
             step.reducer.close()
             step.reducer = BucketedGradReducer([p for p in enc.parameters() if p.requires_grad], None, 64 << 20, inplace_grads=False)

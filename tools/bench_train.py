@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
-ap.add_argument("--linear-mode", choices=["bf16x6", "bf16x3", "f32"], default=None, help="arithmetic of the Linear / convolution kernels (default: VIT_LINEAR_MODE or bf16x6)")
+ap.add_argument("--linear-mode", choices=["bf16x6", "bf16x3", "f16x3", "f32"], default=None, help="arithmetic of the Linear / convolution kernels (default: VIT_LINEAR_MODE or bf16x6)")
 ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                 help="c3: NVS-pretrain, 2 ctx / 4 tgt views, MSE, everything trains.  c4: style stage, 4 ctx / 6 tgt views, "
                      "VGG style loss + identity pass (two encoder/decoder passes), backbone frozen (random-init VGG: no weights here).  "
@@ -29,7 +29,7 @@ args = ap.parse_args()
 if args.linear_mode:
     from styl3r_amd import vit_ops as _vo
     _vo.LINEAR_MODE = args.linear_mode
-    if args.linear_mode in ("bf16x3", "bf16x6"):
+    if args.linear_mode in ("bf16x3", "bf16x6", "f16x3"):
         _vo.ATTENTION_ARITH = args.linear_mode          # one arithmetic mode for every GEMM-shaped kernel of the step
 if args.torch_linear:
     from styl3r_amd import vit as _vit
@@ -66,9 +66,9 @@ recentre_output_heads_(enc, batch["context"], dict(image=(batch["style"]["image"
 if c4:
     from styl3r_amd.losses import IdentityLoss, LossStyle, VGGEncoder
     vgg = VGGEncoder().to(dev)
-    step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg))
+    step = TrainStep(enc, dec, dist=dist, losses=[LossStyle(vgg=vgg)], identity_loss=IdentityLoss(vgg=vgg), warm_up_steps=2000)
 else:
-    step = TrainStep(enc, dec, dist=dist)
+    step = TrainStep(enc, dec, dist=dist, warm_up_steps=2000)      # config/main.yaml:37
 for _ in range(args.warmup):
     step(batch)
 assert rasterizer.LAST_STATS["pairs"] > rasterizer.LAST_STATS["gaussians_per_scene"], rasterizer.LAST_STATS
