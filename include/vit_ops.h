@@ -126,6 +126,10 @@ size_t vit_split_weight_bytes(int rows, int cols);
 int vit_x6_set_products(int n);
 int vit_x6_products(void);
 int vit_x6_set_operand_amax(const void *a_word, const void *b_word);
+/* `word` (zeroed): the next vit_linear_x6_fwd / vit_linear_x6r_fwd (cfg 1) launch on this thread writes the |max| of its OUTPUT there -- its
+ * epilogue sees every value it stores -- so the consumer of that output needs no vit_amax pass of its own.  Any arithmetic mode.  Consumed by
+ * that launch; one that cannot honour it (split-K partial sums, the 256 x 256 ring kernels) returns VIT_EINVAL. */
+int vit_x6_set_output_amax(void *word);
 int vit_amax(const float *x, int64_t n, void *out_word, void *stream);
 int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
 /*

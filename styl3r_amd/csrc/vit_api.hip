@@ -50,6 +50,7 @@ int adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, 
 int x6_set_products(int n);
 int x6_products();
 int x6_set_operand_amax(const void *a, const void *b);
+int x6_set_output_amax(void *word);
 int amax(const float *x, int64_t n, void *out, hipStream_t stream);
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
@@ -113,12 +114,13 @@ VIT_EXPORT int vit_adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr
 VIT_EXPORT int vit_x6_set_products(int n) { return vit::x6_set_products(n); }
 VIT_EXPORT int vit_x6_products(void) { return vit::x6_products(); }
 VIT_EXPORT int vit_x6_set_operand_amax(const void *a, const void *b) { return vit::x6_set_operand_amax(a, b); }
+VIT_EXPORT int vit_x6_set_output_amax(void *word) { return vit::x6_set_output_amax(word); }
 VIT_EXPORT int vit_amax(const float *x, int64_t n, void *out_word, void *stream) { return vit::amax(x, n, out_word, static_cast<hipStream_t>(stream)); }
 
 VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose)
 {
     const size_t R = transpose ? cols : rows, K = transpose ? rows : cols;
-    return ((R + 63) / 64) * 64 * K * 6;
+    return ((R + 63) / 64) * 64 * K * 6 + 256;       // (+ 256: the weight's |max| word of the f16x3 mode sits right behind the pieces)
 }
 
 VIT_EXPORT int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream)

@@ -131,11 +131,12 @@ __device__ inline float f16_scale(uint32_t amax_bits)
 // two (scaled) fp32 values -> their two fp16 pieces, each packed (lo = first value)
 __device__ inline void split2h(float a, float b, uint32_t &p0, uint32_t &p1)
 {
-    f32x2 f = {a, b};
-    const f16x2 h = __builtin_convertvector(f, f16x2);
-    const f32x2 r = f - __builtin_convertvector(h, f32x2);
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    p0 = __builtin_bit_cast(uint32_t, h); p1 = __builtin_bit_cast(uint32_t, l);
+    // h = RNE fp16 of the pair; l = fp16 of the exact residuals a - h (v_fma_mix_f32 reads the fp16 halves in place: no v_cvt_f32_f16)
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(p0));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(p0));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
 }
 
 // NPROD == 6 / 3: three bf16 pieces (the third unused by 3); NPROD == 2: two fp16 pieces of s * value (q2 is left alone)
@@ -184,7 +185,9 @@ __global__ void __launch_bounds__(256) k_amax(const float *__restrict__ x, int64
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t bm = max(max(part[0], part[1]), max(part[2], part[3]));
-        if (bm) atomicMax(out, bm);
+        // (a plain look first: after the first few workgroups nearly every block's maximum is already covered, and ~1 300 serialised
+        // atomics on one word were most of the pass on the 21 MB activations: 17 us against 4 us of memory time)
+        if (bm > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bm);
     }
 }
 
@@ -195,9 +198,11 @@ template <int ACT, int TN, bool SPLITK, int NPROD>
 __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                       const float *__restrict__ bias, const float *__restrict__ residual,
                                                       float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
-                                                      const uint32_t *__restrict__ amax_x, const uint32_t *__restrict__ amax_w)
+                                                      const uint32_t *__restrict__ amax_x, const uint32_t *__restrict__ amax_w,
+                                                      uint32_t *__restrict__ amax_out)
 {
     constexpr int BN = 64 * TN;
+    uint32_t omax = 0;          // |max| of the values this lane stores (published to *amax_out: the consumer's f16x3 scale without a pass of its own)
     // f16x3: scale of the activation tensor (applied while it is split) and the two inverse scales of the epilogue
     float sx = 1.f, ix = 1.f, iw = 1.f;
     if (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
@@ -342,15 +347,23 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
                     continue;
                 }
                 if (ACT == 2) {          // input-gradient GEMM of the layer BEHIND a GELU: out = (dY . W) * gelu'(pre), `residual` carries pre
-                    out[o] = t * gelu_grad_exact(residual[o]);
+                    t *= gelu_grad_exact(residual[o]);
+                    out[o] = t;
+                    omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu);
                     continue;
                 }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
                 out[o] = t;
+                omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu);
             }
         }
+    }
+    if (!SPLITK && amax_out) {   // (wave-uniform branch; one atomic per wave)
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
+        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
     }
 }
 
@@ -903,7 +916,14 @@ int x6_set_operand_amax(const void *a, const void *b)
     g_amax_a = static_cast<const uint32_t *>(a); g_amax_b = static_cast<const uint32_t *>(b);
     return VIT_OK;
 }
+static thread_local uint32_t *g_amax_out = nullptr;
+// Device address of a ZEROED word that the NEXT vit_linear_x6_fwd / vit_linear_x6r_fwd launch on this thread fills with the |max| of the
+// values it stores (its epilogue sees every one of them): the consumer of that output then needs no vit_amax pass.  Consumed by that
+// launch; a launch that cannot honour it (split-K partial sums) returns VIT_EINVAL.
+int x6_set_output_amax(void *word) { g_amax_out = static_cast<uint32_t *>(word); return VIT_OK; }
+uint32_t *x6_take_output_amax() { uint32_t *p = g_amax_out; g_amax_out = nullptr; return p; }
 static void take_amax(const uint32_t *&a, const uint32_t *&b) { a = g_amax_a; b = g_amax_b; g_amax_a = g_amax_b = nullptr; }
+void x6_take_amax(const uint32_t *&a, const uint32_t *&b) { take_amax(a, b); }      // (vit_gemm_x6r.hip)
 // the weight's |max| word lives right behind its rows x cols x 6 bytes of pieces (vit_split_weight_bytes leaves room)
 static const uint32_t *weight_amax(const void *packed, int rows, int cols)
 {
@@ -991,6 +1011,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     const int np = x6_products();
     const uint32_t *am_x, *am_unused, *am_w = weight_amax(wp, N, K);
     take_amax(am_x, am_unused);
+    uint32_t *am_out = x6_take_output_amax();
     if (np == 2 && !am_x) return VIT_EINVAL;      // f16x3 without the activation's |max|: refuse, never guess a scale
     (void)hipGetLastError();
     // split-K when the tiles cannot fill the 256 CUs x 3 resident workgroups: S = 2 / 4 / 8 ranges of >= 8 slabs each
@@ -1000,8 +1021,9 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
         while (S < 8 && tiles * S * 2 <= 768 && nk / (S * 2) >= 8) S *= 2;
     }
     if (S > 1) {
+        if (am_out) return VIT_EINVAL;             // partial sums: no workgroup sees a final value
         if (!zero_fill(out, (size_t)M * N * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-#define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w)
+#define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w, am_out)
         if (np == 3) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
         else if (np == 2) { if (narrow) VIT_LAUNCH_X6S(1, 2); else VIT_LAUNCH_X6S(2, 2); }
         else { if (narrow) VIT_LAUNCH_X6S(1, 6); else VIT_LAUNCH_X6S(2, 6); }
@@ -1009,9 +1031,9 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     } else {
 #define VIT_LAUNCH_X6(ACT, TN)                                                                                                                          \
     do {                                                                                                                                                \
-        if (np == 3) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 3>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w); \
-        else if (np == 2) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 2>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w); \
-        else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w);      \
+        if (np == 3) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 3>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w, am_out); \
+        else if (np == 2) hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 2>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w, am_out); \
+        else hipLaunchKernelGGL((x6::k_linear_x6<ACT, TN, false, 6>), dim3(tiles), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w, am_out);      \
     } while (0)
         if (act == 1) { if (narrow) VIT_LAUNCH_X6(1, 1); else VIT_LAUNCH_X6(1, 2); }
         else if (act == 2) { if (narrow) VIT_LAUNCH_X6(2, 1); else VIT_LAUNCH_X6(2, 2); }

@@ -39,12 +39,16 @@
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
-int x6_products();     // vit_gemm_x6.hip: partial products per launch (6 / 3), per host thread
+int x6_products();     // vit_gemm_x6.hip: partial products per launch (6 / 3; 2 = "f16x3"), per host thread
+void x6_take_amax(const uint32_t *&a, const uint32_t *&b);      // vit_gemm_x6.hip: the announced |max| words of the next launch (consumed)
+uint32_t *x6_take_output_amax();                                 // vit_gemm_x6.hip: where the next launch publishes the |max| of its output (or null)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace x6r {
 constexpr int BK = 16;
@@ -74,6 +78,42 @@ template <typename V4> __device__ inline void split8(const V4 &lo, const V4 &hi,
     split2(hi.x, hi.y, q0.z, q1.z, q2.z);
     split2(hi.z, hi.w, q0.w, q1.w, q2.w);
     f0 = __builtin_bit_cast(bf16x8, q0); f1 = __builtin_bit_cast(bf16x8, q1); f2 = __builtin_bit_cast(bf16x8, q2);
+}
+
+// ---- "f16x3" (NPROD == 2; see vit_gemm_x6.hip): two fp16 pieces of value * 2^k, k from the operand tensor's |max| ---------------
+__device__ inline float f16_scale(uint32_t amax_bits)
+{
+    const int e = (int)((amax_bits >> 23) & 0xff);
+    if (e == 0 || e == 255) return 1.f;
+    const int se = min(max(127 + 14 - (e - 127), 27), 227);
+    return __builtin_bit_cast(float, (uint32_t)se << 23);
+}
+__device__ inline void split2h(float a, float b, uint32_t &p0, uint32_t &p1)
+{
+    // h = RNE fp16 of the pair; l = fp16 of the exact residuals a - h (v_fma_mix_f32 reads the fp16 halves in place: no v_cvt_f32_f16)
+    float ra, rb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(p0));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(p0));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(ra), "v"(rb));
+}
+template <int NPROD, typename V4> __device__ inline void split8s(const V4 &lo, const V4 &hi, float s, bf16x8 &f0, bf16x8 &f1, bf16x8 &f2)
+{
+    if constexpr (NPROD == 2) {
+        uint4 q0, q1;
+        split2h(lo.x * s, lo.y * s, q0.x, q1.x);
+        split2h(lo.z * s, lo.w * s, q0.y, q1.y);
+        split2h(hi.x * s, hi.y * s, q0.z, q1.z);
+        split2h(hi.z * s, hi.w * s, q0.w, q1.w);
+        f0 = __builtin_bit_cast(bf16x8, q0); f1 = __builtin_bit_cast(bf16x8, q1); f2 = f1;
+    } else {
+        split8(lo, hi, f0, f1, f2);
+    }
+}
+template <int NPROD> __device__ inline f32x16 mma(const bf16x8 &a, const bf16x8 &b, const f32x16 &c)
+{
+    if constexpr (NPROD == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // same walk as vit_gemm_x6.hip's: XCD x owns a contiguous range of the tile sequence, the sequence walks groups of 8
@@ -127,10 +167,14 @@ template <int N> __device__ inline void wait_vmcnt()
 template <int ACT, int BM, int BN, int WM, int WN, int NST, int OCC, int NPROD = 6>
 __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                    const float *__restrict__ bias, const float *__restrict__ residual,
-                                                                   float *__restrict__ out, float *__restrict__ pre, int M, int N, int K)
+                                                                   float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
+                                                                   const uint32_t *__restrict__ amax_x, const uint32_t *__restrict__ amax_w,
+                                                                   uint32_t *__restrict__ amax_out)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; it has no amdgcn builtins / asm constraints)
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
+    float sx = 1.f, ix = 1.f, iw = 1.f;           // f16x3: activation scale (applied at the fragment split), inverse scales of the epilogue
+    if constexpr (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 96, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int A_CH = BM / 16, B_CH = 6 * (BN / 64), CH = A_CH + B_CH, CPW = (CH + NW - 1) / NW;   // 1 KiB DMA chunks per stage, per wave
     static_assert(BM % 64 == 0 && BN % 64 == 0 && RM >= 1 && (RN == 1 || RN == 2), "tile shape");
@@ -226,19 +270,19 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
             } else if (i + 1 < RM) lds_wait<2>(lo[i & 1], hi[i & 1]);
             else lds_wait<0>(lo[i & 1], hi[i & 1]);
             bf16x8 fa0, fa1, fa2;
-            split8(lo[i & 1], hi[i & 1], fa0, fa1, fa2);
+            split8s<NPROD>(lo[i & 1], hi[i & 1], sx, fa0, fa1, fa2);
 #pragma unroll
             for (int j = 0; j < RN; ++j) {      // smallest partial products first
                 const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
                 f32x16 c = acc[i][j];
                 if constexpr (NPROD == 6) {     // the three 2^-16-level products; left out in three-product mode (vit_x6_set_products(3))
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa2, b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b2, c, 0, 0, 0);
+                    c = mma<NPROD>(fa2, b0, c);
+                    c = mma<NPROD>(fa1, b1, c);
+                    c = mma<NPROD>(fa0, b2, c);
                 }
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, b0, c, 0, 0, 0);
+                c = mma<NPROD>(fa1, b0, c);
+                c = mma<NPROD>(fa0, b1, c);
+                c = mma<NPROD>(fa0, b0, c);
                 acc[i][j] = c;
             }
         }
@@ -247,6 +291,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
     wait_vmcnt<0>();   // the surplus DMAs of the last slabs must not outlive the workgroup's LDS allocation
 
     // acc[i][j]: lane column n = n0 + wn*(BN/WN) + 32 j + col ; register r = row m0 + wm*(BM/WM) + 32 i + (r&3) + 8 (r>>2) + 4 half
+    uint32_t omax = 0;
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int n = n0 + wn * (BN / WN) + 32 * j + col;
@@ -259,14 +304,22 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
-                float t = acc[i][j][r] + bv;
-                if (ACT == 2) { out[o] = t * gelu_grad_exact(residual[o]); continue; }
+                float t = acc[i][j][r];
+                if constexpr (NPROD == 2) t = t * ix * iw;
+                t += bv;
+                if (ACT == 2) { t *= gelu_grad_exact(residual[o]); out[o] = t; omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu); continue; }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
                 out[o] = t;
+                omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu);
             }
         }
+    }
+    if (amax_out) {             // |max| of the stored values (see vit_x6_set_output_amax): one atomic per wave
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
+        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
     }
 #endif
 }
@@ -303,9 +356,13 @@ template <int ACT, int BM, int BN, int WM, int WN, bool PROF = false, int NPROD 
 __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__restrict__ x, const uint4 *__restrict__ wp,
                                                                  const float *__restrict__ bias, const float *__restrict__ residual,
                                                                  float *__restrict__ out, float *__restrict__ pre, int M, int N, int K,
-                                                                 float4 *__restrict__ slabs, int *__restrict__ tickets)
+                                                                 float4 *__restrict__ slabs, int *__restrict__ tickets,
+                                                                 const uint32_t *__restrict__ amax_x, const uint32_t *__restrict__ amax_w,
+                                                                 uint32_t *__restrict__ amax_out)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    float sx = 1.f, ix = 1.f, iw = 1.f;           // f16x3: activation scale (applied by the converter), inverse scales of the epilogue
+    if constexpr (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
     constexpr int RAW_BYTES = BM * 64, B_BYTES = BN * 96, AC_BYTES = BM * 96;
     constexpr int RAW0 = 0, B0 = 3 * RAW_BYTES, AC0 = B0 + 2 * B_BYTES, LDS_BYTES = AC0 + 2 * AC_BYTES;   // raw ring of 3
@@ -378,7 +435,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
 
     auto convert = [&](int s_, f32x4 &lo, f32x4 &hi) {   // (lo, hi already waited for) -> planes of Ac[s_ & 1]
         bf16x8 f0, f1, f2;
-        split8(lo, hi, f0, f1, f2);
+        split8s<NPROD>(lo, hi, sx, f0, f1, f2);
         const uint32_t w = c_wr + (s_ & 1) * AC_BYTES;
         lds_write<0>(w, f0); lds_write<BM * 16>(w, f1);
         if constexpr (NPROD == 6) lds_write<2 * BM * 16>(w, f2);      // three-product mode never reads the third plane
@@ -433,18 +490,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                     const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]), b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
                     f32x16 c = acc[i][j];
                     if constexpr (NPROD == 6) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+                        c = mma<NPROD>(a2, b0, c);
+                        c = mma<NPROD>(a1, b1, c);
+                        c = mma<NPROD>(a0, b2, c);
                     }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+                    c = mma<NPROD>(a1, b0, c);
+                    c = mma<NPROD>(a0, b1, c);
+                    c = mma<NPROD>(a0, b0, c);
                     acc[i][j] = c;
                     const int blk = i * RN + j;
                     if (blk >= 4) {               // one quarter of the split rides in this block's six MFMA gaps
                         const float c0 = blk == 4 ? clo.x : blk == 5 ? clo.z : blk == 6 ? chi.x : chi.z, c1 = blk == 4 ? clo.y : blk == 5 ? clo.w : blk == 6 ? chi.y : chi.w;
-                        split2(c0, c1, p0[blk - 4], p1[blk - 4], p2[blk - 4]);
+                        if constexpr (NPROD == 2) split2h(c0 * sx, c1 * sx, p0[blk - 4], p1[blk - 4]);
+                        else split2(c0, c1, p0[blk - 4], p1[blk - 4], p2[blk - 4]);
 #pragma unroll
                         for (int k = 0; k < 6; ++k) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -455,8 +513,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 }
             }
         } else {
-            split2(clo.x, clo.y, p0[0], p1[0], p2[0]); split2(clo.z, clo.w, p0[1], p1[1], p2[1]);
-            split2(chi.x, chi.y, p0[2], p1[2], p2[2]); split2(chi.z, chi.w, p0[3], p1[3], p2[3]);
+            if constexpr (NPROD == 2) {
+                split2h(clo.x * sx, clo.y * sx, p0[0], p1[0]); split2h(clo.z * sx, clo.w * sx, p0[1], p1[1]);
+                split2h(chi.x * sx, chi.y * sx, p0[2], p1[2]); split2h(chi.z * sx, chi.w * sx, p0[3], p1[3]);
+            } else {
+                split2(clo.x, clo.y, p0[0], p1[0], p2[0]); split2(clo.z, clo.w, p0[1], p1[1], p2[1]);
+                split2(chi.x, chi.y, p0[2], p1[2], p2[2]); split2(chi.z, chi.w, p0[3], p1[3], p2[3]);
+            }
         }
         const uint32_t w = c_wr + (s_conv & 1) * AC_BYTES;
         lds_write<0>(w, __builtin_bit_cast(bf16x8, q0)); lds_write<BM * 16>(w, __builtin_bit_cast(bf16x8, q1));
@@ -556,6 +619,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         }
     }
 
+    uint32_t omax = 0;
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int n = n0 + wn * (BN / WN) + 32 * j + col;
@@ -568,23 +632,34 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
                 const int m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m >= M) continue;
                 const int64_t o = (int64_t)m * N + n;
-                float t = acc[i][j][r] + bv;
-                if (ACT == 2) { out[o] = t * gelu_grad_exact(residual[o]); continue; }
+                float t = acc[i][j][r];
+                if constexpr (NPROD == 2) t = t * ix * iw;
+                t += bv;
+                if (ACT == 2) { t *= gelu_grad_exact(residual[o]); out[o] = t; omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu); continue; }
                 if (pre) pre[o] = t;
                 if (ACT == 1) t = gelu_exact(t);
                 if (residual) t += residual[o];
                 out[o] = t;
+                omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu);
             }
         }
+    }
+    if (amax_out) {             // |max| of the stored values (vit_x6_set_output_amax): one atomic per wave
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
+        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
     }
 #endif
 }
 
 // w (R, C) row-major fp32 -> block layout packed[r / 64][c / 8][piece][r % 64][8] bf16, rows padded with zeros to a
 // multiple of 64.  transpose = 1 packs w^T (output row = column of w, k = row of w).
+template <int NPROD>
 __global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w, uint4 *__restrict__ packed, int rows, int cols,
-                                                     int transpose)
+                                                     int transpose, const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tail = *amax;     // the scale the readers of this image undo
+    const float sw = NPROD == 2 ? f16_scale(*amax) : 1.f;
     // output rows R_ = transpose ? cols : rows, contraction length K_ = transpose ? rows : cols
     const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols, KG = K_ >> 3;
     __shared__ float s[64][65];                       // [output row][k]: 64 rows x 64 k (8 k groups)
@@ -605,9 +680,9 @@ __global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w
         const float4 lo = make_float4(s[r][kg * 8 + 0], s[r][kg * 8 + 1], s[r][kg * 8 + 2], s[r][kg * 8 + 3]);
         const float4 hi = make_float4(s[r][kg * 8 + 4], s[r][kg * 8 + 5], s[r][kg * 8 + 6], s[r][kg * 8 + 7]);
         bf16x8 f0, f1, f2;
-        split8(lo, hi, f0, f1, f2);
+        split8s<NPROD>(lo, hi, sw, f0, f1, f2);
         uint4 *o = packed + (((int64_t)rb * KG + (k0 >> 3) + kg) * 3) * 64 + r;
-        o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); o[128] = __builtin_bit_cast(uint4, f2);
+        o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
     }
 }
 }  // namespace x6r
@@ -618,8 +693,15 @@ int split_weight_block(const float *w, void *packed, int rows, int cols, int tra
     const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols;
     if (K_ % 8 != 0) return VIT_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(x6r::k_split_block, dim3((K_ + 63) / 64, (R_ + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed),
-                       rows, cols, transpose);
+    // f16x3: the weight's |max| word must be announced (vit_x6_set_operand_amax(word, NULL)); the image keeps a copy right behind its pieces
+    const uint32_t *am, *unused;
+    x6_take_amax(am, unused);
+    uint32_t *tail = reinterpret_cast<uint32_t *>(static_cast<char *>(packed) + (size_t)((R_ + 63) / 64) * 64 * (size_t)K_ * 6);
+    if (x6_products() == 2) {
+        if (!am) return VIT_EINVAL;
+        hipLaunchKernelGGL(x6r::k_split_block<2>, dim3((K_ + 63) / 64, (R_ + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), rows, cols, transpose, am, tail);
+    } else
+        hipLaunchKernelGGL(x6r::k_split_block<6>, dim3((K_ + 63) / 64, (R_ + 63) / 64), dim3(256), 0, stream, w, static_cast<uint4 *>(packed), rows, cols, transpose, am, tail);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
@@ -634,35 +716,49 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
     if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre || (cfg != 1 && cfg != 3))) ||
         !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split; act 2: see vit_linear_x6_fwd
     const uint4 *w4 = static_cast<const uint4 *>(wp);
-    if (x6_products() == 2) return VIT_EINVAL;      // f16x3 (two fp16 pieces + tensor scales) is served by vit_linear_x6_fwd
+    const uint32_t *am_x, *am_unused;
+    x6_take_amax(am_x, am_unused);
+    const uint32_t *am_w = reinterpret_cast<const uint32_t *>(static_cast<const char *>(wp) + (size_t)((N + 63) / 64) * 64 * (size_t)K * 6);
+    const bool f16 = x6_products() == 2;
+    uint32_t *am_out = x6_take_output_amax();
+    if (am_out && cfg != 1 && cfg != 3) return VIT_EINVAL;   // the lockstep 256 x 256 kernel (cfg 2) does not publish its output's |max|
+    if (f16 && ((cfg != 1 && cfg != 3) || !am_x)) return VIT_EINVAL;      // f16x3: cfg 1 / cfg 3, with the activation's |max| announced
     (void)hipGetLastError();
 #define X6R_ARGS(BM, BN, THREADS) dim3(((M + BM - 1) / BM) * ((N + BN - 1) / BN)), dim3(THREADS), 0, stream, x, w4, bias, residual, out, pre, M, N, K
     const bool three = x6_products() == 3;
     if (cfg == 1) {
-        if (three) {
-            if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
-            else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
-            else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256));
-        } else if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
-        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
-        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256));
+        if (f16) {
+            if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+            else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+            else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+        } else if (three) {
+            if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+            else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+            else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2, 3>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+        } else if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6r<2, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
+        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 128, 128, 2, 2, 3, 2>), X6R_ARGS(128, 128, 256), am_x, am_w, am_out);
     } else if (cfg == 2) {
         if (act == 2) return VIT_EINVAL;
-        if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
-        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512));
+        if (act) hipLaunchKernelGGL((x6r::k_linear_x6r<1, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512), am_x, am_w, am_out);
+        else hipLaunchKernelGGL((x6r::k_linear_x6r<0, 256, 256, 2, 4, 3, 1>), X6R_ARGS(256, 256, 512), am_x, am_w, am_out);
     } else if (cfg == 4) {      // phase-timing instantiation (tools/probes/gemm_lab.py): needs `pre` with room for 32 floats
         if (!pre || (size_t)M * N < 32) return VIT_EINVAL;
-        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, true>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
     } else if (cfg >= 34) {
         return VIT_EINVAL;            // K splits need a workspace: vit_linear_x6c_fwd
+    } else if (f16) {
+        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4, false, 2>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 2>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, false, 2>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
     } else if (three) {
-        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
-        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
-        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4, false, 3>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
     } else {
-        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
-        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
-        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr);
+        if (act == 2) hipLaunchKernelGGL((x6r::k_linear_x6c<2, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
+        else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), X6R_ARGS(256, 256, 512), nullptr, nullptr, am_x, am_w, am_out);
     }
 #undef X6R_ARGS
     hipError_t e = hipGetLastError();
@@ -706,8 +802,8 @@ int linear_x6c_fwd(const float *x, const void *wp, const float *bias, const floa
     int *tickets = splits > 1 ? reinterpret_cast<int *>(static_cast<unsigned char *>(workspace) + (size_t)tiles * splits * 256 * 256 * sizeof(float)) : nullptr;
     (void)hipGetLastError();
     if (splits > 1 && hipMemsetAsync(tickets, 0, (size_t)tiles * sizeof(int), stream) != hipSuccess) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
-    if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets);
-    else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets);
+    if (act) hipLaunchKernelGGL((x6r::k_linear_x6c<1, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((x6r::k_linear_x6c<0, 256, 256, 2, 4>), dim3(tiles, splits), dim3(512), 0, stream, x, w4, bias, residual, out, pre, M, N, K, slabs, tickets, nullptr, nullptr, nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

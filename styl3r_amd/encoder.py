@@ -32,6 +32,7 @@ from torch import Tensor, nn
 
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg, _linear
+from . import vit_ops
 from .vit_ops import Conv2dX6, fused_linear, head_tail, input_merger_upsample_add, relu_dropout, upsample2x
 
 inf = float("inf")
@@ -505,7 +506,10 @@ class DPTAdapter(nn.Module):
         p1 = self.scratch.refinenet1(p2, layers[0])
         if self.kind == "gs":
             merged = input_merger_upsample_add(p1, imgs, self.input_merger[0])          # im2col planes + bf16x6 1x1 conv + fused ReLU / add
-            p1 = merged if merged is not None else upsample2x(p1) + self.input_merger(imgs.contiguous())
+            if merged is None:       # (the image itself needs a gradient -- parity tests only -- or a host tensor: the framework's 7x7 convolution)
+                vit_ops.CALLS["input_merger_library"] += 1
+                merged = upsample2x(p1) + self.input_merger(imgs.contiguous())
+            p1 = merged
         elif self.kind == "sh":
             p1 = upsample2x(p1)
         # the head tails -- ReLU [-> Dropout] -> 1x1 convolution to 3 / 8 channels -- are one pass over the activation each way

@@ -132,6 +132,9 @@ def recentre_output_heads_(encoder, context: dict, style: dict, targets: dict = 
         o = torch.cat(stats[k], 1)
         mean, std = o.mean(1), o.std(1)
         t_mean, t_std = (torch.tensor(x, dtype=torch.float64, device=o.device) for x in targets[k])
+        if t_mean.numel() != mean.numel():     # (appearance head at sh_degree > 0: 3 x d_sh channels; keep the total colour energy of the degree-0 target)
+            t_std = torch.full_like(mean, float(t_std.mean()) * (t_std.numel() / mean.numel()) ** 0.5)
+            t_mean = torch.zeros_like(mean)
         conv = getattr(encoder, k).dpt.head[4]
         gain = t_std / std
         conv.weight.copy_((conv.weight.double() * gain[:, None, None, None]).float())

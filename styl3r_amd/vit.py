@@ -18,16 +18,17 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from .vit_ops import GeluLink, LayerNorm, attention_qkv, fused_linear, memory_efficient_attention
-
-# Linear layers of the blocks run on the fused kernels (bias / exact GELU / residual in the epilogue); set to False to route
-# them through torch.nn.functional.linear (hipBLASLt) instead (tools/bench_train.py --torch-linear: an A/B switch).
-USE_FUSED_LINEAR = True
-
+from .vit_ops import CALLS, GeluLink, LayerNorm, attention_qkv, fused_linear, memory_efficient_attention
 
 def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False, link=None, link_in=None) -> Tensor:
-    if USE_FUSED_LINEAR and x.is_cuda and layer.in_features % 16 == 0:
+    """Linear layers of the blocks on the fused kernels (bias / exact GELU / residual in the epilogue).  Device tensors ALWAYS take them:
+    a contraction length the kernels cannot take (not a multiple of 16: no layer of the model) is an error, not a silent library GEMM.
+    CPU tensors (host-side tests of the module logic) take the framework's ops and are counted in vit_ops.CALLS["framework_linear"]."""
+    if x.is_cuda:
+        if layer.in_features % 16 != 0:
+            raise RuntimeError(f"fused Linear: in_features = {layer.in_features} is not a multiple of 16 (zero-pad the contraction as encoder._intrinsics_token does)")
         return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu, link=link, link_in=link_in)
+    CALLS["framework_linear"] += 1
     y = torch.nn.functional.linear(x, layer.weight, layer.bias)
     if gelu:
         y = torch.nn.functional.gelu(y)

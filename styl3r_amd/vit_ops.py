@@ -39,7 +39,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -141,6 +141,8 @@ def load() -> C.CDLL:
     lib.vit_x6_set_operand_amax.restype = C.c_int
     lib.vit_amax.argtypes = [vp, i64, vp, vp]
     lib.vit_amax.restype = C.c_int
+    lib.vit_x6_set_output_amax.argtypes = [vp]
+    lib.vit_x6_set_output_amax.restype = C.c_int
     lib.vit_split_weight_block_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.vit_split_weight_block_bytes.restype = C.c_size_t
     lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -536,9 +538,7 @@ def _dead_entry_ref(weight: Tensor, key):
 def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
     multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
-    key = (id(weight), "block_t" if transposed else "block")
-    if _f16():
-        raise RuntimeError("split_weight_block: the ring kernels have no f16x3 variant")
+    key = (id(weight), "block_t" if transposed else "block") + (("f16",) if _f16() else ())
     hit = _SPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
@@ -548,6 +548,8 @@ def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     nbytes = lib.vit_split_weight_block_bytes(N, K, 1 if transposed else 0)
     reuse = hit is not None and hit[0]() is weight and hit[3].numel() == nbytes
     packed = hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    if _f16():
+        _announce(_weight_amax_word(weight, w))
     _check(lib.vit_split_weight_block(w.data_ptr(), packed.data_ptr(), N, K, 1 if transposed else 0, _stream(weight.device)),
            "vit_split_weight_block")
     _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), packed)
@@ -644,7 +646,11 @@ SMALL_CONV_WGRAD = os.environ.get("VIT_CONV_SMALL_WGRAD", "linear")   # 3x3 weig
 _CONV_X6_MIN_ROWS = 96     # output channels (dX: input channels) per 128-row tile: at 64 the tile is half empty and MIOpen wins (82 vs 104 TF)
 # how often each hand-written kernel was taken instead of the library / framework path (the parity tests assert on these)
 CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_merger_x6": 0, "conv_x6_fwd": 0, "conv_x6_dx": 0, "conv_x6_wgrad": 0, "layernorm_hip_fwd": 0, "layernorm_hip_bwd": 0,
-         "layernorm_framework": 0, "adapter_hip": 0}
+         "layernorm_framework": 0, "adapter_hip": 0,
+         # library / framework routes taken ON DEVICE TENSORS (layers the hand-written kernels do not cover): the end-to-end tests assert that every one of them stays at zero
+         "library_conv_fwd": 0, "library_conv_bwd": 0, "framework_upsample": 0, "framework_dropout": 0, "framework_linear": 0,
+         "input_merger_library": 0}     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
+LIBRARY_ROUTES = ("library_conv_fwd", "library_conv_bwd", "framework_upsample", "framework_dropout", "layernorm_framework")
 
 
 def _conv_tiles(out_channels: int, x: Tensor) -> int:
@@ -703,6 +709,7 @@ class _ConvX6(torch.autograd.Function):
                                               x.data_ptr() if ctx.relu_in else None, dx.data_ptr(),
                                               B, Co, Ci, H, W, k, 2 if ctx.relu_in else 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
             else:
+                CALLS["library_conv_bwd"] += 1
                 dx = torch.ops.aten.convolution_backward(g, f_x(), weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
                                                          [True, False, False])[0]
                 if ctx.relu_in:
@@ -740,6 +747,7 @@ class _ConvX6(torch.autograd.Function):
                                               _stream(g.device)), "vit_linear_x6_wgrad (conv)")
             dw = dwl.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
         elif need_w or need_b:
+            CALLS["library_conv_bwd"] += 1
             _, dw, db = torch.ops.aten.convolution_backward(g, f_x(), weight, [weight.shape[0]] if ctx.has_bias else None, [1, 1],
                                                             [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, bool(need_w), bool(need_b)])
         return dx, dw, db, (g if need_r else None), None
@@ -761,12 +769,16 @@ class Conv2dX6(nn.Conv2d):
     def forward(self, x: Tensor) -> Tensor:
         if self._x6_ok(x):
             return _ConvX6.apply(x, self.weight, self.bias)
+        if x.is_cuda:
+            CALLS["library_conv_fwd"] += 1
         return super().forward(x)
 
     def forward_fused(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         """[residual +] conv(relu(x)): one launch on the bf16x6 kernel when the layer qualifies, the plain sequence otherwise."""
         if self._x6_ok(x):
             return _ConvX6.apply(x, self.weight, self.bias, residual, True)
+        if x.is_cuda:
+            CALLS["library_conv_fwd"] += 1
         out = super().forward(torch.relu(x))
         return out if residual is None else out + residual
 
@@ -795,6 +807,8 @@ def upsample2x(x: Tensor) -> Tensor:
     take vit_upsample2x_fwd / vit_upsample2x_bwd, anything else the framework's kernels."""
     if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 2 == 0:
         return _Upsample2x.apply(x)
+    if x.is_cuda:
+        CALLS["framework_upsample"] += 1
     return torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
 
 
@@ -847,6 +861,8 @@ def relu_dropout(x: Tensor, p: float, training: bool) -> Tensor:
     if training and p > 0.0 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and not x.is_leaf:
         seed = int(torch.randint(0, 2 ** 62, (1,), generator=_dropout_generator()).item())
         return _ReluDropout.apply(x, p, seed)
+    if x.is_cuda and training and p > 0.0:
+        CALLS["framework_dropout"] += 1
     return torch.nn.functional.dropout(torch.relu_(x) if not x.is_leaf else torch.relu(x), p, training)
 
 
@@ -1017,6 +1033,9 @@ def invalidate_split_cache() -> None:
 # 221 -> 311, fc1 223 -> 276, fc2 164 -> 283, proj 161 -> 224, decoder qkv 210 -> 252, fc1 224 -> 294, fc2 198 -> 234.  In three-product mode the
 # same table serves the input-gradient GEMMs (dX = dY . W is the Linear with N and K exchanged).  Outputs are bit-identical to vit_linear_x6_fwd.
 _RING_SHAPES = {
+    # f16x3: the data path of bf16x3 with fp16 pieces -- same table
+    "f16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
+              (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
     "bf16x6": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (1024, 4096): 1},
     "bf16x3": {(3072, 1024): 3, (3072, 768): 3, (2304, 768): 3, (4096, 1024): 1, (1024, 4096): 1, (1024, 1024): 1, (1024, 3072): 1,
                (768, 3072): 1, (768, 2304): 1, (768, 768): 1, (768, 1024): 1},
@@ -1026,7 +1045,8 @@ _RING_SHAPES = {
 # Style-encoder shapes at M = 2 560 (tools/probes/gemm_lab.py, r03): three products fc1 209 -> 252 (cfg 3), qkv 179 -> 271, fc2 152 -> 165,
 # qkv dX 140 -> 159 (cfg 1); six products (forward only) fc1 154 -> 173 (cfg 3), qkv 139 -> 177 (cfg 1).  tools/probes/linear_shapes.py: these
 # four shapes are 20 % of the Linear forward + dX FLOPs of a C3 step.
-_RING_SHAPES_MID = {"bf16x3": {(2304, 768): 1, (3072, 768): 1, (4096, 1024): 3, (1024, 4096): 1, (3072, 1024): 1, (1024, 3072): 1},
+_RING_SHAPES_MID = {"f16x3": {(2304, 768): 1, (3072, 768): 1, (4096, 1024): 3, (1024, 4096): 1, (3072, 1024): 1, (1024, 3072): 1},
+                    "bf16x3": {(2304, 768): 1, (3072, 768): 1, (4096, 1024): 3, (1024, 4096): 1, (3072, 1024): 1, (1024, 3072): 1},
                     "bf16x6": {(4096, 1024): 3, (3072, 1024): 1}}
 RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
@@ -1060,16 +1080,29 @@ class _FusedLinear(torch.autograd.Function):
                 pre.data_ptr() if pre is not None else None, M, N, K, int(act), _stream(x.device))
         ring = _ring_cfg(M, N, K) if x6 else 0
         ctx.ax = None
+        f16 = x6 and _f16()
+        # f16x3: |max| of the input (shared with the weight-gradient launch).  An fc2 takes the word its fc1's epilogue filled (GeluLink.ax)
+        # instead of a pass over the (M, 4 C) hidden activation; an fc1 asks its own epilogue for that word
+        publish = f16 and link is not None and need_pre and ring in (0, 1, 3)
+
+        def operands():
+            if not f16:
+                return
+            ctx.ax = link_in.ax if (link_in is not None and link_in.ax is not None) else _amax_word(x2)
+            _announce(ctx.ax)
+            if publish:
+                link.ax = _AMAX.word(x2.device)
+                _check(load().vit_x6_set_output_amax(link.ax.data_ptr()), "vit_x6_set_output_amax")
         if ring:
             # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
             # tools/probes/gemm_lab.py measured them faster (per arithmetic mode: _RING_SHAPES)
             CALLS["linear_x6r"] += 1
-            _check(load().vit_linear_x6r_fwd(x2.data_ptr(), split_weight_block(weight).data_ptr(), *args[:-1], ring, args[-1]), "vit_linear_x6r_fwd")
+            wpb = split_weight_block(weight)
+            operands()
+            _check(load().vit_linear_x6r_fwd(x2.data_ptr(), wpb.data_ptr(), *args[:-1], ring, args[-1]), "vit_linear_x6r_fwd")
         elif x6:
             wp = split_weight(weight)
-            ctx.ax = _amax_word(x2) if _f16() else None        # f16x3: |max| of the input, shared with the weight-gradient launch
-            if ctx.ax is not None:
-                _announce(ctx.ax)
+            operands()
             _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), *args), "vit_linear_x6_fwd")
         else:
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
@@ -1102,11 +1135,20 @@ class _FusedLinear(torch.autograd.Function):
         f16 = ctx.mode == "f16x3" and ctx.weight_ref is not None
         ag = None                                              # f16x3: |max| of dY, one pass shared by the dX and the dW launch
 
+        if f16 and act == 1 and ctx.link is not None and ctx.link.fused and ctx.link.adx is not None:
+            ag = ctx.link.adx                                  # this fc1's dY came out of fc2's input-gradient GEMM, which published its |max|
+
         def amax_g(t):
             nonlocal ag
             if ag is None:
                 ag = _amax_word(t)
             return ag
+
+        def publish_dx(lk, ring):
+            # (fc2, GELU' in the epilogue: the stored values ARE fc1's dY)
+            if f16 and lk is not None and gelu_pre is not None and ring in (0, 1, 3):
+                lk.adx = _AMAX.word(g.device)
+                _check(load().vit_x6_set_output_amax(lk.adx.data_ptr()), "vit_x6_set_output_amax")
         dx = None
         if need_x:
             N, K = w.shape
@@ -1116,16 +1158,21 @@ class _FusedLinear(torch.autograd.Function):
                 lk = ctx.link_in
                 gelu_pre = lk.pre if (lk is not None and lk.pre is not None and tuple(lk.pre.shape) == (g2c.shape[0], K)) else None
                 # (input-gradient GEMMs take the ring kernels in three-product mode only: in six-product mode the A/B on the whole step lost 3 ms)
-                ring = _ring_cfg(g2c.shape[0], K, N) if (ctx.mode == LINEAR_MODE == "bf16x3") else 0
+                ring = _ring_cfg(g2c.shape[0], K, N) if (ctx.mode == LINEAR_MODE and ctx.mode in ("bf16x3", "f16x3")) else 0
                 if ring:
                     CALLS["linear_x6r"] += 1
-                    _check(load().vit_linear_x6r_fwd(g2c.data_ptr(), split_weight_block(ctx.weight_ref, True).data_ptr(), None,
+                    wpb = split_weight_block(ctx.weight_ref, True)
+                    if f16:
+                        _announce(amax_g(g2c))
+                    publish_dx(lk, ring)
+                    _check(load().vit_linear_x6r_fwd(g2c.data_ptr(), wpb.data_ptr(), None,
                                                      gelu_pre.data_ptr() if gelu_pre is not None else None, dx.data_ptr(), None,
                                                      g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, ring, _stream(g.device)), "vit_linear_x6r_fwd (dX)")
                 else:
                     wpt = split_weight(ctx.weight_ref, True)
                     if f16:
                         _announce(amax_g(g2c))
+                    publish_dx(lk, 0)
                     _check(load().vit_linear_x6_fwd(g2c.data_ptr(), wpt.data_ptr(), None,
                                                     gelu_pre.data_ptr() if gelu_pre is not None else None,
                                                     dx.data_ptr(), None, g2c.shape[0], K, N, 2 if gelu_pre is not None else 0, _stream(g.device)),
@@ -1181,11 +1228,14 @@ class GeluLink:
     """Ties the two Linear layers of an Mlp (fc1 -> GELU -> fc2, blocks.py:76-82) together for the backward: fc1's node publishes
     the GELU's pre-activation here, fc2's node -- whose input-gradient GEMM produces exactly the gradient of the GELU's output -- runs
     GELU'(pre) in that GEMM's epilogue (vit_linear_x6_fwd act = 2) and sets `fused`; fc1's node then skips its GeluBackward pass.  Valid
-    only when the GELU's output feeds NOTHING but that fc2 (true inside Mlp: the hidden tensor is local to its forward)."""
-    __slots__ = ("pre", "fused")
+    only when the GELU's output feeds NOTHING but that fc2 (true inside Mlp: the hidden tensor is local to its forward).
+    In f16x3 mode the link also carries two |max| words that the producing GEMMs' epilogues fill on the side (vit_x6_set_output_amax): `ax` for
+    the hidden activation (fc1 publishes it, fc2 needs it for its input scale) and `adx` for its gradient (fc2's input-gradient GEMM publishes
+    it, fc1's backward needs it) -- the two largest operands of a block then cost no vit_amax pass."""
+    __slots__ = ("pre", "fused", "ax", "adx")
 
     def __init__(self):
-        self.pre, self.fused = None, False
+        self.pre, self.fused, self.ax, self.adx = None, False, None, None
 
 
 def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,

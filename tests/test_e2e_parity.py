@@ -7,8 +7,8 @@ The loss is the MSE over the pixels the generator did not flag (below), on both 
 Bars.  Gaussians (means / covariances / SH / opacities): 1e-4, max-norm relative.  Rendered RGB: max-norm over the pixels the
 generator did not flag as discontinuity-adjacent (an alpha within 0.5 % of the 1/255 cut, a depth near-tie between visible
 contributors, a termination decided within 2 %: the image is a discontinuous function of the Gaussians there and ANY fp32 encoder
-flips some of them -- the reference's own fp32 run included); bar = max(1e-4, 5 x the reference's own fp32 distance on the same
-pixels: ONE sample of that noise per quantity, measured ratios 0.3 .. 3.9 over repeated runs), and the table says which of the two applied.  Gradients: the same rule per tensor.  In bf16x3 mode the bar is the
+flips some of them -- the reference's own fp32 run included); bar = max(1e-4, 2 x the reference's own fp32 distance on the same
+pixels: ONE sample of that noise per quantity -- r04: 2 x for the images, measured 0.6 x; 4 x for gradients, measured 0.3 .. 3.2 over repeated runs and fixtures; r03: 5 x), and the table says which of the two applied.  Gradients: the same rule per tensor.  In bf16x3 mode the bar is the
 reference's TF32 distance (`tf32noise:*`: the arithmetic the reference really runs its Linear / Conv layers in, croco.py:13) --
 the evidence VERDICT r02 #2 asked for before that mode may carry a headline number.
 
@@ -82,7 +82,8 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     v, H, W = SHAPES[tag]
     dev = "cuda:0"
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
-    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", mode)          # the three-product mode covers the attention contractions, too
+    import os
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", os.environ.get("E2E_ATTENTION", mode))      # the three-product mode covers the attention contractions, too (E2E_ATTENTION: probe runs)
     m = _load_heads(deterministic_init_(_mid(tag)), G).to(dev)
     dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
     T = lambda k: torch.tensor(G[k], device=dev)
@@ -100,7 +101,15 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     loss = (((out.color - target) ** 2) * ok_t).mean()
     loss.backward()
     took = {k: vit_ops.CALLS[k] - before[k] for k in before}
-    assert took["conv_x6_fwd"] > 0 and took["conv_x6_wgrad"] > 0 and took["layernorm_hip_fwd"] > 0 and took["layernorm_framework"] == 0, took
+    assert took["conv_x6_fwd"] > 0 and took["conv_x6_wgrad"] > 0 and took["layernorm_hip_fwd"] > 0, took
+    # no library convolution, no framework interpolation / dropout / LayerNorm / Linear anywhere in the step (VERDICT r03 hygiene #15)
+    # (one exception, counted on its own: this test asks for the gradient of the IMAGE, which sends the gs heads' 7x7 input merger -- forward
+    # and backward -- to the framework's convolution; a train step never differentiates with respect to its input images)
+    routes = {k: took[k] for k in (*vit_ops.LIBRARY_ROUTES, "framework_linear", "input_merger_library")}
+    assert took["library_conv_fwd"] == took["input_merger_library"] and took["library_conv_bwd"] == 0, routes
+    # (c4 fixture, 128 x 160: the deepest DPT stage is 4 x 5 tokens wide -- an ODD width, which vit_upsample2x does not take; 256 x 256 never gets there)
+    exempt = ("library_conv_fwd", "framework_upsample") if tag == "c4" else ("library_conv_fwd",)
+    assert all(took[k] == 0 for k in vit_ops.LIBRARY_ROUTES if k not in exempt) and took["framework_linear"] == 0, routes
     assert vit_ops.load().vit_x6_products() == {"bf16x6": 6, "bf16x3": 3, "f16x3": 2}[mode]
 
     idx = torch.tensor(G["idx"], device=dev)
@@ -136,7 +145,9 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
             return 2e-4 if k in OUTPUTS else max(1e-4, ntf(k))     # (covariances 0.75e-4 .. 1.05e-4 run to run): printed, bounded at 2e-4
         if k in OUTPUTS:
             return 1e-4
-        return max(1e-4, 5.0 * n32(k))
+        # images (colour, depth): 2 x the reference's own fp32 distance (measured 0.6 x); gradients: 4 x (measured 0.3 .. 3.2 over the rounds,
+        # fixtures and modes -- one noise sample per tensor is itself only good to a factor of ~2); r03 used 5 x for everything
+        return max(1e-4, (2.0 if k in ("color", "depth") else 4.0) * n32(k))
     lines = [f"  [{tag} {mode}] {k:68s} {val:9.2e}  bar {bar(k):8.1e} ({'1e-4' if bar(k) == 1e-4 else 'yardstick'})"
              f"  ref-fp32 {n32(k):8.1e}  ref-tf32 {ntf(k):8.1e}" for k, val in rep.items() if k != "color_all"]
     print("\n".join(lines))
@@ -192,4 +203,4 @@ def test_encoder_batch_and_view_axes_are_consistent_b2_v4():
         want = parts[0][1][n] + parts[1][1][n]
         err = float((gfull[n] - want).abs().max() / want.abs().max())
         print(f"  b=2,v=4 vs summed b=1: d {n:60s} {err:.2e}")
-        assert err <= 1e-3, (n, err)         # one batched launch vs the sum of two: the weight-gradient kernels' atomics reorder fp32 sums
+        assert err <= 7e-4, (n, err)         # one batched launch vs the sum of two: the weight-gradient kernels' atomics reorder fp32 sums (measured <= 6.7e-4 over the rounds)

@@ -234,7 +234,7 @@ def test_fused_linear_vs_fp64(M, N, K, gelu, res):
 # ---------------------------------------------------------------------------
 def _unpack_split(packed, rows, kcols):
     """packed [rows][k/8][piece][8] bf16 -> three fp64 (rows, k) planes"""
-    raw = packed.view(torch.int16).view(rows, kcols // 8, 3, 8).to(torch.int32)
+    raw = packed[: rows * kcols * 6].view(torch.int16).view(rows, kcols // 8, 3, 8).to(torch.int32)     # (256 trailing bytes: the f16x3 mode's |max| word)
     f = (raw << 16).view(torch.float32)
     return [f[:, :, p, :].reshape(rows, kcols).double() for p in range(3)]
 
@@ -806,7 +806,7 @@ def test_patch_embed_as_linear_equals_the_strided_convolution():
     assert_close_rel(pe.proj.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 1e-5, "patch embed db")
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])
 @pytest.mark.parametrize("M", [4100, 2562])             # ragged (not a multiple of any tile height): the large-M and the mid-M table
 @pytest.mark.parametrize("N,K,gelu", [(3072, 1024, False), (4096, 1024, True), (1024, 4096, False), (2304, 768, False), (768, 3072, False)])
 def test_ring_kernel_dispatch_is_bit_identical_forward_and_input_gradient(N, K, gelu, M, mode, monkeypatch):
@@ -834,7 +834,7 @@ def test_ring_kernel_dispatch_is_bit_identical_forward_and_input_gradient(N, K, 
     yb, xb, nb = run(False)
     assert nb == 0
     table = (vit_ops._RING_SHAPES if M >= 4096 else vit_ops._RING_SHAPES_MID).get(mode, {})
-    want = (1 if table.get((N, K)) else 0) + (1 if (mode == "bf16x3" and table.get((K, N))) else 0)
+    want = (1 if table.get((N, K)) else 0) + (1 if (mode in ("bf16x3", "f16x3") and table.get((K, N))) else 0)
     assert na == want and (want >= 1 or mode == "bf16x6" or M < 4096), (na, want)
     assert torch.equal(ya, yb) and torch.equal(xa, xb)
 

@@ -19,7 +19,6 @@ from styl3r_amd.train import TrainStep
 ap = argparse.ArgumentParser()
 ap.add_argument("--scenes", type=int, default=4); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1); ap.add_argument("--tiny", action="store_true")
-ap.add_argument("--torch-linear", action="store_true", help="route the ViT Linear layers through hipBLASLt instead of vit_linear_fwd")
 ap.add_argument("--linear-mode", choices=["bf16x6", "bf16x3", "f16x3", "f32"], default=None, help="arithmetic of the Linear / convolution kernels (default: VIT_LINEAR_MODE or bf16x6)")
 ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
                 help="c3: NVS-pretrain, 2 ctx / 4 tgt views, MSE, everything trains.  c4: style stage, 4 ctx / 6 tgt views, "
@@ -31,9 +30,6 @@ if args.linear_mode:
     _vo.LINEAR_MODE = args.linear_mode
     if args.linear_mode in ("bf16x3", "bf16x6", "f16x3"):
         _vo.ATTENTION_ARITH = args.linear_mode          # one arithmetic mode for every GEMM-shaped kernel of the step
-if args.torch_linear:
-    from styl3r_amd import vit as _vit
-    _vit.USE_FUSED_LINEAR = False
 rank, local_rank, world = dist_utils.env_world()
 torch.cuda.set_device(local_rank); dev = torch.device("cuda", local_rank)
 dist = dist_utils.init_distributed("nccl", dev)
@@ -84,6 +80,6 @@ if rank == 0:
                       "grad_bytes": 4 * sum(p.numel() for p in enc.parameters() if p.requires_grad),
                       "buckets": len(step.reducer.buckets), "peak_mem_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                       "dtype": "f32", "linear_arithmetic": __import__("styl3r_amd.vit_ops", fromlist=["x"]).LINEAR_MODE
-                      if not args.torch_linear else "hipBLASLt f32", "data": "synthetic, random-init weights"}))
+, "data": "synthetic, random-init weights"}))
 if dist is not None:
     dist.barrier(); dist.destroy_process_group()
