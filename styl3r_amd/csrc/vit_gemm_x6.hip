@@ -694,6 +694,204 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
     }
 }
 
+// 3x3 convolution, HALO form (r04).  k_conv_x6 treats the nine taps as nine independent K slabs: every 16-channel slab of every output
+// pixel is fetched from global memory, ReLU'd, masked and SPLIT nine times (once per tap), and in the three-product modes that B-side
+// data path -- not the matrix pipe -- is what bounds the kernel.  Here a workgroup owns a 4 x 32 patch of output pixels of ONE image
+// (x 128 output channels) and stages, once per 16-channel slab, the (4+2) x (32+2) halo patch of the input: one fetch, one ReLU / border
+// mask / split per input element, laid out pixel-major in LDS ([halo pixel][k group][piece][8 channels], the layout of k_conv_x6's B
+// image), so the B fragment of tap (ky, kx) is the same image read at row offset ky * 34 + kx.  A 32-lane fragment column is one patch
+// row = 32 consecutive halo rows (+ the tap offset), which keeps the XOR swizzle of `swz` conflict-free for every tap.  The weight
+// tiles (A: 128 channels x 16 k per tap and slab) stream through two register stages and two LDS images as in k_conv_x6.
+// Per slab and workgroup: 204 halo pixels x 16 channels fetched and split (k_conv_x6: 9 x 128 x 16), 9 x (2 x 2 x NPROD) MFMAs per wave.
+// Epilogue and split-K (gridDim.y) semantics are k_conv_x6's; `amax_out` publishes the |max| of the stored values (unsplit launches).
+template <bool RELU_IN, int NPROD>
+__global__ void __launch_bounds__(256, 2) k_conv3h_x6(const float *__restrict__ in, const uint4 *__restrict__ wp,
+                                                      const float *__restrict__ bias, const float *__restrict__ residual,
+                                                      float *__restrict__ out, int B, int Ci, int Co, int H, int W, int gate,
+                                                      const uint32_t *__restrict__ amax_w, const uint32_t *__restrict__ amax_in,
+                                                      uint32_t *__restrict__ amax_out)
+{
+    constexpr int TY = 4, TX = 32, HY = TY + 2, HX = TX + 2, HP = HY * HX;      // 204 halo pixels
+    __shared__ uint4 sA[2][BM * ROWQ], sP[2][HP * ROWQ];                         // 24 KB + 38.25 KB
+    float sb = 1.f, ia = 1.f, ib = 1.f;                     // f16x3: activation scale (rides in the border mask), inverse scales
+    if (NPROD == 2) { sb = f16_scale(*amax_in); ib = 1.f / sb; ia = 1.f / f16_scale(*amax_w); }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int HW = H * W;
+    const int tiles_x = (W + TX - 1) / TX, tiles_img = tiles_x * ((H + TY - 1) / TY);
+    const int tiles_m = (Co + BM - 1) / BM, tiles_n = B * tiles_img;
+    int tm, tn;
+    tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int co0 = tm * BM;
+    const int b_ = tn / tiles_img, tr = tn - b_ * tiles_img;
+    const int ty0 = (tr / tiles_x) * TY, tx0 = (tr % tiles_x) * TX;
+    const int KG = (9 * Ci) >> 3, CG = Ci >> 3;
+    // gridDim.y > 1: the Ci / 16 channel slabs (nine taps each) are split across workgroups (fp32 atomics into the zeroed output)
+    const int nslab = Ci / BK, S_ = gridDim.y, sp_ = blockIdx.y;
+    const int s_lo = sp_ * (nslab / S_) + min(sp_, nslab % S_), ns = nslab / S_ + (sp_ < nslab % S_ ? 1 : 0);
+    const int nit = ns * 9;
+
+    // A loader (weights): thread -> (row, k group), three 16-byte pieces; k index of (tap, slab) = tap * Ci + slab * 16
+    const int lrow = tid >> 1, kg = tid & 1;
+    const uint4 *wa = wp + ((int64_t)min(co0 + lrow, Co - 1) * KG + kg) * 3;
+    // halo loader: 2 k groups x 204 pixels = 408 items of 8 channels; thread -> items tid and tid + 256 (the latter for tid < 152);
+    // consecutive lanes = consecutive pixels of a halo row = consecutive addresses of one channel plane
+    const float *inb = in + (int64_t)b_ * Ci * HW;
+    int h_off[2], h_row[2], h_slot[2];
+    float h_m[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int item = min(tid + e * 256, 2 * HP - 1);
+        const int kq = item / HP, hp = item - kq * HP, hy = hp / HX, hx = hp - hy * HX;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        h_m[e] = (y >= 0 && y < H && x >= 0 && x < W) ? sb : 0.f;              // border / outside-image pixels contribute zero
+        h_off[e] = (kq * 8) * HW + min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        h_row[e] = hp; h_slot[e] = kq * 3;
+    }
+    const bool second = tid < 2 * HP - 256;
+    float hv0[8], hv1[8];
+    auto halo_gload = [&](int s) {      // slab s of this split -> registers
+        const float *p0_ = inb + (int64_t)(s_lo + s) * BK * HW;
+#pragma unroll
+        for (int c_ = 0; c_ < 8; ++c_) {
+            hv0[c_] = p0_[h_off[0] + c_ * HW];
+            hv1[c_] = p0_[h_off[1] + c_ * HW];                                   // (tid >= 152: a duplicate of the last item, stored to the same place)
+        }
+    };
+    auto halo_store = [&](int buf) {
+        const float lo_ = RELU_IN ? 0.f : -3.0e38f;
+        uint4 q0_, q1_, q2_;
+        {
+            const float m_ = h_m[0];
+            split8s<NPROD>(make_float4(fmaxf(hv0[0], lo_) * m_, fmaxf(hv0[1], lo_) * m_, fmaxf(hv0[2], lo_) * m_, fmaxf(hv0[3], lo_) * m_),
+                           make_float4(fmaxf(hv0[4], lo_) * m_, fmaxf(hv0[5], lo_) * m_, fmaxf(hv0[6], lo_) * m_, fmaxf(hv0[7], lo_) * m_), 1.f, q0_, q1_, q2_);
+            uint4 *pp_ = sP[buf] + h_row[0] * ROWQ;
+            pp_[swz(h_row[0], h_slot[0] + 0)] = q0_; pp_[swz(h_row[0], h_slot[0] + 1)] = q1_; if (NPROD == 6) pp_[swz(h_row[0], h_slot[0] + 2)] = q2_;
+        }
+        if (second) {
+            const float m_ = h_m[1];
+            split8s<NPROD>(make_float4(fmaxf(hv1[0], lo_) * m_, fmaxf(hv1[1], lo_) * m_, fmaxf(hv1[2], lo_) * m_, fmaxf(hv1[3], lo_) * m_),
+                           make_float4(fmaxf(hv1[4], lo_) * m_, fmaxf(hv1[5], lo_) * m_, fmaxf(hv1[6], lo_) * m_, fmaxf(hv1[7], lo_) * m_), 1.f, q0_, q1_, q2_);
+            uint4 *pp_ = sP[buf] + h_row[1] * ROWQ;
+            pp_[swz(h_row[1], h_slot[1] + 0)] = q0_; pp_[swz(h_row[1], h_slot[1] + 1)] = q1_; if (NPROD == 6) pp_[swz(h_row[1], h_slot[1] + 2)] = q2_;
+        }
+    };
+    // two register stages of weight tiles (written out as scalars: see k_conv_x6)
+    uint4 a0_0, a1_0, a2_0, a0_1, a1_1, a2_1;
+    a2_0 = a2_1 = make_uint4(0, 0, 0, 0);
+#define H6_AGLOAD(T, it_)                                                                                              \
+    do {                                                                                                              \
+        const int i_ = min((it_), nit - 1), s_ = i_ / 9, tp_ = i_ - s_ * 9;   /* past the end: the last tile again (never consumed) */ \
+        const uint4 *q_ = wa + (int64_t)(tp_ * CG + (s_lo + s_) * 2) * 3;                                             \
+        a0_##T = q_[0]; a1_##T = q_[1]; if (NPROD == 6) a2_##T = q_[2];                                               \
+    } while (0)
+#define H6_ASTORE(buf, T)                                                                                             \
+    do {                                                                                                              \
+        uint4 *pa_ = sA[buf] + lrow * ROWQ;                                                                           \
+        pa_[swz(lrow, kg * 3 + 0)] = a0_##T; pa_[swz(lrow, kg * 3 + 1)] = a1_##T; if (NPROD == 6) pa_[swz(lrow, kg * 3 + 2)] = a2_##T; \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+    // halo row of this lane's pixel in fragment column j: patch row 2 wn + j, patch column `col`  (tap (ky, kx) adds ky * HX + kx)
+    const int hp0 = (2 * wn) * HX + col;
+    auto compute = [&](int abuf, int pbuf, int tap) {
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const uint4 *a = sA[abuf] + (wm * 64 + col) * ROWQ;
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int hp = hp0 + (j + ky) * HX + kx;
+            const uint4 *b = sP[pbuf] + hp * ROWQ;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[swz(hp, half * 3 + p)]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 cc = acc[i][j];
+                if (NPROD == 6) {
+                    cc = mma<NPROD>(fa[i][2], fb[j][0], cc);
+                    cc = mma<NPROD>(fa[i][1], fb[j][1], cc);
+                    cc = mma<NPROD>(fa[i][0], fb[j][2], cc);
+                }
+                cc = mma<NPROD>(fa[i][1], fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][1], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][0], cc);
+                acc[i][j] = cc;
+            }
+    };
+
+    if (nit > 0) {
+        halo_gload(0);
+        H6_AGLOAD(0, 0);
+        H6_AGLOAD(1, 1);
+        halo_store(0);
+        H6_ASTORE(0, 0);
+        H6_AGLOAD(0, 2);
+        __syncthreads();
+        // iteration `it` = (slab it / 9, tap it % 9): MFMAs on weight image it & 1 and patch image slab & 1; weight stage (it + 1) & 1
+        // -> LDS, its registers then fetch tile it + 3; the NEXT slab's halo is fetched at tap 0 and split / stored at tap 4
+        int s = 0, tap = 0;
+#define H6_STEP(T_CUR, T_NXT, it_)                                                                                     \
+    do {                                                                                                              \
+        if (tap == 0 && s + 1 < ns) halo_gload(s + 1);                                                                \
+        compute(T_CUR, s & 1, tap);                                                                                   \
+        H6_ASTORE(T_NXT, T_NXT);                                                                                      \
+        H6_AGLOAD(T_NXT, (it_) + 3);                                                                                  \
+        if (tap == 4 && s + 1 < ns) halo_store((s + 1) & 1);                                                          \
+        __syncthreads();                                                                                              \
+        if (++tap == 9) { tap = 0; ++s; }                                                                             \
+    } while (0)
+        int it = 0;
+        for (; it + 1 < nit; it += 2) {
+            H6_STEP(0, 1, it);
+            H6_STEP(1, 0, it + 1);
+        }
+        if (it < nit) compute(0, s & 1, tap);      // (nit odd: the last tile sits in weight image 0)
+#undef H6_STEP
+    }
+#undef H6_AGLOAD
+#undef H6_ASTORE
+
+    // acc[i][j]: lane = pixel (ty0 + 2 wn + j, tx0 + col) ; register r = channel co0 + wm*64 + 32 i + (r&3) + 8 (r>>2) + 4 half
+    uint32_t omax = 0;
+    const bool first = blockIdx.y == 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int y = ty0 + 2 * wn + j, x = tx0 + col;
+        if (y >= H || x >= W) continue;
+        const int64_t obase = (int64_t)b_ * Co * HW + (int64_t)y * W + x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co >= Co) continue;
+                const int64_t o = obase + (int64_t)co * HW;
+                float t = (NPROD == 2 ? acc[i][j][r] * ia * ib : acc[i][j][r]) + ((bias && first) ? bias[co] : 0.f);
+                if (residual) { const float rv = residual[o]; if (gate) t = rv > 0.f ? t : 0.f; else if (first) t += rv; }
+                if (gridDim.y == 1) { out[o] = t; omax = max(omax, __builtin_bit_cast(uint32_t, t) & 0x7fffffffu); }
+                else atomicAdd(out + o, t);
+            }
+        }
+    }
+    if (amax_out && gridDim.y == 1) {
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
+        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
+    }
+}
+
 // Weight (+ bias) gradient of that convolution:  dw[co][ci][tap] = sum_{b,y,x} dy[b][co][y][x] * f(in[b][ci][y+ky-1][x+kx-1]).
 // GEMM view: A rows = co, B rows = r = tap * Ci + ci, contraction = the B*H*W output pixels, which are the CONTIGUOUS
 // dimension of both operands (NCHW): both loaders are the Linear kernel's activation loader (thread = (row, 8-pixel
@@ -1112,8 +1310,32 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
     const int np = x6_products();
     const uint32_t *am_in, *am_unused, *am_w = weight_amax(wp, Co, ksize * ksize * Ci);
     take_amax(am_in, am_unused);
+    uint32_t *am_out = x6_take_output_amax();
     if (np == 2 && !am_in) return VIT_EINVAL;
     (void)hipGetLastError();
+    // 3x3 layers at least one 32-pixel patch row wide: the halo kernel (one fetch / split per input element instead of nine)
+    static const bool taps_only = [] { const char *e = getenv("VIT_CONV3"); return e && e[0] == 't'; }();      // VIT_CONV3=taps: A/B switch
+    if (ksize == 3 && W >= 32 && !taps_only) {
+        const int64_t ht = (int64_t)((Co + x6::BM - 1) / x6::BM) * B * ((W + 31) / 32) * ((H + 3) / 4);
+        if (ht > 0x7fffffff) return VIT_EINVAL;
+        int S = 1;
+        const int nslab = Ci / x6::BK;
+        if (ht < 256) { S = (int)(512 / ht); while (S > 1 && nslab / S < 2) --S; if (S < 1) S = 1; if (S > 8) S = 8; }
+        if (S > 1 && !zero_fill(out, (size_t)NP * Co * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+#define VIT_LAUNCH_H6(RL)                                                                                                                                      \
+    do {                                                                                                                                                        \
+        if (np == 3) hipLaunchKernelGGL((x6::k_conv3h_x6<RL, 3>), dim3((unsigned)ht, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in, am_out); \
+        else if (np == 2) hipLaunchKernelGGL((x6::k_conv3h_x6<RL, 2>), dim3((unsigned)ht, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in, am_out); \
+        else hipLaunchKernelGGL((x6::k_conv3h_x6<RL, 6>), dim3((unsigned)ht, S), dim3(256), 0, stream, in, w4, bias, residual, out, B, Ci, Co, H, W, gate, am_w, am_in, am_out);      \
+    } while (0)
+        if (relu_in) VIT_LAUNCH_H6(true); else VIT_LAUNCH_H6(false);
+#undef VIT_LAUNCH_H6
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+        if (am_out && S > 1) return amax(out, NP * Co, am_out, stream);      // partial sums: the |max| of the result needs its own pass
+        return VIT_OK;
+    }
+    if (am_out) return VIT_EINVAL;          // (only the halo kernel publishes its output's |max|)
     // few output tiles: split the K slabs so that tiles x S fills the 512 resident workgroups, >= 8 slabs per split
     int S = 1;
     const int nslab = ksize * ksize * Ci / x6::BK;

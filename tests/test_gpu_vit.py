@@ -464,7 +464,9 @@ def test_split_cache_never_serves_a_dead_tensors_entry():
 
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,k,bias", [(2, 32, 64, 9, 13, 3, True), (1, 16, 130, 17, 5, 3, False), (3, 48, 128, 8, 8, 1, True),
-                                                 (2, 256, 256, 32, 32, 3, True), (1, 96, 256, 16, 24, 3, False)])
+                                                 (2, 256, 256, 32, 32, 3, True), (1, 96, 256, 16, 24, 3, False),
+                                                 # W >= 32: the halo kernel (k_conv3h_x6): ragged patches (H % 4, W % 32 != 0), one patch row, Co not a multiple of 128
+                                                 (2, 32, 64, 37, 45, 3, True), (1, 16, 130, 6, 70, 3, False), (3, 64, 96, 4, 32, 3, True), (1, 512, 128, 33, 33, 3, True)])
 def test_conv_x6_matches_fp64_forward_and_backward(B, Ci, Co, H, W, k, bias, monkeypatch):
     """Conv2dX6 (bf16x6 implicit GEMM: forward + input gradient; library weight gradient) vs an fp64 convolution"""
     from styl3r_amd.vit_ops import Conv2dX6
@@ -506,7 +508,7 @@ def test_conv_x6_weight_gradient_kernel_matches_fp64(B, Ci, Co, H, W, k):
     assert_close_rel(m.bias.grad.cpu().numpy(), bd.grad.cpu().numpy(), 5e-6, "conv db (x6)")
 
 
-@pytest.mark.parametrize("B,C,H,W,force", [(2, 32, 9, 13, True), (1, 144, 17, 8, True), (16, 32, 64, 64, True), (2, 32, 8, 8, False)])
+@pytest.mark.parametrize("B,C,H,W,force", [(2, 32, 9, 13, True), (1, 144, 17, 8, True), (16, 32, 64, 64, True), (2, 32, 8, 8, False), (2, 48, 19, 41, True)])
 def test_residual_conv_unit_fused_relu_and_skip_match_fp64(B, C, H, W, force, monkeypatch):
     """_ResidualConvUnit (dpt_block.py:79-118: conv2(relu(conv1(relu(x)))) + x) with both ReLUs and the skip add inside the
     convolution kernels (relu_in staging, residual epilogue; backward: sign-gate epilogue of the dX launch, relu_in in the
