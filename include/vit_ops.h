@@ -102,7 +102,7 @@ int vit_linear_fwd(const float *x, const float *w, const float *bias, const floa
  *   transpose = 0: w (rows = N, cols = K)  ->  packed weight for  out = x . w^T       (the forward, nn.Linear)
  *   transpose = 1: w (rows = N, cols = K)  ->  packed w^T for     dX  = dY . w        (the input gradient):
  *                  call vit_linear_x6_fwd(dY, packed, NULL, NULL, dX, NULL, M, K, N, 0)
- * `packed` holds vit_split_weight_bytes(rows, cols) = 6 bytes per element (+ 256: the 32-bit word right behind the pieces carries the
+ * `packed` holds vit_split_weight_bytes(rows, cols) = 6 bytes per element (+ 8 KiB: the |max| word right behind the pieces carries the
  * weight's |max| bit pattern in the f16x3 mode), layout [out_row][k/8][piece][8] bf16.
  * The contraction length must be a multiple of 16.
  */
@@ -116,8 +116,9 @@ size_t vit_split_weight_bytes(int rows, int cols);
  * n = 2 selects "f16x3": every operand is split into TWO fp16 pieces (11-bit significands) of value * s, s = the power of two that puts
  * the operand TENSOR's absolute maximum into [2^14, 2^15), and the three products h h' + h l' + l h' run on v_mfma_f32_32x32x16_f16:
  * 2^-22 per product (bf16x3: 2^-16; bf16x6: 2^-24) at the MFMA count and data path of bf16x3.  The kernels then need the |max| of their
- * ACTIVATION operands: compute it with vit_amax (an exact integer max over the fp32 bit patterns of |x|; `out_word` must hold 0 before the
- * launch; several launches may accumulate into one word) and announce the device addresses with vit_x6_set_operand_amax right before the
+ * ACTIVATION operands: compute it with vit_amax (an exact integer max over the fp32 bit patterns of |x|.  A "word" is 64 uint32 slots, one per 128-byte cache
+ * line -- 8 KiB, 4-byte aligned: producers fold their maxima into slot (workgroup + wave) & 63, readers take the max over the slots, so no
+ * single cache line sees thousands of serialised atomics; the 8 KiB must hold zeros before the launch; several launches may accumulate into one word) and announce the device addresses with vit_x6_set_operand_amax right before the
  * launch they belong to, on the launching thread: a = x for vit_linear_x6_fwd / vit_conv_x6_fwd (forward and input-gradient uses alike),
  * a = dY, b = x for vit_linear_x6_wgrad / vit_linear_x6_wgrad_acc / vit_conv_x6_wgrad.  The pair is consumed by that launch; a launch in
  * this mode without it returns VIT_EINVAL (no guessed scale, no fallback).  Weights get their scale inside vit_split_weight (called in
@@ -126,9 +127,10 @@ size_t vit_split_weight_bytes(int rows, int cols);
 int vit_x6_set_products(int n);
 int vit_x6_products(void);
 int vit_x6_set_operand_amax(const void *a_word, const void *b_word);
-/* `word` (zeroed): the next vit_linear_x6_fwd / vit_linear_x6r_fwd (cfg 1) launch on this thread writes the |max| of its OUTPUT there -- its
- * epilogue sees every value it stores -- so the consumer of that output needs no vit_amax pass of its own.  Any arithmetic mode.  Consumed by
- * that launch; one that cannot honour it (split-K partial sums, the 256 x 256 ring kernels) returns VIT_EINVAL. */
+/* `word` (zeroed): the next vit_linear_x6_fwd / vit_linear_x6r_fwd (cfg 1, 3) / vit_conv_x6_fwd / vit_layernorm_fwd / vit_layernorm_bwd launch on
+ * this thread writes the |max| of its OUTPUT there -- the epilogue sees every value it stores -- so the consumer of that output needs no vit_amax
+ * pass of its own.  Any arithmetic mode.  Consumed by that launch; launches whose workgroups only see partial sums (split-K) and the kernels
+ * without the epilogue hook (k_conv_x6) run a vit_amax pass over their result instead; the lockstep ring kernel (cfg 2) returns VIT_EINVAL. */
 int vit_x6_set_output_amax(void *word);
 int vit_amax(const float *x, int64_t n, void *out_word, void *stream);
 int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream);

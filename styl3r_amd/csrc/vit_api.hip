@@ -90,8 +90,8 @@ VIT_EXPORT int vit_linear_fwd(const float *x, const float *w, const float *bias,
     return vit::linear_fwd(x, w, bias, residual, out, pre, M, N, K, act, static_cast<hipStream_t>(stream));
 }
 
-// (+ 256: the word right behind the pieces carries the weight's |max| in the f16x3 mode, vit_x6_set_products(2))
-VIT_EXPORT size_t vit_split_weight_bytes(int rows, int cols) { return (size_t)rows * (size_t)cols * 6 + 256; }
+// (+ 8 KiB: the |max| word -- 64 slots, one per cache line -- of the f16x3 mode right behind the pieces, vit_x6_set_products(2))
+VIT_EXPORT size_t vit_split_weight_bytes(int rows, int cols) { return (size_t)rows * (size_t)cols * 6 + 8192; }
 
 VIT_EXPORT int vit_split_weight(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
 {
@@ -120,7 +120,7 @@ VIT_EXPORT int vit_amax(const float *x, int64_t n, void *out_word, void *stream)
 VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose)
 {
     const size_t R = transpose ? cols : rows, K = transpose ? rows : cols;
-    return ((R + 63) / 64) * 64 * K * 6 + 256;       // (+ 256: the weight's |max| word of the f16x3 mode sits right behind the pieces)
+    return ((R + 63) / 64) * 64 * K * 6 + 8192;      // (+ 8 KiB: the weight's |max| word of the f16x3 mode sits right behind the pieces)
 }
 
 VIT_EXPORT int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream)

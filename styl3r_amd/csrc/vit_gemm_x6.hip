@@ -120,6 +120,25 @@ __device__ inline void split8(const float4 &lo, const float4 &hi, uint4 &q0, uin
 // max over the fp32 bit patterns): 2^14 <= amax s < 2^15.  Elements down to 2^-17 amax keep all 22 bits, smaller ones an absolute error of
 // 2^-39 amax -- below the fp32 rounding of any sum they enter.  Scales are powers of two, so scaling and un-scaling are exact; the epilogue
 // multiplies the fp32 accumulator by the two inverse scales.
+// An "|max| word" is 64 words, ONE PER 128-BYTE CACHE LINE (8 KiB in all): producers fold their maxima into word (workgroup id + wave) & 63.
+// L2 atomics serialise per cache line at ~10 ns each -- thousands of waves folding into one line cost 20 - 50 us per launch (measured: +9 ms per
+// train step from the LayerNorm epilogues alone, and no better with 64 words packed into two lines); spread over 64 lines they run in parallel
+// channels.  Readers take the max over the 64 words with one gather load and a wave reduction.
+constexpr int AMAX_STRIDE = 32;        // words between the 64 slots
+__device__ inline uint32_t amax_line(const uint32_t *__restrict__ line)
+{
+    uint32_t m = line[(threadIdx.x & 63) * AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    return m;
+}
+__device__ inline void amax_fold(uint32_t *__restrict__ line, uint32_t m)     // m: this lane's maximum; one guarded atomic per wave
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    uint32_t *w = line + ((blockIdx.x + 7u * blockIdx.y + (threadIdx.x >> 6)) & 63u) * AMAX_STRIDE;
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, m);
+}
 __device__ inline float f16_scale(uint32_t amax_bits)
 {
     const int e = (int)((amax_bits >> 23) & 0xff);
@@ -159,7 +178,7 @@ template <int NPROD> __device__ inline f32x16 mma(const bf16x8 &a, const bf16x8 
 }
 
 // absolute maximum of a tensor as the bit pattern of |x| (monotone for non-negative floats; a NaN wins, so it stays visible): one
-// atomicMax per workgroup into a pre-zeroed word
+// guarded atomicMax per wave into a pre-zeroed 64-word line (amax_fold)
 __global__ void __launch_bounds__(256) k_amax(const float *__restrict__ x, int64_t n, uint32_t *__restrict__ out)
 {
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -178,17 +197,7 @@ __global__ void __launch_bounds__(256) k_amax(const float *__restrict__ x, int64
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = max(m, __builtin_bit_cast(uint32_t, x[i]) & 0x7fffffffu);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    __shared__ uint32_t part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t bm = max(max(part[0], part[1]), max(part[2], part[3]));
-        // (a plain look first: after the first few workgroups nearly every block's maximum is already covered, and ~1 300 serialised
-        // atomics on one word were most of the pass on the 21 MB activations: 17 us against 4 us of memory time)
-        if (bm > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bm);
-    }
+    amax_fold(out, m);
 }
 
 // SPLITK: gridDim.y workgroups share one output tile, each contracting its own range of K slabs and adding its partial
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
     uint32_t omax = 0;          // |max| of the values this lane stores (published to *amax_out: the consumer's f16x3 scale without a pass of its own)
     // f16x3: scale of the activation tensor (applied while it is split) and the two inverse scales of the epilogue
     float sx = 1.f, ix = 1.f, iw = 1.f;
-    if (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
+    if (NPROD == 2) { sx = f16_scale(amax_line(amax_x)); ix = 1.f / sx; iw = 1.f / f16_scale(amax_line(amax_w)); }
     // (the 64-row B tile is allocated at the 128-row size: keeps the narrow variant at three workgroups per CU; four
     // thrash the L2 on the N = 1024 layers: measured -5 %)
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][128 * ROWQ];
@@ -361,9 +370,7 @@ __global__ void __launch_bounds__(256, 3) k_linear_x6(const float *__restrict__ 
         }
     }
     if (!SPLITK && amax_out) {   // (wave-uniform branch; one atomic per wave)
-#pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
-        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
+        amax_fold(amax_out, omax);
     }
 }
 
@@ -381,7 +388,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_x6(const float *__restrict__ d
 {
     constexpr int TN = 2, BN = 128;
     float sa = 1.f, sb = 1.f, ia = 1.f, ib = 1.f;          // f16x3: tensor scales of dY and X, their inverses for the epilogue
-    if (NPROD == 2) { sa = f16_scale(*amax_dy); sb = f16_scale(*amax_x); ia = 1.f / sa; ib = 1.f / sb; }
+    if (NPROD == 2) { sa = f16_scale(amax_line(amax_dy)); sb = f16_scale(amax_line(amax_x)); ia = 1.f / sa; ib = 1.f / sb; }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -556,7 +563,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_x6(const float *__restrict__ in
 {
     constexpr int TN = 2, BN = 128, TAPS = KS * KS;
     float sb = 1.f, ia = 1.f, ib = 1.f;                     // f16x3: activation scale (rides in the border mask), inverse scales
-    if (NPROD == 2) { sb = f16_scale(*amax_in); ib = 1.f / sb; ia = 1.f / f16_scale(*amax_w); }
+    if (NPROD == 2) { sb = f16_scale(amax_line(amax_in)); ib = 1.f / sb; ia = 1.f / f16_scale(amax_line(amax_w)); }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -714,7 +721,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3h_x6(const float *__restrict__ 
     constexpr int TY = 4, TX = 32, HY = TY + 2, HX = TX + 2, HP = HY * HX;      // 204 halo pixels
     __shared__ uint4 sA[2][BM * ROWQ], sP[2][HP * ROWQ];                         // 24 KB + 38.25 KB
     float sb = 1.f, ia = 1.f, ib = 1.f;                     // f16x3: activation scale (rides in the border mask), inverse scales
-    if (NPROD == 2) { sb = f16_scale(*amax_in); ib = 1.f / sb; ia = 1.f / f16_scale(*amax_w); }
+    if (NPROD == 2) { sb = f16_scale(amax_line(amax_in)); ib = 1.f / sb; ia = 1.f / f16_scale(amax_line(amax_w)); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
@@ -886,9 +893,7 @@ __global__ void __launch_bounds__(256, 2) k_conv3h_x6(const float *__restrict__ 
         }
     }
     if (amax_out && gridDim.y == 1) {
-#pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
-        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
+        amax_fold(amax_out, omax);
     }
 }
 
@@ -908,7 +913,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
 {
     constexpr int TN = 2, BN = 128, TAPS = KS * KS;
     float sa = 1.f, sb = 1.f, ia = 1.f, ib = 1.f;          // f16x3: tensor scales of dY and the input (the latter rides in the row mask)
-    if (NPROD == 2) { sa = f16_scale(*amax_dy); sb = f16_scale(*amax_in); ia = 1.f / sa; ib = 1.f / sb; }
+    if (NPROD == 2) { sa = f16_scale(amax_line(amax_dy)); sb = f16_scale(amax_line(amax_in)); ia = 1.f / sa; ib = 1.f / sb; }
     __shared__ uint4 sA[2][BM * ROWQ], sB[2][BN * ROWQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
@@ -1053,17 +1058,18 @@ __global__ void __launch_bounds__(256, 2) k_conv_wgrad_x6(const float *__restric
 // w (R, C) row-major fp32 -> packed[r][c/8][piece][8] bf16.  transpose = 0: (r, c) = (row, col) of w, R x C = rows x cols.
 // transpose = 1: packs w^T, i.e. output row r = column r of w, output k index = row of w (tiled through LDS so both the
 // reads and the writes stay coalesced).
-// NPROD == 2 ("f16x3"): two fp16 pieces of w * f16_scale(*amax) in slots 0 / 1 (slot 2 is never read in that mode)
+// NPROD == 2 ("f16x3"): two fp16 pieces of w * f16_scale(amax_line(amax)) in slots 0 / 1 (slot 2 is never read in that mode)
 template <int NPROD>
 __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ w, uint4 *__restrict__ packed, int64_t groups,
                                                     const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-wide k group per thread
-    if (NPROD == 2 && g == 0) *tail = *amax;                            // the scale the kernels that read this image must undo
+    if (NPROD == 2 && blockIdx.x == 0 && threadIdx.x < 64) tail[threadIdx.x * AMAX_STRIDE] = amax[threadIdx.x * AMAX_STRIDE];      // the line the kernels that read this image take their inverse scale from
+    const float sw = NPROD == 2 ? f16_scale(amax_line(amax)) : 1.f;     // (whole waves: before any lane leaves)
     if (g >= groups) return;
     const float4 lo = reinterpret_cast<const float4 *>(w)[g * 2], hi = reinterpret_cast<const float4 *>(w)[g * 2 + 1];
     uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
-    split8s<NPROD>(lo, hi, NPROD == 2 ? f16_scale(*amax) : 1.f, q0, q1, q2);
+    split8s<NPROD>(lo, hi, sw, q0, q1, q2);
     packed[g * 3 + 0] = q0; packed[g * 3 + 1] = q1; if (NPROD != 2) packed[g * 3 + 2] = q2;
 }
 
@@ -1071,7 +1077,8 @@ template <int NPROD>
 __global__ void __launch_bounds__(256) k_split_transposed(const float *__restrict__ w, uint4 *__restrict__ packed, int rows,
                                                           int cols, const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
-    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tail = *amax;
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) tail[threadIdx.x * AMAX_STRIDE] = amax[threadIdx.x * AMAX_STRIDE];
+    const float sw = NPROD == 2 ? f16_scale(amax_line(amax)) : 1.f;     // (whole waves: before any lane leaves)
     // tile: 64 source rows (-> k of the output) x 32 source columns (-> output rows)
     __shared__ float s[64][33];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 32;
@@ -1085,7 +1092,7 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
     float4 lo = make_float4(s[kg * 8 + 0][c], s[kg * 8 + 1][c], s[kg * 8 + 2][c], s[kg * 8 + 3][c]);
     float4 hi = make_float4(s[kg * 8 + 4][c], s[kg * 8 + 5][c], s[kg * 8 + 6][c], s[kg * 8 + 7][c]);
     uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
-    split8s<NPROD>(lo, hi, NPROD == 2 ? f16_scale(*amax) : 1.f, q0, q1, q2);
+    split8s<NPROD>(lo, hi, sw, q0, q1, q2);
     uint4 *o = packed + ((int64_t)(c0 + c) * (rows >> 3) + (r0 >> 3) + kg) * 3;
     o[0] = q0; o[1] = q1; if (NPROD != 2) o[2] = q2;
 }
@@ -1117,7 +1124,7 @@ int x6_set_operand_amax(const void *a, const void *b)
 static thread_local uint32_t *g_amax_out = nullptr;
 // Device address of a ZEROED word that the NEXT vit_linear_x6_fwd / vit_linear_x6r_fwd launch on this thread fills with the |max| of the
 // values it stores (its epilogue sees every one of them): the consumer of that output then needs no vit_amax pass.  Consumed by that
-// launch; a launch that cannot honour it (split-K partial sums) returns VIT_EINVAL.
+// launch (split-K launches run a vit_amax pass over their result instead).
 int x6_set_output_amax(void *word) { g_amax_out = static_cast<uint32_t *>(word); return VIT_OK; }
 uint32_t *x6_take_output_amax() { uint32_t *p = g_amax_out; g_amax_out = nullptr; return p; }
 static void take_amax(const uint32_t *&a, const uint32_t *&b) { a = g_amax_a; b = g_amax_b; g_amax_a = g_amax_b = nullptr; }
@@ -1169,7 +1176,7 @@ int split_weight(const float *w, void *packed, int rows, int cols, int transpose
     const uint32_t *am, *unused;
     take_amax(am, unused);
     if (f16 && !am) {
-        if (!zero_fill(tail, 4, stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
+        if (!zero_fill(tail, 8192, stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
         const int rc = amax(w, (int64_t)rows * cols, tail, stream);
         if (rc != VIT_OK) return rc;
         am = tail;
@@ -1219,7 +1226,6 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
         while (S < 8 && tiles * S * 2 <= 768 && nk / (S * 2) >= 8) S *= 2;
     }
     if (S > 1) {
-        if (am_out) return VIT_EINVAL;             // partial sums: no workgroup sees a final value
         if (!zero_fill(out, (size_t)M * N * sizeof(float), stream)) { g_last_hip_error = hipGetLastError(); return VIT_ELAUNCH; }
 #define VIT_LAUNCH_X6S(TN, NP) hipLaunchKernelGGL((x6::k_linear_x6<0, TN, true, NP>), dim3(tiles, S), dim3(256), 0, stream, x, w4, bias, residual, out, pre, M, N, K, am_x, am_w, am_out)
         if (np == 3) { if (narrow) VIT_LAUNCH_X6S(1, 3); else VIT_LAUNCH_X6S(2, 3); }
@@ -1240,6 +1246,7 @@ int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    if (am_out && S > 1) return amax(out, (int64_t)M * N, am_out, stream);      // split-K partial sums: the |max| of the result needs its own pass
     return VIT_OK;
 }
 
@@ -1335,7 +1342,6 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
         if (am_out && S > 1) return amax(out, NP * Co, am_out, stream);      // partial sums: the |max| of the result needs its own pass
         return VIT_OK;
     }
-    if (am_out) return VIT_EINVAL;          // (only the halo kernel publishes its output's |max|)
     // few output tiles: split the K slabs so that tiles x S fills the 512 resident workgroups, >= 8 slabs per split
     int S = 1;
     const int nslab = ksize * ksize * Ci / x6::BK;
@@ -1352,6 +1358,7 @@ int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float 
 #undef VIT_LAUNCH_C6
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    if (am_out) return amax(out, NP * Co, am_out, stream);      // (k_conv_x6 does not publish its output's |max| itself: one pass here)
     return VIT_OK;
 }
 int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,

@@ -81,6 +81,25 @@ template <typename V4> __device__ inline void split8(const V4 &lo, const V4 &hi,
 }
 
 // ---- "f16x3" (NPROD == 2; see vit_gemm_x6.hip): two fp16 pieces of value * 2^k, k from the operand tensor's |max| ---------------
+// An "|max| word" is 64 words, ONE PER 128-BYTE CACHE LINE (8 KiB in all): producers fold their maxima into word (workgroup id + wave) & 63.
+// L2 atomics serialise per cache line at ~10 ns each -- thousands of waves folding into one line cost 20 - 50 us per launch (measured: +9 ms per
+// train step from the LayerNorm epilogues alone, and no better with 64 words packed into two lines); spread over 64 lines they run in parallel
+// channels.  Readers take the max over the 64 words with one gather load and a wave reduction.
+constexpr int AMAX_STRIDE = 32;        // words between the 64 slots
+__device__ inline uint32_t amax_line(const uint32_t *__restrict__ line)
+{
+    uint32_t m = line[(threadIdx.x & 63) * AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    return m;
+}
+__device__ inline void amax_fold(uint32_t *__restrict__ line, uint32_t m)     // m: this lane's maximum; one guarded atomic per wave
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    uint32_t *w = line + ((blockIdx.x + 7u * blockIdx.y + (threadIdx.x >> 6)) & 63u) * AMAX_STRIDE;
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, m);
+}
 __device__ inline float f16_scale(uint32_t amax_bits)
 {
     const int e = (int)((amax_bits >> 23) & 0xff);
@@ -174,7 +193,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the launch stub; it has no amdgcn builtins / asm constraints)
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
     float sx = 1.f, ix = 1.f, iw = 1.f;           // f16x3: activation scale (applied at the fragment split), inverse scales of the epilogue
-    if constexpr (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
+    if constexpr (NPROD == 2) { sx = f16_scale(amax_line(amax_x)); ix = 1.f / sx; iw = 1.f / f16_scale(amax_line(amax_w)); }
     constexpr int A_BYTES = BM * 64, B_BYTES = BN * 96, ST_BYTES = A_BYTES + B_BYTES;
     constexpr int A_CH = BM / 16, B_CH = 6 * (BN / 64), CH = A_CH + B_CH, CPW = (CH + NW - 1) / NW;   // 1 KiB DMA chunks per stage, per wave
     static_assert(BM % 64 == 0 && BN % 64 == 0 && RM >= 1 && (RN == 1 || RN == 2), "tile shape");
@@ -317,9 +336,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) k_linear_x6r(const float *_
         }
     }
     if (amax_out) {             // |max| of the stored values (see vit_x6_set_output_amax): one atomic per wave
-#pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
-        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
+        amax_fold(amax_out, omax);
     }
 #endif
 }
@@ -362,7 +379,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     float sx = 1.f, ix = 1.f, iw = 1.f;           // f16x3: activation scale (applied by the converter), inverse scales of the epilogue
-    if constexpr (NPROD == 2) { sx = f16_scale(*amax_x); ix = 1.f / sx; iw = 1.f / f16_scale(*amax_w); }
+    if constexpr (NPROD == 2) { sx = f16_scale(amax_line(amax_x)); ix = 1.f / sx; iw = 1.f / f16_scale(amax_line(amax_w)); }
     constexpr int NW = WM * WN, RM = BM / WM / 32, RN = BN / WN / 32;
     constexpr int RAW_BYTES = BM * 64, B_BYTES = BN * 96, AC_BYTES = BM * 96;
     constexpr int RAW0 = 0, B0 = 3 * RAW_BYTES, AC0 = B0 + 2 * B_BYTES, LDS_BYTES = AC0 + 2 * AC_BYTES;   // raw ring of 3
@@ -645,9 +662,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 1) k_linear_x6c(const float *__r
         }
     }
     if (amax_out) {             // |max| of the stored values (vit_x6_set_output_amax): one atomic per wave
-#pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) omax = max(omax, (uint32_t)__shfl_xor((int)omax, o_, 64));
-        if (lane == 0 && omax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, omax);
+        amax_fold(amax_out, omax);
     }
 #endif
 }
@@ -658,8 +673,8 @@ template <int NPROD>
 __global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w, uint4 *__restrict__ packed, int rows, int cols,
                                                      int transpose, const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail)
 {
-    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *tail = *amax;     // the scale the readers of this image undo
-    const float sw = NPROD == 2 ? f16_scale(*amax) : 1.f;
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) tail[threadIdx.x * AMAX_STRIDE] = amax[threadIdx.x * AMAX_STRIDE];     // the line the readers of this image take their inverse scale from
+    const float sw = NPROD == 2 ? f16_scale(amax_line(amax)) : 1.f;
     // output rows R_ = transpose ? cols : rows, contraction length K_ = transpose ? rows : cols
     const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols, KG = K_ >> 3;
     __shared__ float s[64][65];                       // [output row][k]: 64 rows x 64 k (8 k groups)

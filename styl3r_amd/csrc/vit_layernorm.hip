@@ -20,6 +20,7 @@
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
+uint32_t *x6_take_output_amax();                                 // vit_gemm_x6.hip
 
 namespace {
 constexpr int LN_MAX_N4 = 8;        // C <= 2048
@@ -32,13 +33,29 @@ __device__ inline float wave_sum(float v)
     return v;
 }
 
+__device__ inline uint32_t abs_bits4(const float4 &o)
+{
+    return max(max(__builtin_bit_cast(uint32_t, o.x) & 0x7fffffffu, __builtin_bit_cast(uint32_t, o.y) & 0x7fffffffu),
+               max(__builtin_bit_cast(uint32_t, o.z) & 0x7fffffffu, __builtin_bit_cast(uint32_t, o.w) & 0x7fffffffu));
+}
+__device__ inline void publish_amax(uint32_t *amax_out, uint32_t m, int lane)     // one guarded atomic per wave, spread over the 64-word line
+{
+    if (!amax_out) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    uint32_t *w = amax_out + ((blockIdx.x + (threadIdx.x >> 6)) & 63u) * 32;      // (64 slots, one per 128-byte line: vit_gemm_x6.hip AMAX_STRIDE)
+    if (lane == 0 && m > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, m);
+}
+
 template <int N4>
 __global__ void __launch_bounds__(256) k_ln_fwd(const float *__restrict__ x, const float *__restrict__ gamma,
                                                 const float *__restrict__ beta, float *__restrict__ y,
-                                                float *__restrict__ mean, float *__restrict__ rstd, int M, float eps)
+                                                float *__restrict__ mean, float *__restrict__ rstd, int M, float eps,
+                                                uint32_t *__restrict__ amax_out)
 {
     constexpr int C = N4 * 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t omax = 0;          // |max| of the stored values, published for the f16x3 consumer (vit_x6_set_output_amax)
     float4 gm[N4], bt[N4];
 #pragma unroll
     for (int j = 0; j < N4; ++j) {
@@ -61,22 +78,27 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float *__restrict__ x, con
         const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
         float4 *yr = reinterpret_cast<float4 *>(y + (int64_t)row * C);
 #pragma unroll
-        for (int j = 0; j < N4; ++j)
-            yr[j * 64 + lane] = make_float4(v[j].x * rs * gm[j].x + bt[j].x, v[j].y * rs * gm[j].y + bt[j].y,
-                                            v[j].z * rs * gm[j].z + bt[j].z, v[j].w * rs * gm[j].w + bt[j].w);
+        for (int j = 0; j < N4; ++j) {
+            const float4 o = make_float4(v[j].x * rs * gm[j].x + bt[j].x, v[j].y * rs * gm[j].y + bt[j].y,
+                                         v[j].z * rs * gm[j].z + bt[j].z, v[j].w * rs * gm[j].w + bt[j].w);
+            yr[j * 64 + lane] = o;
+            omax = max(omax, abs_bits4(o));
+        }
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
+    publish_amax(amax_out, omax, lane);
 }
 
 template <int N4>
 __global__ void __launch_bounds__(256) k_ln_bwd(const float *__restrict__ dy, const float *__restrict__ x,
                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                 const float *__restrict__ gamma, const float *__restrict__ dskip,
-                                                float *__restrict__ dx, float *__restrict__ partial, int M)
+                                                float *__restrict__ dx, float *__restrict__ partial, int M, uint32_t *__restrict__ amax_out)
 {
     constexpr int C = N4 * 256;
     __shared__ float4 s_red[3][2 * N4 * 64];     // waves 1..3 hand their column sums to wave 0
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t omax = 0;
     float4 gm[N4], dg[N4], db[N4];
 #pragma unroll
     for (int j = 0; j < N4; ++j) {
@@ -109,8 +131,10 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const float *__restrict__ dy, co
                                    rs * (g[j].z - c2 - xh[j].z * c1), rs * (g[j].w - c2 - xh[j].w * c1));
             if (sr) { const float4 sv = sr[j * 64 + lane]; o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w; }
             dr[j * 64 + lane] = o;
+            omax = max(omax, abs_bits4(o));
         }
     }
+    publish_amax(amax_out, omax, lane);
     // column sums of the workgroup -> partial[blockIdx.x][0..C) = dgamma, [C..2C) = dbeta
     if (wave > 0) {
 #pragma unroll
@@ -172,8 +196,9 @@ int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *
 {
     if (!x || !gamma || !y || !mean || !rstd || M <= 0 || C <= 0 || (C % 256) != 0 || C / 256 > LN_MAX_N4) return VIT_EINVAL;
     const int blocks = (M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048;
+    uint32_t *am_out = x6_take_output_amax();      // (vit_x6_set_output_amax: the |max| of y for an f16x3 consumer)
     (void)hipGetLastError();
-#define VIT_LN_F(N4) case N4: hipLaunchKernelGGL(k_ln_fwd<N4>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, eps); break
+#define VIT_LN_F(N4) case N4: hipLaunchKernelGGL(k_ln_fwd<N4>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, eps, am_out); break
     switch (C / 256) { VIT_LN_F(1); VIT_LN_F(2); VIT_LN_F(3); VIT_LN_F(4); VIT_LN_F(5); VIT_LN_F(6); VIT_LN_F(7); VIT_LN_F(8); }
 #undef VIT_LN_F
     hipError_t e = hipGetLastError();
@@ -187,8 +212,9 @@ int layernorm_bwd(const float *dy, const float *x, const float *mean, const floa
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !scratch || M <= 0 || (C % 256) != 0 || C / 256 > LN_MAX_N4)
         return VIT_EINVAL;
     const int blocks = ln_blocks(M);
+    uint32_t *am_out = x6_take_output_amax();      // (the |max| of dx)
     (void)hipGetLastError();
-#define VIT_LN_B(N4) case N4: hipLaunchKernelGGL(k_ln_bwd<N4>, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dskip, dx, scratch, M); break
+#define VIT_LN_B(N4) case N4: hipLaunchKernelGGL(k_ln_bwd<N4>, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dskip, dx, scratch, M, am_out); break
     switch (C / 256) { VIT_LN_B(1); VIT_LN_B(2); VIT_LN_B(3); VIT_LN_B(4); VIT_LN_B(5); VIT_LN_B(6); VIT_LN_B(7); VIT_LN_B(8); }
 #undef VIT_LN_B
     hipLaunchKernelGGL(k_ln_param_reduce, dim3(2 * C / 32), dim3(256), 0, stream, scratch, dgamma, dbeta, blocks, C, accumulate);

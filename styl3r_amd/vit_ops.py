@@ -474,28 +474,83 @@ def _f16() -> bool:
 
 
 class _AmaxArena:
-    """zero-initialised 32-bit words for vit_amax results (one per activation tensor per use): handed out in order from a device buffer
-    that is replaced -- one allocation + one fill -- when it runs out; words still referenced (saved for a backward) keep their buffer alive"""
+    """zero-initialised |max| "words" for vit_amax results (one per activation tensor per use).  A word is 64 int32 slots, ONE PER 128-BYTE CACHE
+    LINE (8 KiB): producers fold their maxima into slot (workgroup + wave) & 63 -- atomics on one cache line serialise in the L2, thousands of
+    them cost tens of microseconds per launch -- and readers take the max over the slots (csrc/vit_gemm_x6.hip amax_fold / amax_line).  Words
+    are handed out in order from a device buffer that is replaced -- one allocation + one fill -- when it runs out; words still referenced
+    (saved for a backward) keep their buffer alive"""
+    LINE = 64 * 32
 
-    def __init__(self, words: int = 8192):
-        self.words, self.buf, self.next = words, {}, {}
+    def __init__(self, lines: int = 512):
+        self.lines, self.buf, self.next = lines, {}, {}
 
     def word(self, dev) -> Tensor:
-        i = self.next.get(dev, self.words)
-        if i >= self.words:
-            self.buf[dev] = torch.zeros(self.words, dtype=torch.int32, device=dev)
+        i = self.next.get(dev, self.lines)
+        if i >= self.lines:
+            self.buf[dev] = torch.zeros(self.lines * self.LINE, dtype=torch.int32, device=dev)
             i = 0
         self.next[dev] = i + 1
-        return self.buf[dev][i:i + 1]
+        return self.buf[dev][i * self.LINE:(i + 1) * self.LINE]
 
 
 _AMAX = _AmaxArena()
 
 
 def _amax_word(t: Tensor) -> Tensor:
-    """|max| of a contiguous fp32 device tensor as the bit pattern of a non-negative float in a 1-element int32 tensor (vit_amax)"""
+    """|max| of a contiguous fp32 device tensor as a |max| word (vit_amax; 64 slots, 8 KiB): its largest entry is the bit pattern of the maximum"""
     w = _AMAX.word(t.device)
     _check(load().vit_amax(t.data_ptr(), t.numel(), w.data_ptr(), _stream(t.device)), "vit_amax")
+    return w
+
+
+# |max| words PUBLISHED by the kernel that produced a tensor (vit_x6_set_output_amax: LayerNorm forward / backward, the GEMM and halo-convolution
+# epilogues): the f16x3 consumer of that tensor finds the word here instead of running a vit_amax pass.  Keyed by the tensor's memory; an entry
+# holds a WEAK reference to the producing tensor object and is valid only while that object is alive (its memory cannot have been reused), still
+# starts at the same address and carries the version it was published with (no in-place write since).  Views / reshapes of the tensor match too.
+_PUBLISHED: dict = {}        # (data_ptr, numel) -> (weakref(tensor), _version, word)
+
+
+def _publish(t: Tensor, word: Tensor) -> None:
+    key = (t.data_ptr(), t.numel())
+
+    def drop(ref, key=key):
+        h = _PUBLISHED.get(key)
+        if h is not None and h[0] is ref:
+            del _PUBLISHED[key]
+    _PUBLISHED[key] = (weakref.ref(t, drop), t._version, word)
+
+
+PUBLISH_AMAX = os.environ.get("VIT_PUBLISH_AMAX", "1") == "1"      # A/B switch: 0 = every f16x3 operand scale comes from its own vit_amax pass
+
+
+def _known_amax(t: Tensor) -> Optional[Tensor]:
+    if not PUBLISH_AMAX:
+        return None
+    hit = _PUBLISHED.get((t.data_ptr(), t.numel()))
+    if hit is None:
+        return None
+    src = hit[0]()
+    if src is None or src.data_ptr() != t.data_ptr() or src._version != hit[1] or t._version != hit[1]:
+        return None
+    return hit[2]
+
+
+def _amax_of(t: Tensor) -> Tensor:
+    """|max| word of a contiguous fp32 device tensor: the one its producer published, else a vit_amax pass"""
+    w = _known_amax(t)
+    if w is not None:
+        CALLS["amax_published"] += 1
+        return w
+    CALLS["amax_pass"] += 1
+    return _amax_word(t)
+
+
+def _want_output_amax(dev) -> Optional[Tensor]:
+    """f16x3: ask the NEXT launch on this thread (Linear / halo convolution / LayerNorm) to publish the |max| of what it stores"""
+    if not (_f16() and PUBLISH_AMAX):
+        return None
+    w = _AMAX.word(dev)
+    _check(load().vit_x6_set_output_amax(w.data_ptr()), "vit_x6_set_output_amax")
     return w
 
 
@@ -619,7 +674,7 @@ def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
 
 
 def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-                    relu_in: bool = False, packed: Optional[Tensor] = None, amax: Optional[Tensor] = None) -> Tensor:
+                    relu_in: bool = False, packed: Optional[Tensor] = None, amax: Optional[Tensor] = None, publish: bool = False) -> Tensor:
     """out = [residual +] bias + conv2d(relu?(x), weight, padding=k//2) on vit_conv_x6_fwd (no autograd)."""
     B, Ci, H, W = x.shape
     Co, _, k, _ = weight.shape
@@ -628,10 +683,13 @@ def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, re
     wp = packed if packed is not None else split_conv_weight(weight)
     res = residual.contiguous().float() if residual is not None else None
     if _f16():
-        _announce(amax if amax is not None else _amax_word(x))      # (relu_in: |max| of x bounds |max| of relu(x))
+        _announce(amax if amax is not None else _amax_of(x))        # (relu_in: |max| of x bounds |max| of relu(x))
+    pub = _want_output_amax(x.device) if publish else None
     _check(load().vit_conv_x6_fwd(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                   res.data_ptr() if res is not None else None, out.data_ptr(), B, Ci, Co, H, W, k,
                                   1 if relu_in else 0, _stream(x.device)), "vit_conv_x6_fwd")
+    if pub is not None:
+        _publish(out, pub)
     return out
 
 
@@ -649,7 +707,8 @@ CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_mer
          "layernorm_framework": 0, "adapter_hip": 0,
          # library / framework routes taken ON DEVICE TENSORS (layers the hand-written kernels do not cover): the end-to-end tests assert that every one of them stays at zero
          "library_conv_fwd": 0, "library_conv_bwd": 0, "framework_upsample": 0, "framework_dropout": 0, "framework_linear": 0,
-         "input_merger_library": 0}     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
+         "input_merger_library": 0,
+         "amax_pass": 0, "amax_published": 0}     # f16x3: activation |max| words from a vit_amax pass / from the producing kernel's epilogue     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
 LIBRARY_ROUTES = ("library_conv_fwd", "library_conv_bwd", "framework_upsample", "framework_dropout", "layernorm_framework")
 
 
@@ -674,8 +733,10 @@ class _ConvX6(torch.autograd.Function):
         ctx.mode = LINEAR_MODE
         _pin_products(ctx.mode)
         CALLS["conv_x6_fwd"] += 1
-        ctx.ax = _amax_word(x) if _f16() else None             # f16x3: the input's |max|, shared with the weight-gradient launch
-        return conv_x6_forward(x, weight, bias, residual, relu_in, amax=ctx.ax)
+        ctx.ax = _amax_of(x) if _f16() else None               # f16x3: the input's |max|, shared with the weight-gradient launch
+        # (the 3x3 halo kernel publishes its output's |max| from the epilogue: the next convolution of a residual unit / head needs no pass)
+        k_, W_ = weight.shape[2], x.shape[3]
+        return conv_x6_forward(x, weight, bias, residual, relu_in, amax=ctx.ax, publish=(k_ == 3 and W_ >= 32))
 
     @staticmethod
     def backward(ctx, g):
@@ -683,7 +744,7 @@ class _ConvX6(torch.autograd.Function):
         _pin_products(ctx.mode)
         g = g.contiguous().float()
         f16 = ctx.mode == "f16x3"
-        ag = _amax_word(g) if f16 else None                    # |max| of dY: one pass, read by the dX and the dW launch
+        ag = _amax_of(g) if f16 else None                      # |max| of dY (published by the producing kernel, else one pass): read by the dX and the dW launch
         k = weight.shape[2]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         need_r = ctx.has_res and ctx.needs_input_grad[3]
@@ -705,9 +766,12 @@ class _ConvX6(torch.autograd.Function):
                 wpt = split_conv_weight(weight, True)
                 if f16:
                     _announce(ag)
+                pub = _want_output_amax(g.device) if (f16 and k == 3 and W >= 32) else None
                 _check(load().vit_conv_x6_fwd(g.data_ptr(), wpt.data_ptr(), None,
                                               x.data_ptr() if ctx.relu_in else None, dx.data_ptr(),
                                               B, Co, Ci, H, W, k, 2 if ctx.relu_in else 0, _stream(g.device)), "vit_conv_x6_fwd (dX)")
+                if pub is not None:
+                    _publish(dx, pub)
             else:
                 CALLS["library_conv_bwd"] += 1
                 dx = torch.ops.aten.convolution_backward(g, f_x(), weight, None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
@@ -791,6 +855,10 @@ class _Upsample2x(torch.autograd.Function):
         out = torch.empty((B, Cc, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
         _check(load().vit_upsample2x_fwd(x.data_ptr(), out.data_ptr(), B * Cc, H, W, _stream(x.device)), "vit_upsample2x_fwd")
         ctx.shape = (B, Cc, H, W)
+        if _f16():          # bilinear interpolation is a convex combination: |max| of the input bounds |max| of the output (a valid f16x3 scale)
+            w = _known_amax(x)
+            if w is not None:
+                _publish(out, w)
         return out
 
     @staticmethod
@@ -1088,7 +1156,7 @@ class _FusedLinear(torch.autograd.Function):
         def operands():
             if not f16:
                 return
-            ctx.ax = link_in.ax if (link_in is not None and link_in.ax is not None) else _amax_word(x2)
+            ctx.ax = link_in.ax if (link_in is not None and link_in.ax is not None) else _amax_of(x2)
             _announce(ctx.ax)
             if publish:
                 link.ax = _AMAX.word(x2.device)
@@ -1141,7 +1209,7 @@ class _FusedLinear(torch.autograd.Function):
         def amax_g(t):
             nonlocal ag
             if ag is None:
-                ag = _amax_word(t)
+                ag = _amax_of(t)
             return ag
 
         def publish_dx(lk, ring):
@@ -1257,7 +1325,7 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
                 res2 = res2.contiguous().float()
         wp = split_weight(weight)
         if _f16():
-            _announce(_amax_word(x2))
+            _announce(_amax_of(x2))
         _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
                                         1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
@@ -1280,8 +1348,11 @@ class _LayerNormHip(torch.autograd.Function):
         M = xc.numel() // Cn
         y = torch.empty_like(xc)
         stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+        pub = _want_output_amax(x.device)                     # f16x3: the Linear layers that read y take their scale from this word
         _check(load().vit_layernorm_fwd(xc.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                         stats[0].data_ptr(), stats[1].data_ptr(), M, Cn, float(eps), _stream(x.device)), "vit_layernorm_fwd")
+        if pub is not None:
+            _publish(y, pub)
         ctx.save_for_backward(xc, weight, stats)
         ctx.has_bias, ctx.with_skip = bias is not None, bool(with_skip)
         if with_skip:
@@ -1302,9 +1373,12 @@ class _LayerNormHip(torch.autograd.Function):
         dx = torch.empty_like(xc)
         dwb = torch.empty((2, Cn), dtype=torch.float32, device=dev)
         scratch = torch.empty(load().vit_layernorm_scratch_bytes(M, Cn), dtype=torch.uint8, device=dev)
+        pub = _want_output_amax(dev)                          # f16x3: dx is the dY of the Linear layer in front of this block
         _check(load().vit_layernorm_bwd(g.data_ptr(), xc.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), weight.data_ptr(),
                                         gs.data_ptr() if gs is not None else None, dx.data_ptr(), dwb[0].data_ptr(),
                                         dwb[1].data_ptr(), scratch.data_ptr(), M, Cn, 0, _stream(dev)), "vit_layernorm_bwd")
+        if pub is not None:
+            _publish(dx, pub)
         return dx, dwb[0], (dwb[1] if ctx.has_bias else None), None, None
 
 
@@ -1328,10 +1402,13 @@ class LayerNorm(nn.LayerNorm):
                 M = xc.numel() // Cn
                 y = torch.empty_like(xc)
                 stats = torch.empty((2, M), dtype=torch.float32, device=x.device)
+                pub = _want_output_amax(x.device)
                 _check(load().vit_layernorm_fwd(xc.data_ptr(), self.weight.data_ptr(),
                                                 self.bias.data_ptr() if self.bias is not None else None, y.data_ptr(),
                                                 stats.data_ptr(), stats.data_ptr() + 4 * M, M, Cn, float(self.eps),
                                                 _stream(x.device)), "vit_layernorm_fwd")
+                if pub is not None:
+                    _publish(y, pub)
                 return y
             return _LayerNormHip.apply(x, self.weight, self.bias, self.eps, False)
         CALLS["layernorm_framework"] += 1

@@ -234,7 +234,7 @@ def test_fused_linear_vs_fp64(M, N, K, gelu, res):
 # ---------------------------------------------------------------------------
 def _unpack_split(packed, rows, kcols):
     """packed [rows][k/8][piece][8] bf16 -> three fp64 (rows, k) planes"""
-    raw = packed[: rows * kcols * 6].view(torch.int16).view(rows, kcols // 8, 3, 8).to(torch.int32)     # (256 trailing bytes: the f16x3 mode's |max| word)
+    raw = packed[: rows * kcols * 6].view(torch.int16).view(rows, kcols // 8, 3, 8).to(torch.int32)     # (8 KiB of trailing bytes: the f16x3 mode's |max| word)
     f = (raw << 16).view(torch.float32)
     return [f[:, :, p, :].reshape(rows, kcols).double() for p in range(3)]
 
@@ -922,7 +922,7 @@ def test_f16x3_refuses_a_launch_without_operand_maxima(monkeypatch):
     assert lib.vit_linear_x6_wgrad(x.data_ptr(), x.data_ptr(), out.data_ptr(), None, 64, 64, 64, s) == -1
     word = vit_ops._amax_word(x)
     torch.cuda.synchronize()
-    assert int(word.item()) == int(x.abs().max().view(torch.int32).item())      # the exact bit pattern of the maximum
+    assert word.numel() == 64 * 32 and int(word.max().item()) == int(x.abs().max().view(torch.int32).item())      # (a 64-word line) the exact bit pattern of the maximum
     vit_ops._announce(word)
     assert lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, 64, 64, 64, 0, s) == 0
     assert lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), None, None, out.data_ptr(), None, 64, 64, 64, 0, s) == -1   # consumed
@@ -957,5 +957,63 @@ def test_f16x3_convolutions_forward_input_and_weight_gradient(monkeypatch):
         for i in range(3):
             assert cerrs["f16x3"][i] <= 2.0 * cerrs["bf16x6"][i] + 3e-7, (i, cerrs)
             assert cerrs["f16x3"][i] * 2.5 <= cerrs["bf16x3"][i] or cerrs["f16x3"][i] <= 5e-7, (i, cerrs)
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
+    vit_ops._x6()
+
+
+def test_f16x3_operand_maxima_published_by_the_producing_kernels(monkeypatch):
+    """f16x3 needs the |max| of every activation operand.  LayerNorm (forward: y, backward: dx), the GEMM epilogues (GeluLink) and the 3x3 halo
+    convolution publish the |max| of what they store (vit_x6_set_output_amax), and the consumer finds the word through vit_ops._PUBLISHED instead
+    of running a vit_amax pass.  A transformer block and a residual convolution unit, forward + backward: (i) words really are reused,
+    (ii) a published word IS the exact |max| (LayerNorm: bit-identical results with publishing switched off), (iii) results stay at the
+    f16x3 accuracy against float64."""
+    from styl3r_amd import vit_ops
+    from styl3r_amd.encoder import _ResidualConvUnit
+    from styl3r_amd.vit import Block, LayerNorm6, RopeCfg
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", "bf16x6")
+    torch.manual_seed(4)
+    blk = Block(1024, 16, 4.0, qkv_bias=True, norm_layer=LayerNorm6, rope=RopeCfg(100.0)).to(DEV)
+    x0 = torch.randn(2, 257, 1024, device=DEV)
+    pos = torch.stack(torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij"), -1).reshape(1, 256, 2)
+    pos = torch.cat([torch.tensor([[[16, 0]]]), pos], 1).expand(2, -1, -1).contiguous().to(DEV)
+    gy = torch.randn(2, 257, 1024, device=DEV) * 1e-4
+
+    def run_block(publish):
+        monkeypatch.setattr(vit_ops, "PUBLISH_AMAX", publish)
+        blk.zero_grad()
+        before = dict(vit_ops.CALLS)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x, pos)
+        (y * gy).sum().backward()
+        return y.detach(), x.grad, blk.mlp.fc1.weight.grad.clone(), {k: vit_ops.CALLS[k] - before[k] for k in ("amax_pass", "amax_published")}
+    ya, xa, wa, ca = run_block(True)
+    yb, xb, wb, cb = run_block(False)
+    print(f"  block: with publishing {ca}, without {cb}")
+    # published: LN1 -> qkv, LN2 -> fc1 (forward), LN2's dx -> proj's dY (backward); fc1 <-> fc2 go through the GeluLink words, which are not counted;
+    # left to a pass: the attention output (-> proj), the attention backward's dqkv (-> qkv) and the incoming gradient of this stand-alone block
+    assert cb["amax_published"] == 0 and ca["amax_published"] >= 3 and ca["amax_pass"] <= cb["amax_pass"] - 3, (ca, cb)
+    # a published word is the exact |max| of the tensor: same scales either way (what is left is the split-K / split-M kernels' fp32 atomics
+    # reordering their partial sums from run to run at this small M)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(ya, yb) <= 2e-6 and rel(xa, xb) <= 2e-6 and rel(wa, wb) <= 2e-6
+
+    rcu = _ResidualConvUnit(128).to(DEV)
+    cx0 = torch.randn(2, 128, 64, 64, device=DEV) * 0.5
+    cg = torch.randn(2, 128, 64, 64, device=DEV) * 1e-3
+    xd = cx0.double().requires_grad_(True)
+    w1, b1, w2, b2 = (t.detach().double() for t in (rcu.conv1.weight, rcu.conv1.bias, rcu.conv2.weight, rcu.conv2.bias))
+    F = torch.nn.functional
+    ref = F.conv2d(torch.relu(F.conv2d(torch.relu(xd), w1, b1, padding=1)), w2, b2, padding=1) + xd
+    (ref * cg.double()).sum().backward()
+    monkeypatch.setattr(vit_ops, "PUBLISH_AMAX", True)
+    before = dict(vit_ops.CALLS)
+    cx = cx0.clone().requires_grad_(True)
+    out = rcu(cx)
+    (out * cg).sum().backward()
+    took = {k: vit_ops.CALLS[k] - before[k] for k in ("amax_pass", "amax_published")}
+    print(f"  residual conv unit: {took}; fwd {rel(out.detach().double(), ref.detach()):.1e}, dX {rel(cx.grad.double(), xd.grad):.1e}")
+    assert took["amax_published"] >= 2, took                      # conv1's output -> conv2's input; conv2's dX -> conv1's dY
+    assert rel(out.detach().double(), ref.detach()) <= 2e-6 and rel(cx.grad.double(), xd.grad) <= 2e-6
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
     vit_ops._x6()

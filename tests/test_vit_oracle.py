@@ -48,3 +48,29 @@ def test_attention_backward_oracle_fd():
         arr[idx] = a0 - eps; fm = f(q, k, v)
         arr[idx] = a0
         np.testing.assert_allclose(grad[idx], (fp - fm) / (2 * eps), rtol=1e-6, atol=1e-9)
+
+
+def test_torch_cpu_attention_of_the_baseline_leg_matches_the_numpy_oracle():
+    """oracle/encoder_cpu.py (the plain-torch attention bench.py's CPU baseline runs the encoder with) against oracle/vit_oracle.py,
+    which is pinned to the reference's RoPE2D / attention goldens above: RoPE, forward, and the gradients through autograd"""
+    import numpy as np
+    import torch
+    from oracle import vit_oracle
+    from oracle.encoder_cpu import attention_torch, rope2d_torch
+    g = torch.Generator().manual_seed(3)
+    B, N, H, D = 2, 37, 3, 64
+    q, k, v = (torch.randn(B, N, H, D, generator=g, dtype=torch.float64, requires_grad=True) for _ in range(3))
+    pos = torch.stack([torch.randint(0, 16, (B, N), generator=g), torch.randint(0, 16, (B, N), generator=g)], -1)
+    want_q = vit_oracle.rope2d(q.detach().numpy(), pos.numpy())
+    assert np.abs(rope2d_torch(q.detach(), pos).numpy() - want_q).max() < 1e-12
+    out = attention_torch(q, k, v, 0.125, qpos=pos, kpos=pos)
+    qr, kr = vit_oracle.rope2d(q.detach().numpy(), pos.numpy()), vit_oracle.rope2d(k.detach().numpy(), pos.numpy())
+    want, _ = vit_oracle.attention(qr, kr, v.detach().numpy(), 0.125)
+    assert np.abs(out.detach().numpy() - want).max() < 1e-12
+    gy = torch.randn(B, N, H, D, generator=g, dtype=torch.float64)
+    (out * gy).sum().backward()
+    dq, dk, dv = vit_oracle.attention_backward(qr, kr, v.detach().numpy(), 0.125, gy.numpy())
+    assert np.abs(v.grad.numpy() - dv).max() < 1e-12
+    # dq / dk of the oracle are gradients w.r.t. the ROTATED tensors: rotate back (the rotation is orthogonal: inverse = fwd -1)
+    assert np.abs(q.grad.numpy() - vit_oracle.rope2d(dq, pos.numpy(), fwd=-1.0)).max() < 1e-12
+    assert np.abs(k.grad.numpy() - vit_oracle.rope2d(dk, pos.numpy(), fwd=-1.0)).max() < 1e-12
