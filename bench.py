@@ -547,8 +547,33 @@ def infer_leg(args, dev):
 
     # bf16x6 = the arithmetic of the 1e-4 RGB statement against fp32; bf16x3 = the TF32-class mode the train leg's headline uses (tests/test_e2e_parity.py bounds both)
     out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("bf16x6"), "steps": steps,
-           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "encoder_launch": "eager, style branch + decoder 2 + heads on side streams (total_ms); stream_graphs_total_ms: one hipGraph per stream segment",
+           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "f16x3": timed("f16x3"),
+           "encoder_launch": "eager, style branch + decoder 2 + heads on side streams (total_ms); stream_graphs_total_ms: one hipGraph per stream segment",
            "dtype": "f32", "data": "synthetic, random-init weights"}
+    # `test.align_pose` (config/main.yaml:57-60, model_wrapper_style.py:391-447): before the evaluation render the reference optimises the 3 target
+    # poses for pose_align_steps = 100 Adam steps, each one a rasterizer forward + backward with pose gradients (theta / rho) on the 3 views.
+    # Timed on a scene the heads were re-centred for (a random-init encoder renders nothing), from poses perturbed by ~1 degree / 1 % of the baseline.
+    try:
+        from styl3r_amd.pose_align import align_poses
+        from styl3r_amd.scenes import recentre_output_heads_
+        recentre_output_heads_(enc, ctx, style)
+        with torch.no_grad():
+            gs = enc(ctx, style, 0)
+            ref_img = dec.forward(gs, *cams, (H, H)).color
+        gq = torch.Generator(dev).manual_seed(7)
+        pert = cams[0].clone()
+        pert[..., :3, 3] += 0.01 * torch.randn(1, v_tgt, 3, device=dev, generator=gq)
+        align_poses(dec, gs, ref_img, pert, cams[1], cams[2], cams[3], steps=5)            # warm-up
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _, hist = align_poses(dec, gs, ref_img, pert, cams[1], cams[2], cams[3], steps=100)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        out["align_pose"] = {"steps": 100, "views": v_tgt, "total_ms": round(1e3 * dt, 1), "ms_per_step": round(10.0 * dt, 3),
+                             "loss_first": hist[0], "loss_last": hist[-1],
+                             "note": "100 Adam steps x (rasterizer forward + backward with theta / rho gradients on 3 views, 131 072 Gaussians); host loop as in the reference (one loss read-back per step)"}
+    except Exception as e:
+        out["align_pose"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del enc, dec
     torch.cuda.empty_cache()
     return out

@@ -301,6 +301,8 @@ typedef struct VitAdamChunk {
     const float *step;
     int32_t n;
     int32_t vec;
+    uint32_t *amax;     /* NULL, or the (zeroed) |max| word of the parameter this chunk belongs to: the kernel folds the |max| of the UPDATED values into
+                           it, so the f16x3 mode's per-weight scale (vit_split_weight) costs no vit_amax pass after an optimizer step */
 } VitAdamChunk;
 int vit_adamw_step(const VitAdamChunk *chunks, int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay,
                    const float *grad_scale, void *stream);

@@ -49,6 +49,9 @@ __global__ void __launch_bounds__(256) k_adamw(const VitAdamChunk *__restrict__ 
         c.scale = grad_scale ? *grad_scale : 1.f;
     }
     const int n = ch.n, tid = threadIdx.x;
+    uint32_t pm = 0;            // |max| of the updated parameter values of this lane (folded into *ch.amax for the f16x3 weight scale)
+    auto seen = [&](float v) { pm = max(pm, __builtin_bit_cast(uint32_t, v) & 0x7fffffffu); };
+    auto seen4 = [&](const float4 &v) { seen(v.x); seen(v.y); seen(v.z); seen(v.w); };
     if (ch.vec) {
         float4 *p4 = reinterpret_cast<float4 *>(ch.p), *m4 = reinterpret_cast<float4 *>(ch.m), *v4 = reinterpret_cast<float4 *>(ch.v);
         const float4 *g4 = reinterpret_cast<const float4 *>(ch.g);
@@ -61,23 +64,33 @@ __global__ void __launch_bounds__(256) k_adamw(const VitAdamChunk *__restrict__ 
             adam1(P1.x, G1.x, M1.x, V1.x, c); adam1(P1.y, G1.y, M1.y, V1.y, c); adam1(P1.z, G1.z, M1.z, V1.z, c); adam1(P1.w, G1.w, M1.w, V1.w, c);
             p4[i] = P0; m4[i] = M0; v4[i] = V0;
             p4[i + 256] = P1; m4[i + 256] = M1; v4[i + 256] = V1;
+            seen4(P0); seen4(P1);
         }
         for (; i < n4; i += 256) {
             float4 P0 = p4[i], G0 = g4[i], M0 = m4[i], V0 = v4[i];
             adam1(P0.x, G0.x, M0.x, V0.x, c); adam1(P0.y, G0.y, M0.y, V0.y, c); adam1(P0.z, G0.z, M0.z, V0.z, c); adam1(P0.w, G0.w, M0.w, V0.w, c);
             p4[i] = P0; m4[i] = M0; v4[i] = V0;
+            seen4(P0);
         }
         for (int j = (n4 << 2) + tid; j < n; j += 256) {
             float P = ch.p[j], M = ch.m[j], V = ch.v[j];
             adam1(P, ch.g[j], M, V, c);
             ch.p[j] = P; ch.m[j] = M; ch.v[j] = V;
+            seen(P);
         }
     } else {
         for (int j = tid; j < n; j += 256) {
             float P = ch.p[j], M = ch.m[j], V = ch.v[j];
             adam1(P, ch.g[j], M, V, c);
             ch.p[j] = P; ch.m[j] = M; ch.v[j] = V;
+            seen(P);
         }
+    }
+    if (ch.amax) {              // (workgroup-uniform) 64 slots, one per 128-byte line: csrc/vit_gemm_x6.hip amax_fold
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pm = max(pm, (uint32_t)__shfl_xor((int)pm, o, 64));
+        uint32_t *w = ch.amax + ((blockIdx.x + (threadIdx.x >> 6)) & 63u) * 32;
+        if ((threadIdx.x & 63) == 0 && pm > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, pm);
     }
 }
 }  // namespace

@@ -17,7 +17,8 @@ import torch
 from . import vit_ops
 
 _CHUNK = 16384
-_CHUNK_DTYPE = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("step", "u8"), ("n", "i4"), ("vec", "i4")])   # VitAdamChunk
+_CHUNK_DTYPE = np.dtype([("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("step", "u8"), ("n", "i4"), ("vec", "i4"), ("amax", "u8")])   # VitAdamChunk
+_AMAX_WORDS = 64 * 32     # one |max| word (vit_ops._AmaxArena.LINE): 64 slots, one per cache line
 
 
 def _lib():
@@ -35,6 +36,7 @@ class AdamWHIP(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
         self._tables, self._step_flat = {}, {}
         self._owner = owner
+        self._amax = {}          # group index -> (flat int32 tensor of per-parameter |max| words, [parameters in table order])
         _lib()
 
     def load_state_dict(self, state_dict):
@@ -64,6 +66,10 @@ class AdamWHIP(torch.optim.AdamW):
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
         rows = []
+        n_weights = sum(1 for p in params if p.dim() >= 2)
+        amax_flat = torch.zeros(max(n_weights, 1) * _AMAX_WORDS, dtype=torch.int32, device=params[0].device) if n_weights else None
+        amax_params = []
+        self._amax[gi] = (amax_flat, amax_params)
         for p in params:
             st = self.state[p]
             g, m, v = p.grad, st["exp_avg"], st["exp_avg_sq"]
@@ -79,8 +85,13 @@ class AdamWHIP(torch.optim.AdamW):
             ptrs = [t.data_ptr() + 4 * lo for t in (p, g, m, v)]
             vec = int(all(a % 16 == 0 for a in ptrs))
             n = hi - lo
+            # the |max| of the updated values, for the f16x3 weight scale: only weights (>= 2-D) that are updated as a whole by this rank
+            word = 0
+            if amax_flat is not None and p.dim() >= 2 and lo == 0 and hi == p.numel():
+                word = amax_flat.data_ptr() + 4 * _AMAX_WORDS * len(amax_params)
+                amax_params.append(p)
             for off in range(0, n, _CHUNK):
-                rows.append((ptrs[0] + 4 * off, ptrs[1] + 4 * off, ptrs[2] + 4 * off, ptrs[3] + 4 * off, st["step"].data_ptr(), min(_CHUNK, n - off), vec))
+                rows.append((ptrs[0] + 4 * off, ptrs[1] + 4 * off, ptrs[2] + 4 * off, ptrs[3] + 4 * off, st["step"].data_ptr(), min(_CHUNK, n - off), vec, word))
         host = np.array(rows, dtype=_CHUNK_DTYPE) if rows else np.zeros(0, dtype=_CHUNK_DTYPE)
         if not rows:
             self._tables[gi] = (key, torch.empty(0, dtype=torch.uint8, device=params[0].device), 0)
@@ -120,6 +131,9 @@ class AdamWHIP(torch.optim.AdamW):
             if gs is not None and not (gs.is_cuda and gs.device == dev and gs.dtype == torch.float32 and gs.numel() == 1):
                 raise ValueError("AdamWHIP: grad_scale must be a one-element fp32 tensor on the parameters' device")
             b1, b2 = group["betas"]
+            amax_flat, amax_params = self._amax.get(gi, (None, []))
+            if amax_params:
+                amax_flat.zero_()
             if n_chunks:
                 rc = lib.vit_adamw_step(table.data_ptr(), n_chunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                         float(group["weight_decay"]), gs.data_ptr() if gs is not None else None,
@@ -128,6 +142,9 @@ class AdamWHIP(torch.optim.AdamW):
             # the kernel wrote the parameters through raw pointers: tell autograd (and every cache keyed on `_version` -- the pre-split
             # bf16 weight images of vit_ops._SPLIT_CACHE) that they changed, exactly as an in-place torch op would
             torch.autograd.graph.increment_version(params)
+            # hand the words to the split cache: the next f16x3 image of each weight takes its scale from here (no vit_amax pass)
+            for i, p in enumerate(amax_params):
+                vit_ops.register_weight_amax(p, amax_flat[i * _AMAX_WORDS:(i + 1) * _AMAX_WORDS])
         # the coefficient belongs to THIS step's gradients (ddp.BucketedGradReducer.clip_grad_norm_(defer_to=...)); a later step without a
         # fresh clip must not reuse it
         self.grad_scale = None

@@ -574,6 +574,17 @@ def _weight_amax_word(weight: Tensor, values: Tensor) -> Tensor:
     return word
 
 
+def register_weight_amax(weight: Tensor, word: Tensor) -> None:
+    """the |max| word of `weight`'s CURRENT values, produced elsewhere (optim.AdamWHIP: csrc/vit_optim.hip folds it while it writes the update)"""
+    key = id(weight)
+
+    def drop(ref, key=key):
+        h = _WEIGHT_AMAX.get(key)
+        if h is not None and h[0] is ref:
+            del _WEIGHT_AMAX[key]
+    _WEIGHT_AMAX[key] = (weakref.ref(weight, drop), weight._version, weight.data_ptr(), word)
+
+
 def _announce(a: Optional[Tensor], b: Optional[Tensor] = None) -> None:
     """f16x3: the |max| words of the activation operand(s) of the NEXT x6 launch on this thread (consumed by it)"""
     _check(load().vit_x6_set_operand_amax(a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None),

@@ -335,7 +335,7 @@ def test_hip_adamw_pass_equals_the_frameworks_fused_adamw_and_shares_its_state_l
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", ["hip", "torch"])
-@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])     # (f16x3 + hip: the split takes its scale from the |max| word the AdamW kernel folded)
 def test_forward_sees_the_weights_the_optimizer_just_wrote(impl, mode, monkeypatch):
     """the kernels read PRE-SPLIT bf16 images of every Linear / convolution weight, cached on `Tensor._version`
     (vit_ops._SPLIT_CACHE).  An optimizer that writes parameters through raw pointers (optim.AdamWHIP) -- or the framework's fused AdamW,
@@ -355,6 +355,7 @@ def test_forward_sees_the_weights_the_optimizer_just_wrote(impl, mode, monkeypat
     xc = torch.randn(2, 128, 64, 64, device=dev, generator=g)
     opt = train.make_optimizer([lin_small, lin_ring], list(conv.parameters()), lr=5e-2)
     tol = 2e-4 if mode == "bf16x3" else 2e-5
+    amax_before = dict(vit_ops.CALLS)
     rel = lambda a, e: float((a.double() - e).abs().max() / e.abs().max())
 
     def products():
