@@ -639,7 +639,10 @@ def linear_x6r(x: Tensor, packed_block: Tensor, N: int, bias: Optional[Tensor] =
 
 def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of an nn.Linear weight (N,K) in MFMA operand order (include/vit_ops.h vit_split_weight); cached until
-    the parameter is modified in place (optimizer step, load_state_dict: both bump `_version`) or replaced.  The entry
+    the parameter is modified in place or replaced: `load_state_dict` and in-place torch ops bump `Tensor._version`; optimizer steps do
+    NOT by themselves (optim.AdamWHIP writes through raw pointers, and the framework's fused AdamW leaves the counter alone, too), so
+    AdamWHIP.step and train.make_optimizer's post-step hook bump it explicitly (without that the kernels kept computing with the
+    first split of every weight).  The entry
     holds a weak reference: a new tensor that happens to reuse a dead one's id / address never hits it.  Writes through
     `weight.data` bypass the version counter -- call `invalidate_split_cache()` after such surgery."""
     key = (id(weight), transposed, "f16") if _f16() else (id(weight), transposed)    # (the f16x3 image differs: two fp16 pieces of the scaled weight)
