@@ -127,3 +127,56 @@ def test_vit_ops_reject_cpu_tensors():
         vit_ops.RoPE2D()(torch.zeros(1, 1, 2, 64), torch.zeros(1, 2, 2, dtype=torch.int64))
     with pytest.raises(RuntimeError, match="no CPU path"):
         vit_ops.fused_linear(torch.zeros(2, 16), torch.zeros(4, 16))
+
+
+def test_f16x3_switches_and_struct_layouts_without_a_gpu():
+    """the round-4 additions to the C ABI, as far as they can be exercised without a device: the products switch accepts 2 ("f16x3") and nothing
+    else new; f16x3 launches without announced |max| words are refused BEFORE any launch; VitAdamChunk as optim.py packs it is the header's
+    struct (8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 bytes: the trailing `amax` pointer)"""
+    import numpy as np
+    from styl3r_amd import optim, vit_ops
+    vit_ops.build_library()
+    lib = vit_ops.load()
+    assert lib.vit_x6_set_products(2) == 0 and lib.vit_x6_products() == 2
+    assert lib.vit_x6_set_products(4) == -1 and lib.vit_x6_products() == 2
+    one = C.c_void_p(16)                                           # (any non-null value: validation only, nothing is dereferenced)
+    assert lib.vit_linear_x6_fwd(one, one, None, None, one, None, 16, 16, 16, 0, None) == -1          # no |max| word announced
+    assert lib.vit_linear_x6_wgrad(one, one, one, None, 16, 16, 16, None) == -1
+    assert lib.vit_conv_x6_fwd(one, one, None, None, one, 1, 16, 16, 8, 8, 3, 0, None) == -1
+    assert lib.vit_x6_set_products(6) == 0
+    assert lib.vit_amax(None, 4, one, None) == -1 and lib.vit_amax(one, 0, one, None) == -1
+    assert lib.vit_split_weight_bytes(64, 32) == 64 * 32 * 6 + 8192          # pieces + the |max| word (64 slots, one per cache line)
+    header = (ROOT / "include/vit_ops.h").read_text()
+    body = re.search(r"typedef struct VitAdamChunk \{(.*?)\} VitAdamChunk;", header, re.S).group(1)
+    fields = re.findall(r"\b(\w+);", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == list(optim._CHUNK_DTYPE.names) == ["p", "g", "m", "v", "step", "n", "vec", "amax"]
+    assert optim._CHUNK_DTYPE.itemsize == 56 and optim._CHUNK_DTYPE.fields["amax"][1] == 48
+    assert optim._AMAX_WORDS == vit_ops._AmaxArena.LINE == 64 * 32
+
+
+def test_published_maxima_registry_never_outlives_its_tensor():
+    """vit_ops._PUBLISHED (f16x3): a word published for a tensor is found through any view of the same memory, and never after an in-place
+    write (version counter) or after the producing tensor died (its memory may have been handed to another tensor)"""
+    import gc
+    from styl3r_amd import vit_ops
+    vit_ops._PUBLISHED.clear()
+    t = torch.randn(4, 6)
+    word = torch.zeros(8, dtype=torch.int32)
+    vit_ops._publish(t, word)
+    assert vit_ops._known_amax(t) is word and vit_ops._known_amax(t.reshape(24)) is word and vit_ops._known_amax(t.view(6, 4)) is word
+    assert vit_ops._known_amax(t[1:]) is None and vit_ops._known_amax(torch.randn(4, 6)) is None
+    t.add_(1.0)
+    assert vit_ops._known_amax(t) is None                                        # modified in place: the published maximum is stale
+    u = torch.randn(3, 3)
+    vit_ops._publish(u, word)
+    key = (u.data_ptr(), u.numel())
+    assert key in vit_ops._PUBLISHED
+    del u
+    gc.collect()
+    assert key not in vit_ops._PUBLISHED                                          # the entry went with the tensor
+    keep, vit_ops.PUBLISH_AMAX = vit_ops.PUBLISH_AMAX, False
+    try:
+        v = torch.randn(2, 2); vit_ops._publish(v, word)
+        assert vit_ops._known_amax(v) is None                                     # the A/B switch
+    finally:
+        vit_ops.PUBLISH_AMAX = keep
