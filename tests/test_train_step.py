@@ -355,7 +355,6 @@ def test_forward_sees_the_weights_the_optimizer_just_wrote(impl, mode, monkeypat
     xc = torch.randn(2, 128, 64, 64, device=dev, generator=g)
     opt = train.make_optimizer([lin_small, lin_ring], list(conv.parameters()), lr=5e-2)
     tol = 2e-4 if mode == "bf16x3" else 2e-5
-    amax_before = dict(vit_ops.CALLS)
     rel = lambda a, e: float((a.double() - e).abs().max() / e.abs().max())
 
     def products():
