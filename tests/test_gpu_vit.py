@@ -1017,3 +1017,46 @@ def test_f16x3_operand_maxima_published_by_the_producing_kernels(monkeypatch):
     assert rel(out.detach().double(), ref.detach()) <= 2e-6 and rel(cx.grad.double(), xd.grad) <= 2e-6
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
     vit_ops._x6()
+
+
+def test_halo_convolution_at_the_largest_head_shapes_is_linear_and_mode_consistent(monkeypatch):
+    """k_conv3h_x6 at the sizes the oracle-style fp64 comparison above cannot reach in seconds -- the C5 stress shapes' gs head (256 -> 256 at
+    512 x 512) and the C3 heads at 20 images -- through size-independent properties: (i) the three arithmetic modes (bf16x6 / f16x3: fp32 round-off;
+    bf16x3: 2^-16 class) agree with each other at their own accuracy, (ii) linearity in the input, conv(a x1 + x2) - bias == a (conv(x1) - bias) +
+    (conv(x2) - bias), (iii) a one-hot input reproduces the flipped weight taps exactly where the patch borders, the halo rows and the image
+    borders meet."""
+    from styl3r_amd import vit_ops
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    g = torch.Generator(DEV).manual_seed(31)
+    for (B, Ci, Co, H, W) in [(1, 256, 256, 512, 512), (20, 256, 128, 128, 128)]:
+        conv = vit_ops.Conv2dX6(Ci, Co, 3, padding=1).to(DEV)
+        x1 = torch.randn(B, Ci, H, W, device=DEV, generator=g); x2 = torch.randn(B, Ci, H, W, device=DEV, generator=g)
+        out = {}
+        with torch.no_grad():
+            for mode in ("bf16x6", "f16x3", "bf16x3"):
+                monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+                out[mode] = conv(x1)
+            assert rel(out["f16x3"], out["bf16x6"]) <= 3e-6 and rel(out["bf16x3"], out["bf16x6"]) <= 3e-5, (rel(out["f16x3"], out["bf16x6"]), rel(out["bf16x3"], out["bf16x6"]))
+            monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+            bias = conv.bias.view(1, -1, 1, 1)
+            lhs = conv(0.5 * x1 + x2) - bias
+            rhs = 0.5 * (out["f16x3"] - bias) + (conv(x2) - bias)
+            assert rel(lhs, rhs) <= 4e-6, rel(lhs, rhs)
+            del x2, lhs, rhs
+            # one-hot probes at patch corners (4 x 32 patches), the image corner and an interior pixel
+            for (y, x) in [(0, 0), (3, 31), (4, 32), (H - 1, W - 1), (H // 2 + 1, W // 2 - 3)]:
+                x1.zero_(); x1[0, 5, y, x] = 1.0
+                o = conv(x1) - bias
+                for ky in range(3):
+                    for kx in range(3):
+                        yy, xx = y + 1 - ky, x + 1 - kx            # the output pixel that sees the probe through tap (ky, kx)
+                        if 0 <= yy < H and 0 <= xx < W:
+                            want = conv.weight[:, 5, ky, kx]
+                            assert float((o[0, :, yy, xx] - want).abs().max()) <= 2e-6 * float(conv.weight.abs().max()) + 1e-9, (y, x, ky, kx)
+                assert float(o[0].abs().sum((0,))[max(0, y - 1):y + 2, max(0, x - 1):x + 2].sum()) > 0
+                o[0, :, max(0, y - 1):y + 2, max(0, x - 1):x + 2] = 0
+                assert float(o.abs().max()) == 0.0                  # nothing leaks outside the 3 x 3 footprint
+        del x1, out
+        torch.cuda.empty_cache()
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
+    vit_ops._x6()
