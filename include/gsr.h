@@ -109,7 +109,9 @@ typedef struct GsrLayout {
     size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
     size_t tile_order;   /* uint32[V*T]     (view*T + tile) ids, longest list first: launch order of the composite kernels */
     size_t pairs_alt;    /* uint64[cap]     bucket space of the per-tile sort for lists longer than its LDS budget */
-    size_t quad_mask;    /* uint8[cap]      per list entry: 8x8 quadrants of its tile the splat can touch (forward -> backward) */
+    size_t block_mask;   /* uint32[cap]     per list entry: the 2-row x 4-column pixel blocks of its tile the entry was composited into,
+                            bit 8 q + 2 by + BX (8x8 quadrant q = TL,TR,BL,BR; by = 0..3, BX = 0..1 inside it): forward -> backward,
+                            whose rows walk exactly these (entry, block) items */
     size_t total;        /* total bytes */
 } GsrLayout;
 

@@ -91,7 +91,7 @@ class GsrDims(C.Structure):
 
 class GsrLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("records", "tile_count", "tile_offset", "tile_cursor", "pairs", "point_list",
-                                          "final_T", "n_contrib", "grad_rec", "status", "tile_order", "pairs_alt", "quad_mask", "total")]
+                                          "final_T", "n_contrib", "grad_rec", "status", "tile_order", "pairs_alt", "block_mask", "total")]
 
 
 GSR_FLAG_NTOUCHED = 1

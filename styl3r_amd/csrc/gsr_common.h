@@ -40,7 +40,7 @@ struct Ptrs {             // carved workspace
     uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;
     unsigned long long *pairs, *pairs_alt;
     uint32_t *point_list;
-    uint8_t *quad_mask;
+    uint32_t *block_mask;
     float *final_T;
     uint32_t *n_contrib;
     float *grad_rec;

@@ -24,6 +24,9 @@
 // enters a sort: pairs are bucketed by tile with one counting pass (K1 counters + K3
 // scatter, 8 B/pair written) and each bucket is depth-sorted inside the CU's LDS (8 B/pair
 // read + 4 B/pair written), with no host round trip: ~28 B/pair of binning traffic.
+#include <cstdlib>
+#include <cstring>
+
 #include "gsr_common.h"
 
 namespace gsr {
@@ -569,19 +572,27 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
 // One wavefront per tile.  Lane l owns pixel (l&7, l>>3) of each 8x8 quadrant k = 0..3
 // (TL, TR, BL, BR), so a splat whose footprint misses a quadrant costs that quadrant nothing
 // (wave-uniform scalar branch on the queue's quadrant mask).
-template <bool NTOUCH>
+// BLOCKS: also leave the exact per-entry block masks the row-packed backward (GSR_K6=rows16 / rows8) walks; otherwise the
+// geometric quadrant bits are expanded to the same format (a quadrant's byte = 0xff) for the tile backward.
+template <bool NTOUCH, bool BLOCKS>
 __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      float *__restrict__ image, float *__restrict__ out_depth,
                                                      float *__restrict__ out_opacity, int32_t *__restrict__ n_touched)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
     __shared__ float4 s_q[64 * 3];
+    __shared__ uint4 s_hit[64 * 2];     // per entry of the batch 32 flag bytes: byte 8 q + 2 by + BX = the 2-row x 4-column pixel block (BX, by) of
+                                        // quadrant q composited it
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists are launched first
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const int lane = threadIdx.x;
     const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
+    // lane l = (x, y) = (l & 7, l >> 3) of every quadrant: its pixels lie in block r = (y >= 4) * 2 + (x >= 4)
+    // lane l = (x, y) = (l & 7, l >> 3) of every quadrant: its pixels lie in block by = y >> 1, BX = x >> 2
+    uint8_t *hit_lane = reinterpret_cast<uint8_t *>(s_hit) + (((lane >> 4) << 1) | ((lane >> 2) & 1));
+    if (BLOCKS) { s_hit[lane * 2] = make_uint4(0u, 0u, 0u, 0u); s_hit[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u); }
 
     if (d.flags & GSR_FLAG_PREZERO_GRADS) {
         // side job: this wavefront's slice of the backward's gradient accumulators (stores only; the kernel's own work is
@@ -602,14 +613,15 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
 
     // (pixel coordinates from the lane's base + a per-quadrant constant, as in the backward, were measured here: the two extra
     //  subtractions per evaluation cost 4 % and the 2 registers they free do not reach the next occupancy step)
-    float fx[4], fy[4], Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
+    const float fx0 = (float)ox, fy0 = (float)oy;   // pixel = lane base + the quadrant's constant offset (round 5: the six registers this frees
+                                                     // are the sixth wave per SIMD now that the block flags took two)
+    float Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
     uint32_t last[4];
     bool done[4], inside[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
         inside[k] = px < d.W && py < d.H;
-        fx[k] = (float)px; fy[k] = (float)py;
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = O[k] = 0.f;
         last[k] = 0; done[k] = !inside[k];
     }
@@ -617,8 +629,11 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     for (int base = 0; base < n; base += 64) {
         const int cnt = min(64, n - base);
         __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
-        if (lane < cnt)   // one list entry per lane; the quadrant mask is kept for the backward
-            ws.quad_mask[start + base + lane] = (uint8_t)stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
+        if (lane < cnt) {  // one list entry per lane; the geometric quadrant mask steers this kernel's own scalar skips
+            const uint32_t qm = stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
+            if (!BLOCKS) ws.block_mask[start + base + lane] = ((qm & 1u) ? 0xffu : 0u) | ((qm & 2u) ? 0xff00u : 0u) |
+                                                              ((qm & 4u) ? 0xff0000u : 0u) | ((qm & 8u) ? 0xff000000u : 0u);
+        }
         __syncthreads();
 
         // (reading entry j + 1 ahead of entry j's evaluation was measured: +7 VGPRs, 8 -> 7 waves per SIMD, -6 %)
@@ -628,11 +643,12 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
             const float4 c = s_q[j * 3 + 2];
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
             uint32_t touched = 0;
+            uint8_t *hit_j = hit_lane + j * 32;   // this entry's 32 block flags, at the lane's block of each quadrant
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(quad & (1u << k))) continue;  // scalar branch
                 if (done[k]) continue;
-                const float dx = a.x - fx[k], dy = a.y - fy[k];
+                const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (power > 0.f) continue;
                 const float alpha = fminf(0.99f, b.y * __expf(power));
@@ -646,6 +662,10 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 if (NTOUCH) touched += (test_T > 0.5f) ? 1u : 0u;
                 Tr[k] = test_T;
                 last[k] = (uint32_t)(base + j + 1);
+                // the backward's rows walk exactly the (entry, pixel block) items that composited something: one LDS byte store
+                // under the exec mask of the lanes that did (same value from every lane of a block: stores to one address
+                // merge; an LDS atomic OR of 64 lanes on one word serialises -- measured: this kernel 0.50 -> 1.90 ms)
+                if (BLOCKS) hit_j[8 * k] = 1;
             }
             if (NTOUCH) {
                 // wave total of `touched` (0..4 per lane): three ballots, one atomic per (tile, splat)
@@ -653,6 +673,15 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                                      4u * (uint32_t)__popcll(__ballot(touched & 4u));
                 if (tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)tot);
             }
+        }
+        if (BLOCKS) {   // lane j: entry base + j's 32 flags -> 32-bit mask (bit 8 q + 2 by + BX), flags re-armed for the next batch
+            __syncthreads();
+            const uint4 f0 = s_hit[lane * 2], f1 = s_hit[lane * 2 + 1];
+            s_hit[lane * 2] = make_uint4(0u, 0u, 0u, 0u); s_hit[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);
+            auto nib = [](uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); };
+            if (lane < cnt)
+                ws.block_mask[start + base + lane] = nib(f0.x) | (nib(f0.y) << 4) | (nib(f0.z) << 8) | (nib(f0.w) << 12) |
+                                                      (nib(f1.x) << 16) | (nib(f1.y) << 20) | (nib(f1.z) << 24) | (nib(f1.w) << 28);
         }
         if (__all(done[0] && done[1] && done[2] && done[3])) break;
     }
@@ -698,7 +727,7 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.status = take(GSR_STATUS_WORDS * 4);
     L.tile_order = take(V * T * 4);
     L.pairs_alt = take((size_t)cap * 8);
-    L.quad_mask = take((size_t)cap);
+    L.block_mask = take((size_t)cap * 4);
     L.total = off;
     return GSR_OK;
 }
@@ -719,7 +748,7 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.status = reinterpret_cast<int32_t *>(p + L.status);
     w.tile_order = reinterpret_cast<uint32_t *>(p + L.tile_order);
     w.pairs_alt = reinterpret_cast<unsigned long long *>(p + L.pairs_alt);
-    w.quad_mask = reinterpret_cast<uint8_t *>(p + L.quad_mask);
+    w.block_mask = reinterpret_cast<uint32_t *>(p + L.block_mask);
     return w;
 }
 
@@ -775,12 +804,15 @@ render_phase:
         hipLaunchKernelGGL(k_tile_sort, dim3(T, V), dim3(256), lds_keys * 8, stream, d, ws, lds_keys);
     }
     tm.end(GSR_STAGE_SORT); tm.begin(GSR_STAGE_COMPOSITE_FWD);
-    if (ntouch)
-        hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity,
-                           n_touched);
-    else
-        hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth,
-                           opacity, n_touched);
+    {
+        // GSR_K6=rows16 / rows8 (read per call, as in gsr_backward): the row-packed backward needs the exact block masks
+        const char *k6_env = getenv("GSR_K6");
+        const bool blocks = k6_env && !strncmp(k6_env, "rows", 4);
+#define GSR_LAUNCH_K5(NT, BL) hipLaunchKernelGGL((k_composite_fwd<NT, BL>), dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity, n_touched)
+        if (ntouch) { if (blocks) GSR_LAUNCH_K5(true, true); else GSR_LAUNCH_K5(true, false); }
+        else { if (blocks) GSR_LAUNCH_K5(false, true); else GSR_LAUNCH_K5(false, false); }
+#undef GSR_LAUNCH_K5
+    }
     tm.end(GSR_STAGE_COMPOSITE_FWD);
     return launch_status();
 }

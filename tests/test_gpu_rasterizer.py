@@ -191,14 +191,23 @@ def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0),
         assert_close_rel(theta.grad.cpu().numpy(), res["f64"]["theta"], max(2e-4, f64_rel), "d theta")
 
 
+@pytest.fixture(params=["tile", "rows16", "rows8"])
+def k6(request, monkeypatch):
+    """every composite-backward kernel against the same oracle bars: the one-wavefront-per-tile kernel (default) and the
+    round-5 row-packed kernels (GSR_K6=rows16 / rows8: a wavefront per 8x8 quadrant, four 4x4-block or eight 2x4-block systolic
+    rows walking the exact block masks of the forward).  libgsr_hip.so reads the variable per call."""
+    monkeypatch.setenv("GSR_K6", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("sh_degree", [0, 2, 4])
-def test_backward_parity(sh_degree):
+def test_backward_parity(sh_degree, k6):
     cam = simple_camera(64, 80, c2w=CAM_C2W)
     means, cov6, opac, shs = random_scene(1200, seed=60 + sh_degree, sh_degree=sh_degree, scale=(0.03, 0.15))
     _check_backward(means, cov6, opac, cam, shs=shs, sh_degree=sh_degree, bg=(0.3, 0.5, 0.2))
 
 
-def test_backward_parity_colors_precomp_and_pose():
+def test_backward_parity_colors_precomp_and_pose(k6):
     cam = simple_camera(48, 48, c2w=CAM_C2W)
     means, cov6, opac, shs = random_scene(600, seed=77, scale=(0.03, 0.15))
     _check_backward(means, cov6, opac, cam, colors=np.abs(shs[:, 0, :]), bg=(0.1, 0.1, 0.4), pose=True)
@@ -293,7 +302,7 @@ def _scene_view_cam(sc, views, i):
     return s, cov6, cam
 
 
-def test_full_size_workload_backward_parity_single_view():
+def test_full_size_workload_backward_parity_single_view(k6):
     """the BACKWARD at the headline size (G = 65 536, 256 x 256; lists of ~630 entries, multi-batch
     back-to-front walk) against the f32 and f64 oracles, every gradient, depth gradient included (k_composite_bwd<true>)."""
     from styl3r_amd.decoder import prepare_views
@@ -306,7 +315,7 @@ def test_full_size_workload_backward_parity_single_view():
     # single alpha >= 1/255 decisions differ between the two precisions on 630-entry lists
 
 
-def test_c4_size_view_backward_parity():
+def test_c4_size_view_backward_parity(k6):
     """one view of the C4 workload: 4 context views x 256^2 = 262 144 Gaussians (lists of ~2 250, up to ~4 700 entries: beyond the
     tile sort's LDS budget), forward integer state + images and every gradient against the oracles"""
     from styl3r_amd.decoder import prepare_views

@@ -1030,18 +1030,24 @@ def test_halo_convolution_at_the_largest_head_shapes_is_linear_and_mode_consiste
     g = torch.Generator(DEV).manual_seed(31)
     for (B, Ci, Co, H, W) in [(1, 256, 256, 512, 512), (20, 256, 128, 128, 128)]:
         conv = vit_ops.Conv2dX6(Ci, Co, 3, padding=1).to(DEV)
+        with torch.no_grad():                                         # weights from the seeded generator too (the global RNG made the bars order-dependent)
+            bound = 1.0 / (Ci * 9) ** 0.5
+            conv.weight.copy_((torch.rand(conv.weight.shape, device=DEV, generator=g) * 2 - 1) * bound)
+            conv.bias.copy_((torch.rand(conv.bias.shape, device=DEV, generator=g) * 2 - 1) * bound)
         x1 = torch.randn(B, Ci, H, W, device=DEV, generator=g); x2 = torch.randn(B, Ci, H, W, device=DEV, generator=g)
         out = {}
         with torch.no_grad():
             for mode in ("bf16x6", "f16x3", "bf16x3"):
                 monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
                 out[mode] = conv(x1)
-            assert rel(out["f16x3"], out["bf16x6"]) <= 3e-6 and rel(out["bf16x3"], out["bf16x6"]) <= 3e-5, (rel(out["f16x3"], out["bf16x6"]), rel(out["bf16x3"], out["bf16x6"]))
+            # bars from tools/probes/halo_bar_calibration.py (6 seeds x both shapes, gpurun_out/r05a_halo_bars.jsonl -> profiles/r05_halo_bars.jsonl):
+            # worst f16x3 3.3e-6, bf16x3 5.3e-6, linearity 2.2e-6; the bars keep >= 2.4x margin over the worst observation
+            assert rel(out["f16x3"], out["bf16x6"]) <= 8e-6 and rel(out["bf16x3"], out["bf16x6"]) <= 3e-5, (rel(out["f16x3"], out["bf16x6"]), rel(out["bf16x3"], out["bf16x6"]))
             monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
             bias = conv.bias.view(1, -1, 1, 1)
             lhs = conv(0.5 * x1 + x2) - bias
             rhs = 0.5 * (out["f16x3"] - bias) + (conv(x2) - bias)
-            assert rel(lhs, rhs) <= 4e-6, rel(lhs, rhs)
+            assert rel(lhs, rhs) <= 6e-6, rel(lhs, rhs)
             del x2, lhs, rhs
             # one-hot probes at patch corners (4 x 32 patches), the image corner and an interior pixel
             for (y, x) in [(0, 0), (3, 31), (4, 32), (H - 1, W - 1), (H // 2 + 1, W // 2 - 3)]:
