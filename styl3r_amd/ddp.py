@@ -168,9 +168,48 @@ class BucketedGradReducer:
             self._gathers.append(self.dist.all_gather_into_tensor(b["pflat"], b["pflat"][lo:hi], async_op=True))
 
     def wait_params(self):
+        """fence of the asynchronous parameter all-gather ("rs_ag").  The optimizer bumped `Tensor._version` when IT wrote its owned ranges;
+        the other ranks' ranges only change here, so the versions are bumped again once the gather has landed (a forward
+        between step() and this fence had cached split weight images of the stale shards under the new version for good)."""
+        if not self._gathers:
+            return
         for h in self._gathers:
             h.wait()
         self._gathers.clear()
+        torch.autograd.graph.increment_version([p for b in self.buckets for p in b["params"]])
+
+    def guard_readers(self, module: nn.Module):
+        """every reader of the parameters outside the train step -- a validation / inference forward of `module`, `state_dict()` for a
+        checkpoint -- first waits for the parameter all-gather in flight (forward pre-hook + state-dict pre-hook; no-ops otherwise)."""
+        self._hooks.append(module.register_forward_pre_hook(lambda m, args: self.wait_params()))
+        self._hooks.append(module.register_state_dict_pre_hook(lambda m, prefix, keep_vars: self.wait_params()))
+
+    @torch.no_grad()
+    def consolidate_optimizer_state(self, optimizer, keys=("exp_avg", "exp_avg_sq")):
+        """COLLECTIVE ("rs_ag"): all-gather the moment shards so that `optimizer.state_dict()` holds the full moments on every rank (each
+        rank only ever updates the moments of its owned element ranges; a checkpoint written from one rank alone would store zeros for
+        the rest).  Call on every rank before `state_dict()`; the sharded optimizers refuse `state_dict()` otherwise."""
+        if self.mode == "rs_ag":
+            self.wait_params()
+            for b in self.buckets:
+                lo, hi = b["shard"]
+                for key in keys:
+                    flat = torch.zeros_like(b["pflat"])
+                    off = 0
+                    for p in b["params"]:
+                        st, r = optimizer.state.get(p), self._range.get(id(p))
+                        if st and key in st and r is not None:
+                            flat[off + r[0]:off + r[1]] = st[key].reshape(-1)[r[0]:r[1]]
+                        off += p.numel()
+                    if self.collective:
+                        self.dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+                    off = 0
+                    for p in b["params"]:
+                        st = optimizer.state.get(p)
+                        if st and key in st:
+                            st[key].copy_(flat[off:off + p.numel()].view_as(p))
+                        off += p.numel()
+        optimizer._shards_consolidated = True
 
     def _make_hook(self, bi):
         def hook(p):

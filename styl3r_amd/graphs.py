@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import vit_ops
 from .decoder import Gaussians
 
 
@@ -27,6 +28,7 @@ class GraphedEncoder:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self.encoder(self.ctx, self.style, 0)
+        vit_ops._AMAX.end_capture()      # f16x3 |max| words: this graph's arena (zero fill captured with it) is not handed to anyone else
 
     @torch.no_grad()
     def __call__(self, context: dict, style: dict) -> Gaussians:
@@ -74,6 +76,7 @@ class StreamGraphedEncoder:
             box = {}
             with torch.no_grad(), torch.cuda.graph(g, stream=cap):
                 box["out"] = fn()
+            vit_ops._AMAX.end_capture()  # every graph zero-fills its own |max| arena on replay (words were never re-zeroed)
             self._keep.append(box)
             return g, box["out"]
 

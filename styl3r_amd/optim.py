@@ -148,7 +148,21 @@ class AdamWHIP(torch.optim.AdamW):
         # the coefficient belongs to THIS step's gradients (ddp.BucketedGradReducer.clip_grad_norm_(defer_to=...)); a later step without a
         # fresh clip must not reuse it
         self.grad_scale = None
+        self._shards_consolidated = False
         return loss
+
+    def state_dict(self):
+        _refuse_sharded_state_dict(self)
+        return super().state_dict()
+
+
+def _refuse_sharded_state_dict(opt):
+    """owned-range optimizers ("rs_ag"): the moments of the element ranges other ranks own are zeros here until
+    `reducer.consolidate_optimizer_state(optimizer)` (a collective) has gathered them"""
+    owner = getattr(opt, "_owner", None)
+    if owner is not None and getattr(owner, "mode", "") == "rs_ag" and owner.world > 1 and not getattr(opt, "_shards_consolidated", True):
+        raise RuntimeError("state_dict() of a sharded (rs_ag) optimizer: call reducer.consolidate_optimizer_state(optimizer) on EVERY rank "
+                           "first -- each rank holds the moments of its owned element ranges only")
 
 
 class ShardedAdamWTorch(torch.optim.AdamW):
@@ -192,4 +206,9 @@ class ShardedAdamWTorch(torch.optim.AdamW):
             if touched:
                 torch.autograd.graph.increment_version(touched)
         self.grad_scale = None
+        self._shards_consolidated = False
         return None
+
+    def state_dict(self):
+        _refuse_sharded_state_dict(self)
+        return super().state_dict()

@@ -111,6 +111,8 @@ class TrainStep:
         self.reducer = BucketedGradReducer([p for p in encoder.parameters() if id(p) in trainable], dist, bucket_bytes,
                                            force_collective=force_collective, mode=self.dp_mode, groups=[list(new), list(pre)])
         self.optimizer = make_optimizer(new, pre, lr, backbone_lr_multiplier, owner=self.reducer if self.dp_mode == "rs_ag" else None)
+        if self.dp_mode == "rs_ag":
+            self.reducer.guard_readers(encoder)   # validation forwards / checkpoints between two steps wait for the parameter all-gather
         self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
         self.global_step = 0
 

@@ -485,12 +485,26 @@ class _AmaxArena:
         self.lines, self.buf, self.next = lines, {}, {}
 
     def word(self, dev) -> Tensor:
-        i = self.next.get(dev, self.lines)
+        """one arena per (device, STREAM, capture state), allocated and zero-filled on the stream that asks -- the stream the
+        producer's atomics run on -- so the fill is ordered in front of them (a device-wide arena could be refilled on a side stream while
+        the main stream already folded maxima into it).  Under hipGraph capture the arena is a fresh buffer of the graph's pool whose fill
+        KERNEL (not a memset node: DESIGN R3.6) is captured in front of the producers, so every replay starts from zeroed words; the graph's
+        pool keeps the memory for the graph's lifetime.  The stream key is the raw handle (~0.1 us), not torch.cuda.current_stream."""
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (idx, torch._C._cuda_getCurrentRawStream(idx), capturing)
+        i = self.next.get(key, self.lines)
         if i >= self.lines:
-            self.buf[dev] = torch.zeros(self.lines * self.LINE, dtype=torch.int32, device=dev)
+            self.buf[key] = torch.empty(self.lines * self.LINE, dtype=torch.int32, device=dev).fill_(0)
             i = 0
-        self.next[dev] = i + 1
-        return self.buf[dev][i * self.LINE:(i + 1) * self.LINE]
+        self.next[key] = i + 1
+        return self.buf[key][i * self.LINE:(i + 1) * self.LINE]
+
+    def end_capture(self) -> None:
+        """drop the arenas opened under a capture: the next capture (or eager code on the same stream handle) must not be handed words of
+        a pool whose zero fill it does not replay"""
+        for key in [k for k in self.buf if k[2]]:
+            del self.buf[key]; del self.next[key]
 
 
 _AMAX = _AmaxArena()
@@ -507,7 +521,7 @@ def _amax_word(t: Tensor) -> Tensor:
 # epilogues): the f16x3 consumer of that tensor finds the word here instead of running a vit_amax pass.  Keyed by the tensor's memory; an entry
 # holds a WEAK reference to the producing tensor object and is valid only while that object is alive (its memory cannot have been reused), still
 # starts at the same address and carries the version it was published with (no in-place write since).  Views / reshapes of the tensor match too.
-_PUBLISHED: dict = {}        # (data_ptr, numel) -> (weakref(tensor), _version, word)
+_PUBLISHED: dict = {}        # (data_ptr, numel) -> (weakref(tensor), _version, word, raw stream it was published on)
 
 
 def _publish(t: Tensor, word: Tensor) -> None:
@@ -517,7 +531,8 @@ def _publish(t: Tensor, word: Tensor) -> None:
         h = _PUBLISHED.get(key)
         if h is not None and h[0] is ref:
             del _PUBLISHED[key]
-    _PUBLISHED[key] = (weakref.ref(t, drop), t._version, word)
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    _PUBLISHED[key] = (weakref.ref(t, drop), t._version, word, torch._C._cuda_getCurrentRawStream(idx))
 
 
 PUBLISH_AMAX = os.environ.get("VIT_PUBLISH_AMAX", "1") == "1"      # A/B switch: 0 = every f16x3 operand scale comes from its own vit_amax pass
@@ -532,6 +547,9 @@ def _known_amax(t: Tensor) -> Optional[Tensor]:
     src = hit[0]()
     if src is None or src.data_ptr() != t.data_ptr() or src._version != hit[1] or t._version != hit[1]:
         return None
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if hit[3] != torch._C._cuda_getCurrentRawStream(idx) and not torch.cuda.is_current_stream_capturing():
+        hit[2].record_stream(torch.cuda.current_stream(t.device))     # word of another stream's arena read here: the allocator must know
     return hit[2]
 
 

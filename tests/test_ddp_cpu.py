@@ -271,11 +271,28 @@ RSAG_WORKER = textwrap.dedent("""
             norms.append(float(red.clip_grad_norm_(0.05, defer_to=None if mode == "all_reduce" else opt)))
             opt.step()
             red.gather_params()
+        # ADVICE r04: (i) a reader between step() and the fence: the guarded module's forward waits for the all-gather and the
+        # versions move when it lands; (ii) the moments of the other rank's ranges are gathered before a checkpoint
+        v0 = [p._version for p in params]
+        red.guard_readers(model)
+        pending = len(red._gathers)
+        model(torch.randn(2, 16))
+        fenced = len(red._gathers) == 0 and (pending == 0 or all(p._version > v for p, v in zip(params[:-1], v0[:-1])))
         red.wait_params()
-        return [p.detach().clone() for p in params], norms, red, opt
+        refused = False
+        if mode == "rs_ag":
+            try:
+                opt.state_dict()
+            except RuntimeError:
+                refused = True
+            red.consolidate_optimizer_state(opt)
+        moments = [opt.state[p][k].detach().clone() for p in params if opt.state.get(p) for k in ("exp_avg", "exp_avg_sq")]
+        opt.state_dict()
+        return [p.detach().clone() for p in params], norms, red, opt, dict(fenced=fenced, refused=refused, pending=pending), moments
 
-    pa, na, ra, oa = run("all_reduce")
-    pb, nb, rb, ob = run("rs_ag")
+    pa, na, ra, oa, xa, ma = run("all_reduce")
+    pb, nb, rb, ob, xb, mb = run("rs_ag")
+    mom_err = max(float((a - b).abs().max() / (a.abs().max() + 1e-30)) for a, b in zip(ma, mb))
     err = max(float((a - b).abs().max() / a.abs().max()) for a, b in zip(pa, pb))
     flat = torch.cat([p.reshape(-1) for p in pb]).double()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
@@ -284,7 +301,7 @@ RSAG_WORKER = textwrap.dedent("""
     total = sum(b["n"] for b in rb.buckets)
     print(json.dumps(dict(rank=rank, err=err, norm_err=max(abs(x - y) / x for x, y in zip(na, nb)), same=all(torch.equal(gathered[0], g) for g in gathered),
                           owned=owned, total=total, unused_untouched=bool(torch.equal(pb[-1], torch.ones(5))), nbuckets=len(rb.buckets),
-                          kinds=[type(oa).__name__, type(ob).__name__])), flush=True)
+                          kinds=[type(oa).__name__, type(ob).__name__], mom_err=mom_err, n_moments=len(mb), guard=xb)), flush=True)
     dist.barrier(); dist.destroy_process_group()
 """) % str(ROOT)
 
@@ -305,3 +322,6 @@ def test_reduce_scatter_all_gather_mode_trains_like_the_all_reduce_mode(tmp_path
         assert d["err"] <= 1e-6 and d["norm_err"] <= 1e-6 and d["same"] and d["unused_untouched"], d
         assert d["nbuckets"] >= 3 and abs(d["owned"] - d["total"] / 2) <= d["nbuckets"], d
         assert d["kinds"][1] == "ShardedAdamWTorch", d
+        # the consolidated moments equal the all-reduce mode's on every rank; state_dict() refused before the consolidation;
+        # the guarded forward fenced a gather that was really in flight
+        assert d["mom_err"] <= 1e-6 and d["n_moments"] >= 10 and d["guard"]["refused"] and d["guard"]["fenced"] and d["guard"]["pending"] > 0, d

@@ -244,6 +244,48 @@ def test_head_streams_option_gives_the_same_gaussians():
     m.head_streams = False
 
 
+@pytest.mark.gpu
+def test_f16x3_maxima_words_across_streams_and_graph_replays(monkeypatch):
+    """the f16x3 |max| word arena is keyed by (device, stream, capture state) and every captured graph zero-fills its own
+    arena on replay.  (i) f16x3 with `head_streams` (words produced and consumed on side streams) equals the single-stream f16x3 result,
+    repeatedly; (ii) the per-stream-segment graphs in f16x3 follow new inputs over several replays, including inputs 8x SMALLER than the
+    captured ones right after larger ones -- a word that is not re-zeroed keeps the larger maximum and the fp16 pieces of the small
+    tensors lose up to three bits."""
+    from styl3r_amd import vit_ops
+    from styl3r_amd.graphs import StreamGraphedEncoder
+    from tests.gpu_utils import assert_close_rel
+    dev = "cuda:0"
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+    vit_ops._x6()
+    try:
+        m = deterministic_init_(_build(0)).to(dev)
+        T = lambda k: torch.tensor(G[f"sh0_{k}"], device=dev)
+        ctx, style = dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style"))
+        names = ("means", "covariances", "harmonics", "opacities")
+        with torch.no_grad():
+            ref = m(ctx, style, 0)
+            m.head_streams = True
+            for _ in range(3):
+                got = m(ctx, style, 0)
+                torch.cuda.synchronize()
+                for n in names:
+                    assert_close_rel(getattr(got, n).cpu().numpy(), getattr(ref, n).cpu().numpy(), 1e-4, "head_streams f16x3: " + n)
+            m.head_streams = False
+        genc = StreamGraphedEncoder(m, ctx, style)
+        small = dict(image=(ctx["image"] * 0.125).contiguous(), intrinsics=ctx["intrinsics"])
+        big = dict(image=(ctx["image"] * 0.9 + 0.05).contiguous(), intrinsics=ctx["intrinsics"])
+        for inp in (big, small, big, small):
+            with torch.no_grad():
+                want = m(inp, style, 0)
+            got = genc(inp, style)
+            torch.cuda.synchronize()
+            for n in names:
+                assert_close_rel(getattr(got, n).cpu().numpy(), getattr(want, n).cpu().numpy(), 1e-4, "graph replay f16x3: " + n)
+    finally:
+        vit_ops.LINEAR_MODE = "bf16x6"
+        vit_ops._x6()
+
+
 # ---- StructureBuilder + the 2-view `noposplat_token_style` registry entry ------------------------------------------------
 SB = np.load(Path(__file__).resolve().parent / "golden" / "structure_builder.npz")
 SB_TINY = dict(enc_depth=1, dec_depth=12, enc_embed_dim=128, dec_embed_dim=128, enc_num_heads=2, dec_num_heads=2,
