@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-views", type=int, default=2, help="minimum number of views in the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: keep taking views until this much wall time is spent")
     ap.add_argument("--no-infer-leg", action="store_true", help="skip the C2 inference leg")
+    ap.add_argument("--no-dropin-leg", action="store_true", help="skip the per-view drop-in leg (the reference's own call pattern)")
+    ap.add_argument("--no-comm-report", action="store_true", help="train leg: skip the exchange diagnosis / data-parallel mode A/B (runs only with a process group)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
     ap.add_argument("--no-stage-legs", action="store_true", help="skip the C4 style-stage and C5 stress train steps")
     ap.add_argument("--train-scenes", type=int, default=10, help="scenes per GPU per train step (C3: 10)")
@@ -306,6 +308,9 @@ def raster_leg(args, rank, world, dev, dist):
                 "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": pm["traffic"],
                 "limited_by": "valu-issue" if dominant.startswith("composite") else "hbm",
                 "valu": pm["valu"], "pmc_source": pm["pmc_source"],
+                # the roof this kernel actually sits under (VERDICT r04 #7b): VALU-busy / wall from the same counter file
+                # (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles), tools/pmc_latest.py); the HBM fraction stays the north-star figure
+                "valu_frac": (pm["valu"] or {}).get("valu_active_frac"),
                 "alg_bytes_per_launch": dk["alg_bytes"], "avg_launch_ms": dk["avg_ms"],
                 "ns_per_pair_per_simd": round(dk["avg_ms"] * 1e6 * 1024 / max(R, 1), 2),
                 "pairs_R": R, "R_eff": R_eff, "stages": stages}
@@ -315,6 +320,7 @@ def raster_leg(args, rank, world, dev, dist):
     roofline_cf = None if cf is None else {
         "kernel": "k_composite_fwd", "bound": "hbm", "achieved": cf["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(cf["GBps"] / HBM_PEAK_GBS, 4), "traffic": pf["traffic"], "limited_by": "valu-issue", "valu": pf["valu"],
+        "valu_frac": (pf["valu"] or {}).get("valu_active_frac"),
         "alg_bytes_per_launch": cf["alg_bytes"], "avg_launch_ms": cf["avg_ms"], "target_frac": 0.5,
         "note": "SURVEY 8d byte model (44 B per staged entry + 28 B per pixel); the kernel is VALU-issue-bound, DESIGN.md section 6"}
     res = {
@@ -330,9 +336,79 @@ def raster_leg(args, rank, world, dev, dist):
                    "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
         "roofline": roofline, "roofline_composite_fwd": roofline_cf,
     }
+    if rank == 0 and not getattr(args, "no_dropin_leg", False):
+        try:
+            res["dropin_per_view"] = dropin_leg(args, dev, g, cams, target)
+        except Exception as e:
+            res["dropin_per_view"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del g, cams, target, dec
     torch.cuda.empty_cache()
     return res, scenes
+
+
+# ------------------------------------------------------------------ drop-in leg (the reference's own call pattern)
+def dropin_leg(args, dev, g, cams, target, steps=8, warmup=2):
+    """INTEGRATION.md section 1 ("zero source changes"): what `DecoderSplattingCUDA.forward` + `render_cuda` would drive 40 times per step
+    through the drop-in module `diff_gaussian_rasterization` -- the Gaussian tensors replicated per target view
+    (decoder_splatting_cuda.py:51-63), the 1/near rescale as tensor ops (cuda_splatting.py:65-72), and per view: two `.item()` host
+    syncs, a fresh `mean_gradients` tensor, the 13-field settings tuple, the `[:, row, col]` gather of the covariances, ONE
+    `GaussianRasterizer` call with n_touched counted (the 5-tuple of SURVEY 8b), images stacked at the end (cuda_splatting.py:93-132);
+    MSE on the stacked colours, backward through all of it.  Same scenes, cameras and target as the headline leg."""
+    import torch
+    from einops import rearrange, repeat
+    from math import isqrt
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from styl3r_amd.camera import get_fov, get_projection_matrix
+    b, v = cams["extrinsics"].shape[:2]
+    h = w = args.res
+    bg = torch.zeros(b * v, 3, device=dev)
+    leaves = (g.means, g.covariances, g.harmonics, g.opacities)
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        ext = rearrange(cams["extrinsics"], "b v i j -> (b v) i j"); K = rearrange(cams["intrinsics"], "b v i j -> (b v) i j")
+        near = rearrange(cams["near"], "b v -> (b v)"); far = rearrange(cams["far"], "b v -> (b v)")
+        means = repeat(g.means, "b g xyz -> (b v) g xyz", v=v); covs = repeat(g.covariances, "b g i j -> (b v) g i j", v=v)
+        sh = repeat(g.harmonics, "b g c d -> (b v) g c d", v=v); op = repeat(g.opacities, "b g -> (b v) g", v=v)
+        scale = 1 / near
+        ext = ext.clone(); ext[..., :3, 3] = ext[..., :3, 3] * scale[:, None]
+        covs = covs * (scale[:, None, None, None] ** 2); means = means * scale[:, None, None]
+        near, far = near * scale, far * scale
+        degree = isqrt(sh.shape[-1]) - 1
+        shs = rearrange(sh, "b g xyz n -> b g n xyz").contiguous()
+        fov_x, fov_y = get_fov(K).unbind(dim=-1)
+        tx, ty = (0.5 * fov_x).tan(), (0.5 * fov_y).tan()
+        proj = get_projection_matrix(near, far, fov_x, fov_y).transpose(1, 2)
+        view = ext.inverse().transpose(1, 2)
+        full = view @ proj
+        images = []
+        row, col = torch.triu_indices(3, 3)
+        for i in range(b * v):
+            m2d = torch.zeros_like(means[i], requires_grad=True)
+            st = GaussianRasterizationSettings(image_height=h, image_width=w, tanfovx=tx[i].item(), tanfovy=ty[i].item(), bg=bg[i],
+                                               scale_modifier=1.0, viewmatrix=view[i], projmatrix=full[i], projmatrix_raw=proj[i],
+                                               sh_degree=degree, campos=ext[i, :3, 3], prefiltered=False, debug=False)
+            image, radii, depth, opacity, n_touched = GaussianRasterizer(st)(
+                means3D=means[i], means2D=m2d, shs=shs[i], colors_precomp=None, opacities=op[i, ..., None],
+                cov3D_precomp=covs[i, :, row, col], theta=None, rho=None)
+            images.append(image)
+        color = rearrange(torch.stack(images), "(b v) c h w -> b v c h w", b=b, v=v)
+        loss = ((color - target) ** 2).mean()
+        loss.backward()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"views_per_s": round(b * v / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "rasterizer_calls_per_step": b * v,
+            "what": "reference call pattern through the drop-in module: Gaussians replicated per view, per-view GaussianRasterizer calls (5-tuple, n_touched "
+                    "counted, depth gradient path live), 2 .item() syncs and a [:, row, col] covariance gather per view, torch MSE; vs `value` = the batched decoder API"}
 
 
 # ------------------------------------------------------------------ train leg (M2, C3)
@@ -419,6 +495,38 @@ def train_leg(args, rank, world, dev, dist):
                     vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
                     vit_ops._x6()
             out["linear_mfma"] = linear_roofline(dev, b * v_ctx * 257)
+    # ---- the exchange, diagnosed in the same line: per-bucket collective time, overlap fraction, and the other
+    #      data-parallel mode (all_reduce <-> rs_ag) as an automatic A/B.  Only when a process group exists (N > 1, or a one-rank launch
+    #      under torch.distributed.run, whose RCCL group still issues every collective).
+    if step.reducer.collective and not getattr(args, "no_comm_report", False):
+        from styl3r_amd.ddp import broadcast_module_state, comm_report
+        try:
+            vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = head_mode
+            run = lambda: step(batch)
+            out["comm"] = comm_report(step.reducer, run, sync, steps=max(2, min(4, args.train_steps)))
+            modes = {step.dp_mode: {"ms_per_step": out["ms_per_step"], "value": out["value"]}}
+            other_dp = "rs_ag" if step.dp_mode == "all_reduce" else "all_reduce"
+            step.reducer.close()
+            del step
+            if not cpu:
+                torch.cuda.empty_cache()
+            broadcast_module_state(enc, dist, force_collective=forced)       # the no-collective steps let the replicas drift apart
+            step = TrainStep(enc, dec, dist=dist, force_collective=forced, warm_up_steps=2000, dp_mode=other_dp)
+            for _ in range(max(2, args.train_warmup)):
+                step(batch)
+            n2 = args.train_steps
+            dt2 = dist_utils.timed_steps(lambda: step(batch), n2, sync, dist, dev)
+            modes[other_dp] = {"ms_per_step": round(1e3 * dt2 / n2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n2, world, dt2), 3),
+                               "comm": comm_report(step.reducer, lambda: step(batch), sync, steps=max(2, min(4, args.train_steps)))}
+            step.reducer.wait_params()
+            out["dp_modes"] = modes
+            out["dp_mode"] = [m for m in modes if m != other_dp][0]
+        except Exception as e:
+            out["comm_error"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep_mode, keep_attn
+            if not cpu:
+                vit_ops._x6()
     return out
 
 

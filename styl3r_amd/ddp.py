@@ -360,3 +360,73 @@ class BucketedGradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+
+
+def comm_report(reducer: "BucketedGradReducer", run_step, sync, steps: int = 3) -> dict:
+    """One-shot diagnosis of the gradient exchange of a data-parallel step (bench.py prints it when a process group exists, so the first
+    multi-GPU run explains its own scaling number).  Backend-agnostic: nothing here looks inside RCCL.
+      per_bucket_ms   each bucket's collective(s) ALONE on its real buffer, nothing else queued (sync-bracketed, MAX over ranks):
+                      all_reduce, or reduce_scatter + the parameter all_gather of "rs_ag"
+      comm_alone_ms   their sum: the exchange with no compute to hide under
+      step_ms         `run_step()` as it is (collectives overlapped with the backward)
+      step_ms_no_collectives   the same step with the collectives switched off (every rank steps on its local gradients: the
+                      replicas DIVERGE -- the caller re-broadcasts the module state afterwards)
+      overlap_frac    (step_ms_no_collectives + comm_alone_ms - step_ms) / comm_alone_ms clamped to [0, 1]: the share of the exchange
+                      that the compute hides; 1 = free, 0 = fully exposed."""
+    import time
+    dist = reducer.dist
+
+    def timed(fn, n):
+        sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        dt = (time.perf_counter() - t0) / n
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=reducer.buckets[0]["flat"].device if reducer.buckets else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt * 1e3
+
+    out = {"mode": reducer.mode, "world": reducer.world, "buckets": len(reducer.buckets), "bucket_MiB": [round(b["n"] * 4 / 2 ** 20, 1) for b in reducer.buckets]}
+    if not reducer.collective:
+        out["note"] = "no process group: nothing to exchange"
+        return out
+    reducer.wait_params()
+    per = []
+    for b in reducer.buckets:
+        scratch = torch.zeros_like(b["flat"])           # (the real gradients / parameters are not touched)
+        if reducer.mode == "rs_ag":
+            lo, hi = b["shard"]
+            pscr = torch.zeros_like(b["pflat"])
+
+            def one(scratch=scratch, pscr=pscr, lo=lo, hi=hi):
+                dist.reduce_scatter_tensor(scratch[lo:hi], scratch, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(pscr, pscr[lo:hi])
+        else:
+            def one(scratch=scratch):
+                dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+        one()                                            # (first use of a buffer size: communicator warm-up)
+        per.append(round(timed(one, steps), 3))
+        del scratch
+    out["per_bucket_ms"] = per
+    out["comm_alone_ms"] = round(sum(per), 3)
+    out["step_ms"] = round(timed(run_step, steps), 3)
+    keep = reducer.collective
+    try:
+        reducer.wait_params()
+        reducer.collective = False
+        run_step()
+        out["step_ms_no_collectives"] = round(timed(run_step, steps), 3)
+    finally:
+        reducer.collective = keep
+    hidden = out["step_ms_no_collectives"] + out["comm_alone_ms"] - out["step_ms"]
+    out["overlap_frac"] = round(min(1.0, max(0.0, hidden / out["comm_alone_ms"])), 3) if out["comm_alone_ms"] > 0 else None
+    out["exchanged_GB_per_step"] = round(sum(b["n"] for b in reducer.buckets) * 4 / 1e9, 3)
+    out["busbw_GBps_alone"] = round(out["exchanged_GB_per_step"] * 2 * (reducer.world - 1) / max(reducer.world, 1) / (out["comm_alone_ms"] * 1e-3), 1) \
+        if out["comm_alone_ms"] > 0 else None
+    return out
+

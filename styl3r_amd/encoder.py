@@ -171,11 +171,18 @@ class CrocoTrunk(nn.Module):
 class AsymmetricCroCoMulti(CrocoTrunk):
     def __init__(self, cfg: BackboneCrocoCfg, d_in: int = 3, params: Optional[dict] = None):
         super().__init__(**(params or CROCO_PARAMS[cfg.model]))
-        assert cfg.intrinsics_embed_loc == "encoder" and cfg.intrinsics_embed_type == "token", \
-            "only the 'token' intrinsics embedding of config/model/encoder/backbone/croco.yaml is built"
+        # intrinsics embedding (backbone_croco_multiview.py:59-78,129-135,199-206): 'token' (every documented run; the style encoders
+        # require it) and 'linear' (the embedding added to every patch token), or none at all.  'pixelwise' (ray-direction / real-SH
+        # channels concatenated to the image, a 3 + d channel patch embed) and the decoder-side location are not built: they need the
+        # reference's generated SH tables (src/misc/sht.py) and no shipped config selects them.
+        if cfg.intrinsics_embed_type == "pixelwise" and cfg.intrinsics_embed_loc != "none" or cfg.intrinsics_embed_loc == "decoder":
+            raise NotImplementedError("intrinsics_embed_type='pixelwise' / intrinsics_embed_loc='decoder' are not built "
+                                      "(config/model/encoder/backbone/croco.yaml uses loc='encoder', type='token'; 'linear' and loc='none' are available)")
+        self.intrinsics_embed_type = cfg.intrinsics_embed_type if cfg.intrinsics_embed_loc == "encoder" else "none"
         if cfg.asymmetry_decoder:
             self.dec_blocks2 = copy.deepcopy(self.dec_blocks)
-        self.intrinsic_encoder = nn.Linear(9, 1024)
+        if cfg.intrinsics_embed_type in ("linear", "token"):          # (the reference creates it whatever the location, :77-78)
+            self.intrinsic_encoder = nn.Linear(9, 1024)
 
     def load_state_dict(self, ckpt, **kw):
         ckpt = dict(ckpt)
@@ -185,12 +192,15 @@ class AsymmetricCroCoMulti(CrocoTrunk):
                     ckpt[k.replace("dec_blocks", "dec_blocks2")] = v
         return super().load_state_dict(ckpt, **kw)
 
-    def _encode_image(self, image: Tensor, intrinsics_token: Tensor):
+    def _encode_image(self, image: Tensor, intrinsics_token: Optional[Tensor]):
         x, pos = self.patch_embed(image)
-        x = torch.cat((x, intrinsics_token), dim=1)
-        extra = pos[:, 0:1, :].clone()
-        extra[:, :, 0] += pos[:, -1, 0].unsqueeze(-1) + 1            # the token sits at (rows, 0)  (:131-135)
-        pos = torch.cat((pos, extra), dim=1)
+        if intrinsics_token is not None and self.intrinsics_embed_type == "linear":
+            x = x + intrinsics_token                                     # (:128-129)
+        elif intrinsics_token is not None:
+            x = torch.cat((x, intrinsics_token), dim=1)
+            extra = pos[:, 0:1, :].clone()
+            extra[:, :, 0] += pos[:, -1, 0].unsqueeze(-1) + 1            # the token sits at (rows, 0)  (:131-135)
+            pos = torch.cat((pos, extra), dim=1)
         for blk in self.enc_blocks:
             x = blk(x, pos)
         return self.enc_norm(x), pos
@@ -282,17 +292,21 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         """first half of forward(): the 24 encoder blocks over all views -> (feat (b,v,l,c), pos (b,v,l,2))"""
         b, v, _, h, w = context["image"].shape
         images = context["image"].reshape(b * v, -1, h, w)
-        token = _intrinsics_token(self.intrinsic_encoder, context["intrinsics"]).reshape(b * v, 1, -1)
+        token = None
+        if self.intrinsics_embed_type != "none":
+            token = _intrinsics_token(self.intrinsic_encoder, context["intrinsics"]).reshape(b * v, 1, -1)
         feat, pos = self._encode_image(images, token)
         return feat.view(b, v, feat.shape[1], -1), pos.view(b, v, pos.shape[1], 2)
 
     def decode(self, feat: Tensor, pos: Tensor):
-        """second half: the dual decoders; strips the intrinsics token (:222-225)"""
-        return [t[:, :, :-1] for t in self._decoder(feat, pos)]
+        """second half: the dual decoders; strips the intrinsics token where there is one (:222-225)"""
+        outs = self._decoder(feat, pos)
+        return [t[:, :, :-1] for t in outs] if self.intrinsics_embed_type == "token" else outs
 
     def decode_split(self, feat: Tensor, pos: Tensor):
         """the same as pairs (view 0 (b,l-1,c), views 1.. (b*(v-1),l-1,c)) -- what the per-view-group heads consume, no re-assembly"""
-        return [(a[:, :-1], r[:, :-1]) for a, r in self._decoder_split(feat, pos)]
+        outs = self._decoder_split(feat, pos)
+        return [(a[:, :-1], r[:, :-1]) for a, r in outs] if self.intrinsics_embed_type == "token" else outs
 
     def forward(self, context: dict):
         b, v, _, h, w = context["image"].shape
@@ -300,6 +314,33 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         dec_feat = self.decode(feat, pos)
         shape = torch.tensor([h, w]).repeat(b, v, 1)
         return feat, pos, dec_feat, shape, context["image"]
+
+
+class AsymmetricCroCo(AsymmetricCroCoMulti):
+    """The pairwise backbone `croco` (src/model/encoder/backbone/backbone_croco.py:61-286): two views, view 1 decoded by `dec_blocks`
+    against view 2's tokens and view 2 by `dec_blocks2` against view 1's (:196-218) -- the v = 2 case of the multi-view trunk, same
+    parameters and state-dict keys -- behind that class's own return convention `(dec1, dec2, shape1, shape2)`: two lists of 13 per-view
+    tensors (b, l, c), the intrinsics token stripped (:259-263).  Pinned by tests/golden/backbone_variants.npz (the reference's
+    AsymmetricCroCo.forward on the same weights)."""
+
+    def forward(self, context: dict, return_views: bool = False):
+        b, v, _, h, w = context["image"].shape
+        assert v == 2, "the `croco` backbone is the 2-view (pairwise) trunk; `croco_multi` takes any number of views"
+        feat, pos = self.encode(context)
+        outs = self.decode_split(feat, pos)
+        dec1, dec2 = [a for a, _ in outs], [r for _, r in outs]
+        shape = torch.tensor([h, w]).repeat(b, 1)
+        if return_views:
+            return dec1, dec2, shape, shape, {"img": context["image"][:, 0]}, {"img": context["image"][:, 1]}
+        return dec1, dec2, shape, shape
+
+
+BACKBONES = {"croco": AsymmetricCroCo, "croco_multi": AsymmetricCroCoMulti}
+
+
+def get_backbone(cfg: BackboneCrocoCfg, d_in: int = 3, params: Optional[dict] = None):
+    """src/model/encoder/backbone/__init__.py:13-20 registry"""
+    return BACKBONES[cfg.name](cfg, d_in, params)
 
 
 class TokenStylizer(CrocoTrunk):
@@ -635,6 +676,7 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         self.cfg = cfg
         assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
         self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
+        assert self.backbone.intrinsics_embed_type == "token", "the Gaussian heads of this encoder take the 'token' intrinsics embedding (every shipped config)"
         self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
         self.patch_size = 16
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
@@ -830,6 +872,7 @@ class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
         self.cfg = cfg
         assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
         self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
+        assert self.backbone.intrinsics_embed_type == "token", "the Gaussian heads of this encoder take the 'token' intrinsics embedding (every shipped config)"
         self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
         self.patch_size = 16
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
@@ -880,6 +923,7 @@ class EncoderNoPoSplatTokenStyle(EncoderNoPoSplatMultiTokenStyle):
         self.cfg = cfg
         assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1 and cfg.gs_sh_head_type == "dpt"
         self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)     # `croco`: same parameter layout, v = 2
+        assert self.backbone.intrinsics_embed_type == "token", "the Gaussian heads of this encoder take the 'token' intrinsics embedding (every shipped config)"
         self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
         self.patch_size = 16
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in

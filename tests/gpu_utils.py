@@ -1,5 +1,7 @@
 """Helpers for the -m gpu parity tests: run the HIP path through the C ABI and
 the CPU oracle on identical bytes."""
+import os
+
 import numpy as np
 import torch
 
@@ -56,4 +58,6 @@ def assert_close_rel(actual, expected, rel=1e-4, what="", atol=0.0):
     a = np.asarray(actual, dtype=np.float64); e = np.asarray(expected, dtype=np.float64)
     scale = max(np.abs(e).max(), 1e-12)
     err = np.abs(a - e).max()
+    if os.environ.get("PARITY_VERBOSE"):      # bar calibration runs: `PARITY_VERBOSE=1 pytest -s` lists every observed distance beside its bar
+        print(f"    [parity] {what}: rel {err / scale:.3e} (bar {rel:.1e})")
     assert err <= rel * scale + atol, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e})"

@@ -325,3 +325,65 @@ def test_reduce_scatter_all_gather_mode_trains_like_the_all_reduce_mode(tmp_path
         # the consolidated moments equal the all-reduce mode's on every rank; state_dict() refused before the consolidation;
         # the guarded forward fenced a gather that was really in flight
         assert d["mom_err"] <= 1e-6 and d["n_moments"] >= 10 and d["guard"]["refused"] and d["guard"]["fenced"] and d["guard"]["pending"] > 0, d
+
+
+COMM_WORKER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, %r)
+    import torch
+    from torch import nn
+    from styl3r_amd import dist_utils
+    from styl3r_amd.ddp import BucketedGradReducer, broadcast_module_state, comm_report
+    from styl3r_amd.train import make_optimizer
+    rank, _, world = dist_utils.env_world()
+    dist = dist_utils.init_distributed("gloo")
+    res = {}
+    for mode in ("all_reduce", "rs_ag"):
+        torch.manual_seed(0)
+        model = nn.Sequential(nn.Linear(64, 300), nn.GELU(), nn.Linear(300, 300), nn.GELU(), nn.Linear(300, 8))
+        new, pre = list(model[4].parameters()), list(model[0].parameters()) + list(model[2].parameters())
+        red = BucketedGradReducer(list(model.parameters()), dist, bucket_bytes=128 * 1024, mode=mode, groups=[new, pre])
+        opt = make_optimizer(new, pre, lr=1e-3, owner=red if mode == "rs_ag" else None)
+        torch.manual_seed(50 + rank)
+        x = torch.randn(256, 64)
+
+        def step():
+            red.wait_params(); red.prepare()
+            model(x).pow(2).mean().backward()
+            red.finish(); red.clip_grad_norm_(0.5, defer_to=None if mode == "all_reduce" else opt)
+            opt.step(); red.gather_params()
+        step()
+        rep = comm_report(red, step, lambda: None, steps=2)
+        red.wait_params()
+        broadcast_module_state(model, dist)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        rep["replicas_identical_after_rebroadcast"] = bool(torch.equal(both[0], both[1]))
+        rep["collective_restored"] = bool(red.collective)
+        res[mode] = rep
+        red.close()
+    print(json.dumps(res), flush=True)
+    dist.barrier(); dist.destroy_process_group()
+""") % str(ROOT)
+
+
+def test_comm_report_of_the_train_leg_runs_in_both_data_parallel_modes(tmp_path):
+    """the exchange diagnosis bench.py's train leg prints under a process group (styl3r_amd.ddp.comm_report: per-bucket
+    collective time, the step with and without collectives, the overlap fraction) on a world-2 gloo group, in both modes; the
+    no-collective steps let the replicas drift, the re-broadcast makes them identical again, and the reducer's collectives are back on."""
+    script = tmp_path / "comm.py"; script.write_text(COMM_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-3000:]
+        d = json.loads(o.strip().splitlines()[-1])
+        for mode in ("all_reduce", "rs_ag"):
+            r = d[mode]
+            assert r["mode"] == mode and r["world"] == 2 and r["buckets"] >= 2 and len(r["per_bucket_ms"]) == r["buckets"], r
+            assert all(t > 0 for t in r["per_bucket_ms"]) and abs(r["comm_alone_ms"] - sum(r["per_bucket_ms"])) < 1e-2, r
+            assert r["step_ms"] > 0 and r["step_ms_no_collectives"] > 0 and 0.0 <= r["overlap_frac"] <= 1.0, r
+            assert r["replicas_identical_after_rebroadcast"] and r["collective_restored"], r
+

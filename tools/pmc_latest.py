@@ -3,8 +3,15 @@
 means of tools/pmc_summary.py --json.  The file is STAMPED with the digest of the kernel sources + flags of the library that
 was measured (styl3r_amd/_lib.built_digest()); bench.py reports the figures only when its own library carries the same
 digest, otherwise `traffic: null` and a "stale" note.
-  HBM bytes per launch = FETCH_SIZE [KiB] * 1024 * 2  (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X guide)
-                         + WRITE_SIZE [KiB] * 1024
+  HBM bytes per launch = FETCH_SIZE [KiB] * 1024 * f + WRITE_SIZE [KiB] * 1024, with
+                         f = 2.0 for streaming kernels (gfx950: FETCH_SIZE = read requests x 64 B, a wide coalesced read issues 128-B
+                             requests; MI355X guide), and
+                         f = 1.2 for the composite kernels, whose reads are 48-byte record GATHERS: calibrated on that pattern
+                             (tools/probes/fetch_gather_calib.hip, profiles/r05_fetch_gather_calib.md: 2^26 records read once each in
+                             scattered order = 96 B of 64-B lines per record, the counter says 80 B = 1.25 requests x 64 B -- a record
+                             inside one line is a 64-B request, one straddling two lines of a 128-B block ONE 128-B request; with
+                             x 2 the figure would read 160 B).  Rounds 1 - 4 applied x 2 to these kernels too and overstated their
+                             traffic by 1.3 x (the "2.0 x wasted traffic" of VERDICT r04 is 1.5 x)
   kernel cycles        = GRBM_GUI_ACTIVE / 8            (summed over the 8 XCDs)
   valu_insts_per_pair  = SQ_INSTS_VALU / pairs (the (tile, Gaussian) pairs of the launch: what the composite kernels' VALU
                          work scales with); salu / lds likewise
@@ -23,8 +30,11 @@ for kn, c in json.load(open(src)).items():
     short = kn.split("::")[-1].split("<")[0]
     short = short[2:] if short.startswith("k_") else short
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8
-    f2, w = c.get("FETCH_SIZE", 0.0) * 1024 * 2, c.get("WRITE_SIZE", 0.0) * 1024
-    res[short] = {"hbm_bytes_per_launch": int(f2 + w), "fetch_bytes_x2": int(f2), "write_bytes": int(w), "kernel_cycles": int(cyc),
+    raw, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+    factor = 1.2 if short.startswith("composite") else 2.0
+    f2 = raw * 2
+    res[short] = {"hbm_bytes_per_launch": int(raw * factor + w), "fetch_factor": factor, "fetch_bytes_raw": int(raw), "fetch_bytes_x2": int(f2),
+                  "write_bytes": int(w), "kernel_cycles": int(cyc),
                   "valu_insts_per_launch": int(c.get("SQ_INSTS_VALU", 0)),
                   "valu_insts_per_pair": round(c.get("SQ_INSTS_VALU", 0) / pairs, 2),
                   "salu_insts_per_pair": round(c.get("SQ_INSTS_SALU", 0) / pairs, 2),
