@@ -144,6 +144,26 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
  */
 size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);
 int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
+/*
+ * Every weight image of a model in ONE launch (what an optimizer step invalidates): jobs = device array sorted by first_block, one per image.
+ *   kind bit 0: pack w^T (as transpose = 1 above); bit 1: the BLOCK layout of vit_split_weight_block, else the layout of vit_split_weight.
+ *   first_block / nbx: the job owns workgroups [first_block, first_block + nbx * ceil(R / 64)), nbx = ceil(Kc / 64), with R x Kc the
+ *   output rows x contraction length of the image (R = transpose ? cols : rows).  amax / tail: f16x3 only -- the weight's |max| word and
+ *   where the image keeps its copy (right behind the pieces, as the single-weight calls place it).
+ * The arithmetic mode is the calling thread's (vit_x6_set_products).  Results are byte-identical to the single-weight calls.
+ */
+typedef struct VitSplitJob {
+    const float *w;
+    void *packed;
+    const uint32_t *amax;
+    uint32_t *tail;
+    int32_t rows, cols;
+    int32_t kind;
+    uint32_t first_block;
+    uint32_t nbx;
+    uint32_t reserved;
+} VitSplitJob;
+int vit_split_weights_many(const VitSplitJob *jobs_device, int n_jobs, uint32_t total_blocks, void *stream);
 int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                        int M, int N, int K, int act, int cfg, void *stream);
 /*

@@ -92,13 +92,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     // the kernel two waves per SIMD of occupancy.
     for (int hi = max_last; hi > 0; hi -= 64) {
         const int cnt = min(64, hi);
-        __syncthreads();
+        // (single-wave workgroup: its LDS instructions execute in order, so a compiler barrier orders the staging stores against the
+        //  previous batch's reads -- a __syncthreads would also wait, s_waitcnt vmcnt(0), for every gradient atomic still in flight)
+        asm volatile("" ::: "memory");
         if (lane < cnt) {
             const uint32_t bm = ws.block_mask[start + hi - 1 - lane];   // exact block masks of the forward, 8 bits per quadrant
             const uint32_t quad = ((bm & 0xffu) ? 1u : 0u) | ((bm & 0xff00u) ? 2u : 0u) | ((bm & 0xff0000u) ? 4u : 0u) | ((bm >> 24) ? 8u : 0u);
             stage_entry_bwd(recs, plist[hi - 1 - lane], quad, s_q + lane * 3);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // (reading entry j + 1 ahead of time was measured: +12 VGPRs drop the kernel from 5 to 4 waves per SIMD, -6 %)
         for (int j = 0; j < cnt; ++j) {
             const uint32_t entry = (uint32_t)(hi - 1 - j);  // 0-based position in the list

@@ -700,7 +700,72 @@ __global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w
         o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
     }
 }
+// All the weight images of a model in ONE launch (after an optimizer step every weight changed: the per-weight launches above were
+// 1 274 launches and 12 ms of a 285 ms train step at 1.4 TB/s -- launch-bound).  A job = one image of one weight; a workgroup = one
+// 64-row x 64-k tile of one job (binary search over the jobs' first-block table), staged through LDS exactly as k_split_block does, then
+// written in the job's layout: kind bit 1 = the BLOCK layout above, else the MFMA-order layout of vit_split_weight
+// (packed[row][k / 8][piece][8]); kind bit 0 = pack w^T.  Same bytes as the single-weight kernels (tests/test_gpu_vit.py compares them).
+template <int NPROD>
+__global__ void __launch_bounds__(256) k_split_many(const VitSplitJob *__restrict__ jobs, int njobs)
+{
+    int lo = 0, hi = njobs - 1;                        // last job whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const VitSplitJob jb = jobs[lo];
+    const uint32_t local = blockIdx.x - jb.first_block;
+    const int bx = (int)(local % jb.nbx), rb = (int)(local / jb.nbx);
+    const int rows = jb.rows, cols = jb.cols, transpose = jb.kind & 1, block = jb.kind & 2;
+    const float *__restrict__ w = jb.w;
+    uint4 *__restrict__ packed = static_cast<uint4 *>(jb.packed);
+    if (NPROD == 2 && local == 0 && threadIdx.x < 64) jb.tail[threadIdx.x * AMAX_STRIDE] = jb.amax[threadIdx.x * AMAX_STRIDE];
+    const float sw = NPROD == 2 ? f16_scale(amax_line(jb.amax)) : 1.f;
+    const int R_ = transpose ? cols : rows, K_ = transpose ? rows : cols, KG = K_ >> 3;
+    __shared__ float s[64][65];
+    const int k0 = bx * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        int r, k;
+        if (transpose) { k = i >> 6; r = i & 63; } else { r = i >> 6; k = i & 63; }
+        const int R = rb * 64 + r, Kx = k0 + k;
+        float v = 0.f;
+        if (R < R_ && Kx < K_) v = transpose ? w[(int64_t)Kx * cols + R] : w[(int64_t)R * cols + Kx];
+        s[r][k] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+        // block layout: consecutive threads = consecutive rows of one (k group, piece) plane; row-major layout: consecutive threads =
+        // consecutive k groups of one row (48 contiguous bytes each)
+        const int kg = block ? (i >> 6) : (i & 7), r = block ? (i & 63) : (i >> 3);
+        if (k0 + kg * 8 >= K_) continue;
+        const float4 lo4 = make_float4(s[r][kg * 8 + 0], s[r][kg * 8 + 1], s[r][kg * 8 + 2], s[r][kg * 8 + 3]);
+        const float4 hi4 = make_float4(s[r][kg * 8 + 4], s[r][kg * 8 + 5], s[r][kg * 8 + 6], s[r][kg * 8 + 7]);
+        bf16x8 f0, f1, f2;
+        split8s<NPROD>(lo4, hi4, sw, f0, f1, f2);
+        if (block) {
+            uint4 *o = packed + (((int64_t)rb * KG + (k0 >> 3) + kg) * 3) * 64 + r;
+            o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
+        } else if (rb * 64 + r < R_) {
+            uint4 *o = packed + ((int64_t)(rb * 64 + r) * KG + (k0 >> 3) + kg) * 3;
+            o[0] = __builtin_bit_cast(uint4, f0); o[1] = __builtin_bit_cast(uint4, f1);
+            if (NPROD != 2) o[2] = __builtin_bit_cast(uint4, f2);      // (f16x3 never reads slot 2)
+        }
+    }
+}
 }  // namespace x6r
+
+int split_weights_many(const VitSplitJob *jobs_dev, int njobs, uint32_t total_blocks, hipStream_t stream)
+{
+    if (!jobs_dev || njobs <= 0 || total_blocks == 0) return VIT_EINVAL;
+    (void)hipGetLastError();
+    const int np = x6_products();
+    if (np == 2) hipLaunchKernelGGL(x6r::k_split_many<2>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
+    else if (np == 3) hipLaunchKernelGGL(x6r::k_split_many<3>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
+    else hipLaunchKernelGGL(x6r::k_split_many<6>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
 
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream)
 {

@@ -11,6 +11,7 @@ import os
 import torch
 from torch import nn
 
+from . import vit_ops
 from .ddp import BucketedGradReducer, broadcast_module_state
 from .losses import mse_loss
 
@@ -47,6 +48,10 @@ def select_trainable(encoder: nn.Module) -> Tuple[List[nn.Parameter], List[nn.Pa
 OPTIMIZER_IMPL = os.environ.get("STYL3R_OPTIMIZER", "hip")      # "hip": styl3r_amd.optim.AdamWHIP (one launch per group) | "torch": torch.optim.AdamW(fused=True); CPU parameters always take torch's
 
 
+# 1 = all cached weight images are rebuilt by ONE launch right after the optimizer step (vit_ops.refresh_split_cache).  Measured (DESIGN R5.3): 4.7 ms
+# less kernel time per C3 step, 2 ms MORE wall time -- the ~1 270 lazy launches sit in host-bound stretches of the forward / backward where the GPU
+# would idle anyway, the batched kernel is 5.3 ms of serial GPU time at the step's end.  Default: off (lazy, as in rounds 1 - 4).
+BATCHED_RESPLIT = os.environ.get("STYL3R_RESPLIT", "0") == "1"
 DP_MODE = os.environ.get("STYL3R_DP_MODE", "all_reduce")       # "all_reduce" | "rs_ag" (reduce-scatter + sharded AdamW + parameter all-gather, ddp.py)
 
 
@@ -114,6 +119,7 @@ class TrainStep:
         if self.dp_mode == "rs_ag":
             self.reducer.guard_readers(encoder)   # validation forwards / checkpoints between two steps wait for the parameter all-gather
         self.scheduler = make_lr_scheduler(self.optimizer, warm_up_steps, max_steps, lr) if warm_up_steps else None
+        self._weights = [p for p in encoder.parameters() if id(p) in trainable and p.dim() == 2]
         self.global_step = 0
 
     def _render(self, ctx, style, tgt):
@@ -143,6 +149,10 @@ class TrainStep:
             self.reducer.clip_grad_norm_(self.clip, defer_to=self.optimizer)    # the fused AdamW applies the coefficient while it reads the gradients
         self.optimizer.step()
         self.reducer.gather_params()                                      # "rs_ag": asynchronous; fenced at the top of the next step
+        if BATCHED_RESPLIT and self.dp_mode != "rs_ag" and self._weights and self._weights[0].is_cuda:
+            # every cached split image of every updated weight in ONE launch (vit_ops.refresh_split_cache) instead of ~1 270 lazy ones
+            # during the next forward / backward.  ("rs_ag": the weights are complete only when the all-gather has landed.)
+            vit_ops.refresh_split_cache([p for p in self._weights if p.grad is not None])
         if self.scheduler is not None:
             self.scheduler.step()
         self.global_step += 1

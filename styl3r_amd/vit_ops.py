@@ -39,7 +39,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / "libvit_hip.so"
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -147,6 +147,8 @@ def load() -> C.CDLL:
     lib.vit_split_weight_block_bytes.restype = C.c_size_t
     lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight_block.restype = C.c_int
+    lib.vit_split_weights_many.argtypes = [vp, C.c_int, C.c_uint32, vp]
+    lib.vit_split_weights_many.restype = C.c_int
     lib.vit_linear_x6c_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
     lib.vit_linear_x6c_fwd.restype = C.c_int
     lib.vit_linear_x6c_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -619,6 +621,98 @@ def _dead_entry_ref(weight: Tensor, key):
     return weakref.ref(weight, drop)
 
 
+_SPLIT_JOB_DTYPE = None
+_SPLIT_PLAN: dict = {}        # (device index, mode) -> plan of the last refresh: reused while the same buffers serve the same weights
+
+
+def refresh_split_cache(params) -> int:
+    """After an optimizer step: rebuild EVERY cached image of the given 2-D weights (forward / transposed, MFMA-order / block layout, in the
+    current arithmetic mode) in ONE launch (vit_split_weights_many) instead of one launch per image at its next use -- ~1 270 launches and
+    12 ms of the C3 step.  Images that are not cached yet (first step), conv images (they go through a rearranged copy) and weights whose
+    f16x3 |max| word is not current (the optimizer did not publish it) are left to the lazy path.  Returns the number of images rebuilt.
+    The job table is built once: later calls only check that every image buffer / |max| word of the plan still serves its weight (identity
+    tests, ~1 ms of host time for 1 200 images) and that the weight really changed, then launch."""
+    global _SPLIT_JOB_DTYPE
+    import numpy as np
+    if LINEAR_MODE == "f32" or not _x6():
+        return 0
+    f16 = _f16()
+    params = [p for p in params if p.dim() == 2 and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()]
+    if not params:
+        return 0
+    dev = params[0].device
+    pkey = (dev.index, LINEAR_MODE)
+    plan = _SPLIT_PLAN.get(pkey)
+    if plan is not None:                                  # fast path
+        ok = len(plan["params"]) == len(params) and all(a is b for a, b in zip(plan["params"], params))
+        if ok:
+            cache, wam = _SPLIT_CACHE, _WEIGHT_AMAX
+            for key, p, packed, word in plan["entries"]:
+                hit = cache.get(key)
+                if hit is None or hit[3] is not packed or hit[2] != p.data_ptr() or hit[1] == p._version:
+                    ok = False; why = ("image", key, hit is None, hit is not None and hit[3] is not packed, hit is not None and hit[1] == p._version); break
+                if word:                                  # (the optimizer hands in a fresh view of the same word every step: compare addresses)
+                    hw = wam.get(key[0])
+                    if hw is None or hw[3].data_ptr() != word or hw[1] != p._version:
+                        ok = False; why = ("word", key, hw is None, hw is not None and hw[1] != p._version); break
+            if not ok and os.environ.get("VIT_SPLIT_DEBUG"):
+                print("refresh_split_cache: plan dropped:", why, flush=True)
+        elif os.environ.get("VIT_SPLIT_DEBUG"):
+            print("refresh_split_cache: plan dropped: parameter list changed", len(plan["params"]), len(params), flush=True)
+        if ok:
+            _check(load().vit_split_weights_many(plan["table"].data_ptr(), plan["njobs"], plan["blocks"], _stream(dev)), "vit_split_weights_many")
+            for key, p, packed, word in plan["entries"]:
+                hit = _SPLIT_CACHE[key]
+                _SPLIT_CACHE[key] = (hit[0], p._version, hit[2], packed)
+            CALLS["split_many_images"] += plan["njobs"]
+            CALLS["split_plan_reused"] += 1
+            return plan["njobs"]
+        _SPLIT_PLAN.pop(pkey, None)
+    jobs, entries = [], []
+    for p in params:
+        pid, ver, ptr = id(p), p._version, p.data_ptr()
+        word = None
+        if f16:
+            hw = _WEIGHT_AMAX.get(pid)
+            if hw is None or hw[0]() is not p or hw[1] != ver or hw[2] != ptr:
+                continue
+            word = hw[3]
+        N, K = p.shape
+        for transposed in (False, True):
+            for block in (False, True):
+                key = ((pid, "block_t" if transposed else "block") if block else (pid, transposed)) + (("f16",) if f16 else ())
+                hit = _SPLIT_CACHE.get(key)
+                if hit is None or hit[0]() is not p or hit[2] != ptr or hit[1] == ver:
+                    continue
+                R, Kc = (K, N) if transposed else (N, K)
+                if Kc % 8:
+                    continue
+                packed = hit[3]
+                tail = packed.data_ptr() + ((R + 63) // 64 * 64 if block else R) * Kc * 6
+                jobs.append((ptr, packed.data_ptr(), word.data_ptr() if word is not None else 0, tail, N, K,
+                             (1 if transposed else 0) | (2 if block else 0), (Kc + 63) // 64, (R + 63) // 64))
+                entries.append((key, p, packed, word.data_ptr() if word is not None else 0))
+    if not jobs:
+        return 0
+    if _SPLIT_JOB_DTYPE is None:
+        _SPLIT_JOB_DTYPE = np.dtype([("w", "u8"), ("packed", "u8"), ("amax", "u8"), ("tail", "u8"), ("rows", "i4"), ("cols", "i4"), ("kind", "i4"),
+                                     ("first_block", "u4"), ("nbx", "u4"), ("reserved", "u4")])     # VitSplitJob
+    host = np.zeros(len(jobs), dtype=_SPLIT_JOB_DTYPE)
+    first = 0
+    for i, (w, pk, am, tl, N, K, kind, nbx, nby) in enumerate(jobs):
+        host[i] = (w, pk, am, tl, N, K, kind, first, nbx, 0)
+        first += nbx * nby
+    table = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).to(dev)
+    _check(load().vit_split_weights_many(table.data_ptr(), len(jobs), first, _stream(dev)), "vit_split_weights_many")
+    for key, p, packed, word in entries:
+        hit = _SPLIT_CACHE[key]
+        _SPLIT_CACHE[key] = (hit[0], p._version, p.data_ptr(), packed)
+    # the plan is reusable only if it covers every image of every weight handed in (else the first steps, while the cache fills, would pin a partial one)
+    _SPLIT_PLAN[pkey] = {"params": list(params), "entries": entries, "table": table, "njobs": len(jobs), "blocks": first}
+    CALLS["split_many_images"] += len(jobs)
+    return len(jobs)
+
+
 def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
     multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
@@ -740,7 +834,7 @@ CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_mer
          # library / framework routes taken ON DEVICE TENSORS (layers the hand-written kernels do not cover): the end-to-end tests assert that every one of them stays at zero
          "library_conv_fwd": 0, "library_conv_bwd": 0, "framework_upsample": 0, "framework_dropout": 0, "framework_linear": 0,
          "input_merger_library": 0,
-         "amax_pass": 0, "amax_published": 0}     # f16x3: activation |max| words from a vit_amax pass / from the producing kernel's epilogue     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
+         "amax_pass": 0, "amax_published": 0, "split_many_images": 0, "split_plan_reused": 0}     # f16x3: activation |max| words from a vit_amax pass / from the producing kernel's epilogue     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
 LIBRARY_ROUTES = ("library_conv_fwd", "library_conv_bwd", "framework_upsample", "framework_dropout", "layernorm_framework")
 
 
@@ -1124,6 +1218,7 @@ def gaussian_adapter_hip(pts0, ptsr, par0, parr, app, sh_mask, exponent: float, 
 def invalidate_split_cache() -> None:
     _SPLIT_CACHE.clear()
     _WEIGHT_AMAX.clear()
+    _SPLIT_PLAN.clear()
 
 
 # (N, K) -> ring configuration of vit_linear_x6r_fwd for launches of M >= 4096 rows, per arithmetic mode (cfg 3: 256 x 256 tiles, one

@@ -1066,3 +1066,53 @@ def test_halo_convolution_at_the_largest_head_shapes_is_linear_and_mode_consiste
         torch.cuda.empty_cache()
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
     vit_ops._x6()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "bf16x3"])
+def test_batched_weight_resplit_equals_the_single_weight_images(mode, monkeypatch):
+    """vit_ops.refresh_split_cache / vit_split_weights_many (one launch for every cached image of every updated weight, what TrainStep calls
+    after the optimizer step) writes the bytes the single-weight calls write: forward and transposed, MFMA-order and block layout, ragged
+    row counts, in every arithmetic mode; the cache entries carry the new version afterwards and untouched weights are left alone."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    vit_ops._x6()
+    g = torch.Generator(DEV).manual_seed(7)
+    shapes = [(3072, 1024), (200, 72), (64, 136), (768, 768), (1000, 64)]
+    ws = [torch.nn.Parameter(torch.randn(n, k, device=DEV, generator=g) * (0.02 + 0.3 * i)) for i, (n, k) in enumerate(shapes)]
+    images = lambda w: [vit_ops.split_weight(w, False), vit_ops.split_weight(w, True), vit_ops.split_weight_block(w, False), vit_ops.split_weight_block(w, True)]
+    try:
+        first = [images(w) for w in ws]                              # populate the cache
+        ptrs = [[t.data_ptr() for t in im] for im in first]
+        with torch.no_grad():
+            for i, w in enumerate(ws[:-1]):                          # an "optimizer step" on all but the last weight
+                w.mul_(1.0 + 0.01 * (i + 1)).add_(0.001)
+        if mode == "f16x3":
+            for w in ws[:-1]:
+                vit_ops._weight_amax_word(w, w.detach())             # (AdamWHIP publishes these from its own kernel)
+        before = vit_ops.CALLS["split_many_images"]
+        n = vit_ops.refresh_split_cache(ws)
+        assert n == 4 * (len(ws) - 1) and vit_ops.CALLS["split_many_images"] - before == n
+        assert vit_ops.refresh_split_cache(ws) == 0                  # everything is current now
+        torch.cuda.synchronize()
+        for w, (N, K), pp in zip(ws, shapes, ptrs):
+            got = images(w)                                          # cache hits: no launch, the refreshed buffers
+            assert [t.data_ptr() for t in got] == pp
+            ref = images(torch.nn.Parameter(w.detach().clone()))     # the single-weight kernels on the same values
+            for li, (a, b) in enumerate(zip(got, ref)):
+                transposed, block = li & 1, li >= 2
+                R, Kc = (K, N) if transposed else (N, K)
+                Rp = (R + 63) // 64 * 64 if block else R
+                body = Rp * Kc * 6
+                pa, pb = a[:body].view(-1, 16), b[:body].view(-1, 16)
+                if block:                                            # [row block][k group][piece][64 rows][16 B]
+                    pa, pb = pa.view(-1, 3, 64, 16), pb.view(-1, 3, 64, 16)
+                else:                                                # [row][k group][piece][16 B]
+                    pa, pb = pa.view(-1, 3, 16), pb.view(-1, 3, 16)
+                pieces = 2 if mode == "f16x3" else 3                 # (f16x3 never writes or reads the third slot)
+                assert torch.equal(pa[:, :pieces], pb[:, :pieces]), (mode, (N, K), li)
+                if mode == "f16x3":                                  # the |max| line the readers take their inverse scale from
+                    ta, tb = a[body:body + 8192].view(torch.int32)[::32], b[body:body + 8192].view(torch.int32)[::32]
+                    assert torch.equal(ta, tb), (mode, (N, K), li, "tail")
+    finally:
+        vit_ops.LINEAR_MODE = "bf16x6"
+        vit_ops._x6()
