@@ -533,8 +533,10 @@ def _publish(t: Tensor, word: Tensor) -> None:
         h = _PUBLISHED.get(key)
         if h is not None and h[0] is ref:
             del _PUBLISHED[key]
-    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
-    _PUBLISHED[key] = (weakref.ref(t, drop), t._version, word, torch._C._cuda_getCurrentRawStream(idx))
+    stream = 0
+    if t.is_cuda:
+        stream = torch._C._cuda_getCurrentRawStream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    _PUBLISHED[key] = (weakref.ref(t, drop), t._version, word, stream)
 
 
 PUBLISH_AMAX = os.environ.get("VIT_PUBLISH_AMAX", "1") == "1"      # A/B switch: 0 = every f16x3 operand scale comes from its own vit_amax pass
@@ -549,9 +551,10 @@ def _known_amax(t: Tensor) -> Optional[Tensor]:
     src = hit[0]()
     if src is None or src.data_ptr() != t.data_ptr() or src._version != hit[1] or t._version != hit[1]:
         return None
-    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
-    if hit[3] != torch._C._cuda_getCurrentRawStream(idx) and not torch.cuda.is_current_stream_capturing():
-        hit[2].record_stream(torch.cuda.current_stream(t.device))     # word of another stream's arena read here: the allocator must know
+    if t.is_cuda:
+        idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        if hit[3] != torch._C._cuda_getCurrentRawStream(idx) and not torch.cuda.is_current_stream_capturing():
+            hit[2].record_stream(torch.cuda.current_stream(t.device))     # word of another stream's arena read here: the allocator must know
     return hit[2]
 
 
