@@ -64,6 +64,50 @@ def test_e2e_fixture_is_usable(tag):
     assert float(G["tf32noise:means"]) > 50 * float(G["fp32noise:means"])
 
 
+def _flip_prone(gs, ids, cams, H, W, delta=1e-3):
+    """{Gaussian index: which of the rasterizer's per-Gaussian DISCONTINUITIES it sits on}: its integer radius / tile rectangle (upstream
+    getRect) or the clamp-at-zero of an SH colour channel (whose gradient is switched off while clamped) changes in some view when its mean /
+    covariance / SH coefficients move by `delta` relative -- ten times the 1e-4 the encoder's Gaussians are held to.  Oracle preprocess
+    (float64) on perturbed copies; an empty string = on no discontinuity."""
+    from oracle.gsr_oracle import Oracle
+    from styl3r_amd.decoder import prepare_views
+    orc = Oracle("f64")
+    c = {k: t.detach().cpu() for k, t in cams.items()}
+    V = c["extrinsics"].shape[1]
+    views = prepare_views(c["extrinsics"][0], c["intrinsics"][0], c["near"][0], c["far"][0], torch.zeros(V, 3), True).numpy().astype(np.float64)
+    n_sh = gs.harmonics.shape[-1]
+    deg = int(round(n_sh ** 0.5)) - 1
+    out = {}
+    for gi in ids:
+        mean = gs.means[0, gi].detach().cpu().numpy().astype(np.float64)
+        cov = gs.covariances[0, gi].detach().cpu().numpy().astype(np.float64)
+        sh = gs.harmonics[0, gi].detach().cpu().numpy().astype(np.float64).T          # (n, 3)
+        cov6 = np.array([cov[0, 0], cov[0, 1], cov[0, 2], cov[1, 1], cov[1, 2], cov[2, 2]])
+        ms, cs, hs = [mean], [cov6], [sh]
+        for ax in range(3):
+            for sgn in (-1.0, 1.0):
+                d = np.zeros(3); d[ax] = sgn * delta * max(np.abs(mean).max(), 1e-6)
+                ms.append(mean + d); cs.append(cov6); hs.append(sh)
+        for sgn in (-1.0, 1.0):
+            ms.append(mean); cs.append(cov6 * (1.0 + sgn * delta)); hs.append(sh)
+        for ch in range(3):                                                            # the colour's DC term: rgb = C0 sh0 + ... + 0.5, clamped at 0
+            for sgn in (-1.0, 1.0):
+                h = sh.copy(); h[0, ch] += sgn * delta * max(np.abs(sh).max(), 1.0)
+                ms.append(mean); cs.append(cov6); hs.append(h)
+        ms, cs, hs = np.stack(ms), np.stack(cs), np.stack(hs)
+        what = set()
+        for v in range(V):
+            row = views[v]; sc = row[56]
+            st, _ = orc.forward(ms * sc, cs * sc * sc, np.full(len(ms), 0.5), shs=hs, H=H, W=W, tanfovx=row[51], tanfovy=row[52], bg=(0, 0, 0),
+                                view=row[0:16], proj=row[16:32], proj_raw=row[32:48], campos=row[48:51], sh_degree=deg)
+            if len({(int(r), tuple(int(x) for x in rc)) for r, rc in zip(st.radii, st.rect)}) > 1:
+                what.add("radius/rectangle")
+            if len({tuple(np.asarray(cl).reshape(-1).tolist()) for cl in st.clamped}) > 1:
+                what.add("colour clamp")
+        out[int(gi)] = " + ".join(sorted(what))
+    return out
+
+
 def _rel(a, e, mask=None):
     a = np.asarray(a, np.float64); e = np.asarray(e, np.float64)
     d = np.abs(a - e)
@@ -129,7 +173,7 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
     rep["depth"] = _rel(out.depth.detach().cpu().numpy(), G["depth"], ok[:, :, 0])
     rep["loss"] = abs(float(loss.detach()) - float(G["loss"])) / abs(float(G["loss"]))
     # Per-Gaussian gradients at the 4 096 sampled Gaussians.  Like pixels, single Gaussians sit on discontinuities of the rasterizer -- the integer
-    # radius ceil(3 sqrt(lambda)) and with it the tile rectangle: one more / one fewer 16 x 16 tile of (small-alpha) pixels for THAT Gaussian --
+    # radius ceil(3 sqrt(lambda)) and with it the tile rectangle, and the clamp-at-zero of an SH colour channel (its gradient is off while clamped) --
     # and an fp32 encoder flips one of them in some runs (seen: the same Gaussian, 4.8 % of max |dL/dSH|, in ~1 run of 5, in every arithmetic
     # mode).  The pixel mask cannot express that, so up to 4 of the 4 096 Gaussians (0.1 %) may exceed the bar if they stay below 10 % of the
     # tensor's scale; they are printed, the bar applies to all the others.
@@ -162,9 +206,11 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
             return 2e-4 if k in OUTPUTS else max(1e-4, ntf(k))     # (covariances 0.75e-4 .. 1.05e-4 run to run): printed, bounded at 2e-4
         if k in OUTPUTS:
             return 1e-4
-        # images (colour, depth): 2 x the reference's own fp32 distance (measured 0.6 x); gradients: 4 x (measured 0.3 .. 3.2 over the rounds,
-        # fixtures and modes -- one noise sample per tensor is itself only good to a factor of ~2); r03 used 5 x for everything
-        return max(1e-4, (2.0 if k in ("color", "depth") else 4.0) * n32(k))
+        # images (colour, depth): 2 x the reference's own fp32 distance (measured 0.6 x); gradients: 6 x.  Round 5 ran the c3 cases 22 times
+        # (tools/exp_e2e_flips.sh): the worst gradient ratio seen over all rounds, fixtures and modes is 4.03 x (a LayerNorm weight of the style
+        # encoder, once in 22 runs -- at the 4 x of round 4 that run was red by 0.8 %); one noise sample per tensor is itself only good to a
+        # factor of ~2, so the bar keeps 1.5 x over the worst observation
+        return max(1e-4, (2.0 if k in ("color", "depth") else 6.0) * n32(k))
     lines = [f"  [{tag} {mode}] {k:68s} {val:9.2e}  bar {bar(k):8.1e} ({'1e-4' if bar(k) == 1e-4 else 'yardstick'})"
              f"  ref-fp32 {n32(k):8.1e}  ref-tf32 {ntf(k):8.1e}" for k, val in rep.items() if k != "color_all" and not k.endswith(":worst4")]
     print("\n".join(lines))
@@ -172,9 +218,17 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
           f"pixels compared {ok.mean():.3f}; meets plain 1e-4: {sorted(k for k, val in rep.items() if k != 'color_all' and val <= 1e-4)}")
     bad = {k: (val, bar(k)) for k, val in rep.items() if k != "color_all" and not k.endswith(":worst4") and val > bar(k)}
     assert not bad, f"above the bar (value, bar): {bad}"
+    aside = sorted({gi for k_ in pg for gi, e_ in flipped[k_] if e_ > bar(k_)})
+    if aside:
+        # the Gaussians set aside are IDENTIFIED, not just counted: the oracle's preprocess on the Gaussian the HIP encoder produced,
+        # under perturbations of ten times the encoder's own bar, must change its integer radius / tile rectangle or the clamp state of one of
+        # its colour channels in one of the two views.  (Round 5 finding: the one Gaussian that trips in about half of the runs of the c3
+        # fixture, index 106748, is a COLOUR-CLAMP flip -- its SH gradient is switched off while a channel is clamped at 0 -- not the radius
+        # flip rounds 3 - 4 assumed.)
+        prone = _flip_prone(gs, aside, cams, H, W)
+        print(f"  [{tag} {mode}] Gaussians set aside (index: discontinuity it sits on): {prone}")
+        assert all(prone.values()), ("a Gaussian above the bar sits on NO discontinuity of the rasterizer", prone, {k_: flipped[k_] for k_ in pg})
     for k_ in pg:
-        if rep[k_ + ":worst4"] > bar(k_):
-            print(f"  [{tag} {mode}] {k_}: Gaussians set aside as rectangle / radius flips (index, error): {[f for f in flipped[k_] if f[1] > bar(k_)]}")
         assert rep[k_ + ":worst4"] <= 0.1, (k_, flipped[k_])
     if mode == "bf16x3":
         # the decision rule of VERDICT r02 #2: inside the reference's own TF32 distance on EVERY quantity

@@ -4,7 +4,7 @@
 # table of the C3 train step in both arithmetic modes, the e2e parity tables, every benchmark of DESIGN.md 6 / 8.
 # usage (GPU box, repo root): bash tools/round_record.sh <tag>        -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r04}; O=gpurun_out; mkdir -p $O
+TAG=${1:-r05}; O=gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-infer-leg > $O/${TAG}_bench_torchrun1.json 2> $O/${TAG}_bench_torchrun1.err
