@@ -69,7 +69,7 @@ typedef struct {
 
 /* real-SH constants: bands 0-3 are the published 3DGS tables; band 4 is the
  * build's own extension (standard orthonormal real SH, checked for
- * orthonormality in tests/test_oracle_sh.py). */
+ * orthonormality in tests/test_oracle_gradients.py::test_sh_tables_orthonormal). */
 static const double SH_C0 = 0.28209479177387814;
 static const double SH_C1 = 0.4886025119029199;
 static const double SH_C2[5] = {1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
