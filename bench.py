@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: keep taking views until this much wall time is spent")
     ap.add_argument("--no-infer-leg", action="store_true", help="skip the C2 inference leg")
     ap.add_argument("--no-dropin-leg", action="store_true", help="skip the per-view drop-in leg (the reference's own call pattern)")
+    ap.add_argument("--dp-ab", action="store_true", help="train leg at N > 1: also time the step in the other data-parallel mode (all_reduce <-> rs_ag); automatic at N = 1 under torch.distributed.run")
     ap.add_argument("--no-comm-report", action="store_true", help="train leg: skip the exchange diagnosis / data-parallel mode A/B (runs only with a process group)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the C3 train-step leg (M2)")
     ap.add_argument("--no-stage-legs", action="store_true", help="skip the C4 style-stage and C5 stress train steps")
@@ -550,6 +551,15 @@ def train_leg(args, rank, world, dev, dist):
             run = lambda: step(batch)
             out["comm"] = comm_report(step.reducer, run, sync, steps=max(2, min(4, args.train_steps)))
             modes = {step.dp_mode: {"ms_per_step": out["ms_per_step"], "value": out["value"]}}
+            # the other data-parallel mode as an A/B: automatic in a one-rank group (that path has run on hardware); at N > 1 only with --dp-ab --
+            # "rs_ag" has never run on more than one GPU (gloo world-2 and one-rank RCCL only), and a collective mismatch there would not fail, it
+            # would hang the whole scaling run this line is meant to explain
+            if world > 1 and not getattr(args, "dp_ab", False):
+                out["dp_modes"] = modes
+                out["dp_mode"] = step.dp_mode
+                out["dp_ab_note"] = "rerun with --dp-ab for the all_reduce / rs_ag A/B at N > 1 (opt-in: untested on more than one GPU)"
+                broadcast_module_state(enc, dist, force_collective=forced)       # the no-collective steps of the report let the replicas drift
+                raise StopIteration
             other_dp = "rs_ag" if step.dp_mode == "all_reduce" else "all_reduce"
             step.reducer.close()
             del step
@@ -566,6 +576,8 @@ def train_leg(args, rank, world, dev, dist):
             step.reducer.wait_params()
             out["dp_modes"] = modes
             out["dp_mode"] = [m for m in modes if m != other_dp][0]
+        except StopIteration:
+            pass
         except Exception as e:
             out["comm_error"] = f"{type(e).__name__}: {e}"[:300]
         finally:
