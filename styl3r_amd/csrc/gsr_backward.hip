@@ -84,7 +84,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     const int max_last = (int)mx;
-    const int slot = reduce10_slot(lane);
+    // DEPTH: ten sums, reduce10; depth-free: the nine live sums go through wave_reduce9 (GR_DEPTH's column of grad_rec keeps its zero)
+#ifdef GSR_K6_R10
+    constexpr bool NINE = false;
+#else
+    constexpr bool NINE = !DEPTH;
+#endif
+    int slot;                                   // the grad_rec column this lane publishes, -1: none
+    if (NINE) { const int i9 = reduce9_slot(lane); slot = i9 < 0 ? -1 : (i9 < 3 ? i9 : i9 + 1); }      // v = s[0..2], s[4..9]
+    else slot = reduce10_slot(lane);
 
     // entries [0, max_last) of the sorted list, in batches from the back; slot l of a batch = entry hi-1-l.  Each lane
     // gathers one entry's record and parks it in LDS at the start of the batch (stage_entry): holding the NEXT batch in 12
@@ -111,21 +119,29 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             if (quad == 0) continue;   // footprint misses the tile: nothing to evaluate, nothing to reduce
             const float kop = -0.5f * b.y;
             float s[10];
-            s[GR_DEPTH] = 0.f;
-            bool any = false;
+            // "Defined" here by an empty asm: on the paths the compiler cannot rule out (an accumulating quadrant without an assigning one)
+            // the sums would otherwise be the PREVIOUS entry's, i.e. live across the reduction -- ten v_mov copies in front of its swaps
+#pragma unroll
+            for (int i = 0; i < 10; ++i) asm volatile("" : "=v"(s[i]));
+            if (!DEPTH && !NINE) s[GR_DEPTH] = 0.f;
+            unsigned long long anym = 0ull;   // lanes that composited this entry, over its quadrants (a scalar OR of the compare masks: no VALU)
             // one evaluation of quadrant k.  FIRST (the first quadrant of this entry, wave-uniform) ASSIGNS the ten partial
             // sums, later ones accumulate: no per-entry zeroing of ten registers (a tenth of the kernel's VALU slots when
             // 1.4 quadrants are evaluated per entry)
-            auto eval = [&](auto first_tag, const int k) {
-                constexpr bool FIRST = decltype(first_tag)::value;
+            auto eval = [&](const bool FIRST, const int k) {      // FIRST: wave-uniform
                 // Straight-line, predicated by `valid`: an invalid (pixel, splat) pair runs with alpha = G = 0, which
                 // leaves T and S unchanged (w = 0) and contributes exactly 0 to every sum.
                 const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float Graw = __expf(fminf(power, 0.f));
+                // (no clamp of `power`: where it is positive the splat is invalid whatever G is -- +inf, or NaN * 0 behind it, never reaches a sum:
+                //  alpha and Gv are selected to 0 by `valid`, and v_min_f32 returns the number of (0.99, NaN))
+                const float Graw = footprint_exp(power);
                 const float araw = fminf(0.99f, b.y * Graw);
-                const bool valid = (entry < last[k]) && (power <= 0.f) && (araw >= (1.f / 255.f));
-                any |= valid;
+                const bool c1 = entry < last[k], c2 = power <= 0.f, c3 = araw >= (1.f / 255.f);
+                const bool valid = c1 && c2 && c3;
+                // (the ballot of the AND is a v_cndmask + v_cmp round trip through a register; the AND of the compares' own masks is scalar.
+                //  Measured and dropped: a chain of VALU selects instead of the scalar AND in front of the two selects, 0.887 vs 0.871 ms)
+                anym |= __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2) & __builtin_amdgcn_ballot_w64(c3);
                 const float alpha = valid ? araw : 0.f;
                 const float Gv = valid ? Graw : 0.f;
                 const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp) for both 1/(1-alpha) uses
@@ -156,15 +172,23 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(quad & (1u << k))) continue;  // scalar branches: the only control flow of the evaluation
-                if ((quad & ((1u << k) - 1u)) == 0u) eval(std::true_type{}, k);
-                else eval(std::false_type{}, k);
+                eval((quad & ((1u << k) - 1u)) == 0u, k);
             }
-            if (__ballot(any) == 0ull) continue;  // wave-uniform
+            if (anym == 0ull) continue;  // wave-uniform
             float tot[3];
-            wave_reduce10(s, tot);
-            if (slot >= 0) {
-                const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
-                if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
+            if (NINE) {
+                const float v9[9] = {s[0], s[1], s[2], s[4], s[5], s[6], s[7], s[8], s[9]};
+                wave_reduce9(v9, tot);
+                if (slot >= 0) {
+                    const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
+                    if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
+                }
+            } else {
+                wave_reduce10(s, tot);
+                if (slot >= 0) {
+                    const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
+                    if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
+                }
             }
         }
     }
@@ -328,8 +352,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd_rows(GsrDims d, const GsrV
                         const float4 *rr = reinterpret_cast<const float4 *>(recs + id);
                         const float4 q0 = rr[0], q1 = rr[1], q2 = rr[2];
                         float4 *dst = s_rec + (cbase + fill + rank) * 3;
-                        dst[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
-                        dst[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+                        dst[0] = make_float4(q0.x, q0.y, q1.x * CONIC_PRESCALE, q1.y * CONIC_PRESCALE);      // as stage_entry_bwd
+                        dst[1] = make_float4(q1.z * CONIC_PRESCALE, q1.w, q0.z, __uint_as_float(id));
                         dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float((uint32_t)p));
                         s_bits[fill + rank] = row_bits<W>(fm);
                     }
@@ -367,7 +391,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd_rows(GsrDims d, const GsrV
         const float4 c = s_rec[slot * 3 + 2];                // r, g, b, list position
         const float dx = a.x - fpx, dy = a.y - fpy;
         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float Graw = __expf(fminf(power, 0.f));
+        const float Graw = footprint_exp(fminf(power, 0.f));
         const float araw = fminf(0.99f, b.y * Graw);
         const bool valid = (item >= 0) && (__float_as_uint(c.w) < last) && (power <= 0.f) && (araw >= (1.f / 255.f));
         const float alpha = valid ? araw : 0.f;

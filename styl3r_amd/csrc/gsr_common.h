@@ -287,6 +287,17 @@ __device__ inline uint32_t quadrant_mask(const float4 q0, const float4 q1, uint3
     return quad;
 }
 
+// The composite kernels evaluate G = exp(power) as ONE v_exp_f32 (= 2^x): the conic is multiplied by log2(e) once per staged entry, so that
+// `power` comes out in base-2 units.  Both kernels stage through the functions below and evaluate the same expression, so the forward's and
+// the backward's alpha agree bit for bit (the backward re-derives which pixels a splat was composited into from it).
+// -DGSR_EXP_E: the round-2..4 form, exp(power) = v_mul(log2 e) + v_exp_f32 on the unscaled conic (A/B).
+#ifdef GSR_EXP_E
+#define CONIC_PRESCALE 1.0f
+__device__ inline float footprint_exp(float power) { return __expf(power); }
+#else
+#define CONIC_PRESCALE 1.4426950408889634f
+__device__ inline float footprint_exp(float power) { return __builtin_amdgcn_exp2f(power); }
+#endif
 // One list entry of a composite batch: gather the splat record of Gaussian `id` (three dwordx4 loads) and park it as a
 // QueueRec in the three float4 LDS slots at `dst`.  The forward also marks the quadrants of the tile at (ox, oy) the
 // footprint can touch and leaves that mask in `quad_out` (one byte per list entry); the backward reads it back instead of
@@ -296,8 +307,8 @@ __device__ inline uint32_t stage_entry_fwd(const SplatRec *__restrict__ recs, ui
     const float4 *r = reinterpret_cast<const float4 *>(recs + id);
     const float4 q0 = r[0], q1 = r[1], q2 = r[2];
     const uint32_t quad = quadrant_mask(q0, q1, __float_as_uint(q2.w), ox, oy);
-    dst[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
-    dst[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+    dst[0] = make_float4(q0.x, q0.y, q1.x * CONIC_PRESCALE, q1.y * CONIC_PRESCALE);
+    dst[1] = make_float4(q1.z * CONIC_PRESCALE, q1.w, q0.z, __uint_as_float(id));
     dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
     return quad;
 }
@@ -305,8 +316,8 @@ __device__ inline void stage_entry_bwd(const SplatRec *__restrict__ recs, uint32
 {
     const float4 *r = reinterpret_cast<const float4 *>(recs + id);
     const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-    dst[0] = make_float4(q0.x, q0.y, q1.x, q1.y);
-    dst[1] = make_float4(q1.z, q1.w, q0.z, __uint_as_float(id));
+    dst[0] = make_float4(q0.x, q0.y, q1.x * CONIC_PRESCALE, q1.y * CONIC_PRESCALE);
+    dst[1] = make_float4(q1.z * CONIC_PRESCALE, q1.w, q0.z, __uint_as_float(id));
     dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
 }
 
@@ -398,21 +409,38 @@ __device__ inline float row_allsum(float v)
     v += dpp_mov<0x128, 0xf, 0xf, true>(v);  // row_ror:8
     return v;
 }
+// (round 5: the swaps are compiler builtins, not inline asm, so that the compiler schedules them and their wait states itself)
+__device__ inline float swapsum32(float x, float y)     // lanes < 32: sum of x's two halves, lanes >= 32: of y's
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float swapsum16(float x, float y)     // rows 0, 2: x's row pairs (0,1), (2,3); rows 1, 3: y's
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ inline void wave_reduce10(const float *a, float *out)
 {
-    // level 1: five v_permlane32_swap back to back (independent registers: one pair of wait states covers all five)
-    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], x4 = a[4], y0 = a[5], y1 = a[6], y2 = a[7], y3 = a[8], y4 = a[9];
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
-                 "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4));
-    float b0 = x0 + y0, b1 = x1 + y1, b2 = x2 + y2, b3 = x3 + y3, b4 = x4 + y4;   // lanes<32: a_i, lanes>=32: a_{i+5}
+    // level 1: halves.  b_i: lanes < 32 hold a_i, lanes >= 32 hold a_{i+5}
+    const float b0 = swapsum32(a[0], a[5]), b1 = swapsum32(a[1], a[6]), b2 = swapsum32(a[2], a[7]), b3 = swapsum32(a[3], a[8]),
+                b4 = swapsum32(a[4], a[9]);
     // level 2: rows.  (b0,b1) -> a0 a1 a5 a6 ; (b2,b3) -> a2 a3 a7 a8 ; (b4,0) -> a4 - a9 -
-    float z = 0.f;
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5"
-                 : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(z));
-    out[0] = row_allsum(b0 + b1); out[1] = row_allsum(b2 + b3); out[2] = row_allsum(b4 + z);
+    out[0] = row_allsum(swapsum16(b0, b1)); out[1] = row_allsum(swapsum16(b2, b3)); out[2] = row_allsum(swapsum16(b4, 0.f));
+}
+// Nine values (the depth-free instantiation of the composite backward): eight go through the two swap levels (rows of out[0]: v0 v1 v4 v5,
+// of out[1]: v2 v3 v6 v7; every lane of a row holds the row's total), the ninth is summed on its own with DPP adds (total in lane 63):
+// 6 swaps + 6 adds + 14 DPP adds against 8 + 8 + 12 and two zero registers for ten values.
+__device__ inline void wave_reduce9(const float *v, float *out)
+{
+    const float b0 = swapsum32(v[0], v[4]), b1 = swapsum32(v[1], v[5]), b2 = swapsum32(v[2], v[6]), b3 = swapsum32(v[3], v[7]);
+    out[0] = row_allsum(swapsum16(b0, b1)); out[1] = row_allsum(swapsum16(b2, b3));
+    // the ninth: row totals, then the two cross-row steps as FUSED DPP adds (rows outside row_mask keep their value; written through
+    // update_dpp(0, ...) + add the compiler spends a zero register, a v_mov_dpp and an add on each)
+    float t = row_allsum(v[8]);
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t));
+    out[2] = t;      // lane 63: the wave total
 }
 // which of the ten values a lane publishes after wave_reduce10: lanes 16r+s, s<3 -> value index, else -1
 __device__ inline int reduce10_slot(int lane)
@@ -422,6 +450,14 @@ __device__ inline int reduce10_slot(int lane)
     if (s == 1) return (r < 2) ? r + 2 : r + 5;    // 2,3,7,8
     if (s == 2) return (r == 0) ? 4 : (r == 2 ? 9 : -1);
     return -1;
+}
+// ... after wave_reduce9 (index into ITS nine inputs): lanes 16r -> out[0] (v0 v1 v4 v5), 16r+1 -> out[1] (v2 v3 v6 v7), lane 63 -> out[2] (v8)
+__device__ inline int reduce9_slot(int lane)
+{
+    const int r = lane >> 4, s = lane & 15;
+    if (s == 0) return (r < 2) ? r : r + 2;        // 0,1,4,5
+    if (s == 1) return (r < 2) ? r + 2 : r + 4;    // 2,3,6,7
+    return lane == 63 ? 8 : -1;
 }
 
 }  // namespace gsr

@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (power > 0.f) continue;
-                const float alpha = fminf(0.99f, b.y * __expf(power));
+                const float alpha = fminf(0.99f, b.y * footprint_exp(power));
                 if (alpha < (1.f / 255.f)) continue;
                 const float test_T = Tr[k] * (1.f - alpha);
                 if (test_T < 0.0001f) { done[k] = true; continue; }
