@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     // deepest contributor of the tile: nothing behind it received any light
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    const int max_last = (int)mx;
+    const int max_last = __builtin_amdgcn_readfirstlane((int)mx);   // wave-uniform (all-lanes maximum): batch / entry counters and the loop controls stay scalar
     // DEPTH: ten sums, reduce10; depth-free: the nine live sums go through wave_reduce9 (GR_DEPTH's column of grad_rec keeps its zero)
 #ifdef GSR_K6_R10
     constexpr bool NINE = false;
@@ -103,20 +103,24 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         // (single-wave workgroup: its LDS instructions execute in order, so a compiler barrier orders the staging stores against the
         //  previous batch's reads -- a __syncthreads would also wait, s_waitcnt vmcnt(0), for every gradient atomic still in flight)
         asm volatile("" ::: "memory");
+        uint32_t bm = 0;
         if (lane < cnt) {
-            const uint32_t bm = ws.block_mask[start + hi - 1 - lane];   // exact block masks of the forward, 8 bits per quadrant
+            bm = ws.block_mask[start + hi - 1 - lane];   // exact block masks of the forward, 8 bits per quadrant
             const uint32_t quad = ((bm & 0xffu) ? 1u : 0u) | ((bm & 0xff00u) ? 2u : 0u) | ((bm & 0xff0000u) ? 4u : 0u) | ((bm >> 24) ? 8u : 0u);
             stage_entry_bwd(recs, plist[hi - 1 - lane], quad, s_q + lane * 3);
         }
+        // the slots whose footprint touches the tile at all, as a scalar bit mask: the entry loop visits only those (no per-entry LDS read
+        // + readfirstlane + branch just to find out that there is nothing to evaluate, and the entry's record is read in one go)
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(bm != 0u);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // (reading entry j + 1 ahead of time was measured: +12 VGPRs drop the kernel from 5 to 4 waves per SIMD, -6 %)
-        for (int j = 0; j < cnt; ++j) {
+        for (; todo; todo &= todo - 1ull) {
+            const int j = __builtin_ctzll(todo);
             const uint32_t entry = (uint32_t)(hi - 1 - j);  // 0-based position in the list
             const float4 a = s_q[j * 3 + 0];                // x, y, A, B
             const float4 b = s_q[j * 3 + 1];                // C, opacity, depth, id
             const float4 c = s_q[j * 3 + 2];                // r, g, b, quad
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            if (quad == 0) continue;   // footprint misses the tile: nothing to evaluate, nothing to reduce
             const float kop = -0.5f * b.y;
             float s[10];
             // "Defined" here by an empty asm: on the paths the compiler cannot rule out (an accumulating quadrant without an assigning one)
@@ -179,16 +183,20 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             if (NINE) {
                 const float v9[9] = {s[0], s[1], s[2], s[4], s[5], s[6], s[7], s[8], s[9]};
                 wave_reduce9(v9, tot);
-                if (slot >= 0) {
-                    const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
-                    if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
-                }
             } else {
                 wave_reduce10(s, tot);
-                if (slot >= 0) {
-                    const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
-                    if (val != 0.f) atomicAdd(grad + (size_t)__float_as_uint(b.w) * GR_STRIDE + slot, val);
-                }
+            }
+            // (opaque to the compiler here: it would otherwise sink the last DPP step of each row sum into the publishing lanes' branch as
+            //  v_mov_dpp + v_add instead of one fused v_add_dpp)
+            asm volatile("" : "+v"(tot[0]), "+v"(tot[1]), "+v"(tot[2]));
+            if (slot >= 0) {
+                const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
+                // uniform base + 32-bit byte offset (the saddr form of the atomic instead of a 64-bit multiply-add per lane)
+                static_assert(GR_STRIDE * 4 == 48, "48-byte gradient records: id * 48 = (id << 5) + (id << 4)");
+                uint32_t id16 = __float_as_uint(b.w) << 4;
+                asm("" : "+v"(id16));          // (keeps the two v_lshl_add_u32: recombined to id * 48 it becomes a quarter-rate v_mad_u64_u32)
+                const uint32_t off = (id16 << 1) + ((uint32_t)slot * 4u + id16);
+                if (val != 0.f) atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(grad) + off), val);
             }
         }
     }

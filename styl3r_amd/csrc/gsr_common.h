@@ -321,6 +321,27 @@ __device__ inline void stage_entry_bwd(const SplatRec *__restrict__ recs, uint32
     dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(quad));
 }
 
+// Select by a SCALAR lane mask (one bit per lane, e.g. the AND of several compares' ballots): v_cndmask_b32 reads the mask straight from its SGPR
+// pair.  In C++ the same select needs a per-lane bool, i.e. the mask expanded to a register and compared again.
+__device__ inline float sel_f(unsigned long long m, float t, float f)
+{
+    float r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+__device__ inline float sel0_f(unsigned long long m, float t)         // m ? t : 0
+{
+    float r;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(t), "s"(m));
+    return r;
+}
+__device__ inline uint32_t sel_u(unsigned long long m, uint32_t t, uint32_t f)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+
 // ---- wave64 helpers ------------------------------------------------------
 // Sum over the 64 lanes with DPP row operations (no LDS traffic); the total
 // lands in lane 63.  gfx9-family DPP: quad_perm, row_ror, row_bcast15/31.

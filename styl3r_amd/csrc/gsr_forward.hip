@@ -613,37 +613,88 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
 
     // (pixel coordinates from the lane's base + a per-quadrant constant, as in the backward, were measured here: the two extra
     //  subtractions per evaluation cost 4 % and the 2 registers they free do not reach the next occupancy step)
-    const float fx0 = (float)ox, fy0 = (float)oy;   // pixel = lane base + the quadrant's constant offset (round 5: the six registers this frees
+    float fx0 = (float)ox, fy0 = (float)oy;   // pixel = lane base + the quadrant's constant offset (round 5: the six registers this frees
                                                      // are the sixth wave per SIMD now that the block flags took two)
+    asm volatile("" : "+v"(fx0), "+v"(fy0));     // (kept in registers: the compiler re-converted ox per list entry)
     float Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
     uint32_t last[4];
-    bool done[4], inside[4];
+    bool inside[4];
+    // finished pixels (outside the image, or T fell below 1e-4) as SCALAR lane masks, one per quadrant: the evaluation below is straight-line
+    // code whose selects read scalar masks (round 5; the round-1..4 form nested four exec-mask branches per evaluation -- done, power > 0,
+    // alpha < 1/255, T < 1e-4 -- and kept `done` as a register that every evaluation tested with two VALU instructions; -DGSR_K5_BRANCHY)
+    unsigned long long dmask[4];
+#ifdef GSR_K5_BRANCHY
+    bool done[4];
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
         inside[k] = px < d.W && py < d.H;
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = O[k] = 0.f;
-        last[k] = 0; done[k] = !inside[k];
+        last[k] = 0;
+        dmask[k] = __builtin_amdgcn_ballot_w64(!inside[k]);
+#ifdef GSR_K5_BRANCHY
+        done[k] = !inside[k];
+#endif
     }
 
     for (int base = 0; base < n; base += 64) {
-        const int cnt = min(64, n - base);
+        const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - base));     // (scalar loop control)
         __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
+        uint32_t qm = 0;
         if (lane < cnt) {  // one list entry per lane; the geometric quadrant mask steers this kernel's own scalar skips
-            const uint32_t qm = stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
+            qm = stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
             if (!BLOCKS) ws.block_mask[start + base + lane] = ((qm & 1u) ? 0xffu : 0u) | ((qm & 2u) ? 0xff00u : 0u) |
                                                               ((qm & 4u) ? 0xff0000u : 0u) | ((qm & 8u) ? 0xff000000u : 0u);
         }
         __syncthreads();
 
+        // the entry loop visits only the slots whose footprint can touch the tile (a scalar bit mask of the batch)
         // (reading entry j + 1 ahead of entry j's evaluation was measured: +7 VGPRs, 8 -> 7 waves per SIMD, -6 %)
+#ifndef GSR_K5_BRANCHY
+        for (unsigned long long todo = __builtin_amdgcn_ballot_w64(qm != 0u); todo; todo &= todo - 1ull) {
+            const int j = __builtin_ctzll(todo);
+#else
         for (int j = 0; j < cnt; ++j) {
+#endif
             const float4 a = s_q[j * 3 + 0];
             const float4 b = s_q[j * 3 + 1];
             const float4 c = s_q[j * 3 + 2];
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            uint32_t touched = 0;
             uint8_t *hit_j = hit_lane + j * 32;   // this entry's 32 block flags, at the lane's block of each quadrant
+#ifndef GSR_K5_BRANCHY
+            uint32_t touched_tot = 0;             // scalar: pixels of this tile whose T stays above 1/2 behind the splat
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!(quad & (1u << k))) continue;        // scalar branches: the only control flow of the evaluation
+                if (dmask[k] == ~0ull) continue;
+                const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                // (evaluated for every lane: a positive power gives G > 1 or +inf, alpha = 0.99 after the clamp -- v_min_f32 returns the number of
+                //  (0.99, NaN) -- and the lane is masked out by `live`)
+                const float alpha = fminf(0.99f, b.y * footprint_exp(power));
+                const float test_T = Tr[k] * (1.f - alpha);
+                const unsigned long long live = __builtin_amdgcn_ballot_w64(!(power > 0.f)) & __builtin_amdgcn_ballot_w64(!(alpha < (1.f / 255.f))) & ~dmask[k];
+                const unsigned long long keep = __builtin_amdgcn_ballot_w64(!(test_T < 0.0001f));
+                dmask[k] |= live & ~keep;                  // T would fall below 1e-4: the pixel is finished, this splat is not composited
+                const unsigned long long comp = live & keep;
+                const float w = sel0_f(comp, alpha * Tr[k]);
+                C0[k] += c.x * w; C1[k] += c.y * w; C2[k] += c.z * w;
+                D[k] += b.z * w;
+                O[k] += w;
+                if (NTOUCH) touched_tot += (uint32_t)__popcll(comp & __builtin_amdgcn_ballot_w64(test_T > 0.5f));
+                Tr[k] = sel_f(comp, test_T, Tr[k]);
+                last[k] = sel_u(comp, (uint32_t)(base + j + 1), last[k]);
+                // the backward's rows walk exactly the (entry, pixel block) items that composited something: one LDS byte store
+                // under the exec mask of the lanes that did (same value from every lane of a block: stores to one address
+                // merge; an LDS atomic OR of 64 lanes on one word serialises -- measured: this kernel 0.50 -> 1.90 ms)
+                if (BLOCKS) { if (sel_u(comp, 1u, 0u)) hit_j[8 * k] = 1; }
+            }
+            if (NTOUCH) {   // one atomic per (tile, splat)
+                if (touched_tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)touched_tot);
+            }
+#else
+            uint32_t touched = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!(quad & (1u << k))) continue;  // scalar branch
@@ -662,9 +713,6 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 if (NTOUCH) touched += (test_T > 0.5f) ? 1u : 0u;
                 Tr[k] = test_T;
                 last[k] = (uint32_t)(base + j + 1);
-                // the backward's rows walk exactly the (entry, pixel block) items that composited something: one LDS byte store
-                // under the exec mask of the lanes that did (same value from every lane of a block: stores to one address
-                // merge; an LDS atomic OR of 64 lanes on one word serialises -- measured: this kernel 0.50 -> 1.90 ms)
                 if (BLOCKS) hit_j[8 * k] = 1;
             }
             if (NTOUCH) {
@@ -673,6 +721,7 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                                      4u * (uint32_t)__popcll(__ballot(touched & 4u));
                 if (tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)tot);
             }
+#endif
         }
         if (BLOCKS) {   // lane j: entry base + j's 32 flags -> 32-bit mask (bit 8 q + 2 by + BX), flags re-armed for the next batch
             __syncthreads();
@@ -683,7 +732,11 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 ws.block_mask[start + base + lane] = nib(f0.x) | (nib(f0.y) << 4) | (nib(f0.z) << 8) | (nib(f0.w) << 12) |
                                                       (nib(f1.x) << 16) | (nib(f1.y) << 20) | (nib(f1.z) << 24) | (nib(f1.w) << 28);
         }
+#ifndef GSR_K5_BRANCHY
+        if ((dmask[0] & dmask[1] & dmask[2] & dmask[3]) == ~0ull) break;
+#else
         if (__all(done[0] && done[1] && done[2] && done[3])) break;
+#endif
     }
 
     const size_t P = (size_t)d.H * d.W;
