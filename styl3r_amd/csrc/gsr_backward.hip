@@ -179,18 +179,14 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 eval((quad & ((1u << k) - 1u)) == 0u, k);
             }
             if (anym == 0ull) continue;  // wave-uniform
-            float tot[3];
+            float val;             // the packed register of the reduction: every publishing lane finds its total in its own lane
             if (NINE) {
                 const float v9[9] = {s[0], s[1], s[2], s[4], s[5], s[6], s[7], s[8], s[9]};
-                wave_reduce9(v9, tot);
+                val = wave_reduce9(v9);
             } else {
-                wave_reduce10(s, tot);
+                val = wave_reduce10(s);
             }
-            // (opaque to the compiler here: it would otherwise sink the last DPP step of each row sum into the publishing lanes' branch as
-            //  v_mov_dpp + v_add instead of one fused v_add_dpp)
-            asm volatile("" : "+v"(tot[0]), "+v"(tot[1]), "+v"(tot[2]));
             if (slot >= 0) {
-                const float val = (lane & 15) == 0 ? tot[0] : ((lane & 15) == 1 ? tot[1] : tot[2]);
                 // uniform base + 32-bit byte offset (the saddr form of the atomic instead of a 64-bit multiply-add per lane)
                 static_assert(GR_STRIDE * 4 == 48, "48-byte gradient records: id * 48 = (id << 5) + (id << 4)");
                 uint32_t id16 = __float_as_uint(b.w) << 4;

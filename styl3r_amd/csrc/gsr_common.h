@@ -441,43 +441,67 @@ __device__ inline float swapsum16(float x, float y)     // rows 0, 2: x's row pa
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ inline void wave_reduce10(const float *a, float *out)
+// ---- the last level: several row-level registers summed into ONE packed register -------------------------------------------------------
+// After the two swap levels a register holds four values, one per 16-lane row, and each still has to be summed over its row.  One at a time
+// that is four DPP adds per register (quad_perm x 2, row_ror:4, row_ror:8).  DPP instructions write only the banks (4-lane groups of a row)
+// named in bank_mask, so the halving steps can PACK instead: after the row_ror:8 step a value needs 8 lanes (two registers share one), after the
+// rotate-by-4 step 4 lanes (a third moves into a free bank), and the two quad_perm steps then serve every bank at once.
+//   X -> bank 0, Y -> bank 2, U -> bank 3 (lanes 12..15: lane 15 feeds row_bcast, which is how the depth-free kernel's ninth value, ONE value
+//   over all 64 lanes, gets its cross-row sum).  Rotation: row_ror:12 (lane i reads lane i - 12 = i + 4 of its row).
+// Wait states: a DPP read of a register written by the previous VALU instruction needs two (s_nop 1); inline asm is not scheduled.
+__device__ inline float rows_packed_sum(float x, float y, float u, const bool u_whole_wave)
+{
+    float z, u8;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x8\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(z), "=&v"(u8) : "v"(x), "v"(y), "v"(u));
+    if (u_whole_wave)     // lanes 12..15 of every row hold u's row total: rows 1, 3 += row 0, 2 ; rows 2, 3 += row 1 -> lane 63: the wave total
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0x8\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0x8" : "+v"(z));
+    return z;
+}
+// Ten values -> one register: lanes 16r (+0..3) hold a0 a1 a5 a6 (r = 0..3), lanes 16r + 8 a2 a3 a7 a8, lanes 16r + 12 a4 - a9 -.
+// 8 swaps + 8 adds + 7 DPP adds (round 2-4: 8 + 8 + 12, and two selects to pick among three registers).
+__device__ inline float wave_reduce10(const float *a)
 {
     // level 1: halves.  b_i: lanes < 32 hold a_i, lanes >= 32 hold a_{i+5}
     const float b0 = swapsum32(a[0], a[5]), b1 = swapsum32(a[1], a[6]), b2 = swapsum32(a[2], a[7]), b3 = swapsum32(a[3], a[8]),
                 b4 = swapsum32(a[4], a[9]);
     // level 2: rows.  (b0,b1) -> a0 a1 a5 a6 ; (b2,b3) -> a2 a3 a7 a8 ; (b4,0) -> a4 - a9 -
-    out[0] = row_allsum(swapsum16(b0, b1)); out[1] = row_allsum(swapsum16(b2, b3)); out[2] = row_allsum(swapsum16(b4, 0.f));
+    return rows_packed_sum(swapsum16(b0, b1), swapsum16(b2, b3), swapsum16(b4, 0.f), false);
 }
-// Nine values (the depth-free instantiation of the composite backward): eight go through the two swap levels (rows of out[0]: v0 v1 v4 v5,
-// of out[1]: v2 v3 v6 v7; every lane of a row holds the row's total), the ninth is summed on its own with DPP adds (total in lane 63):
-// 6 swaps + 6 adds + 14 DPP adds against 8 + 8 + 12 and two zero registers for ten values.
-__device__ inline void wave_reduce9(const float *v, float *out)
-{
-    const float b0 = swapsum32(v[0], v[4]), b1 = swapsum32(v[1], v[5]), b2 = swapsum32(v[2], v[6]), b3 = swapsum32(v[3], v[7]);
-    out[0] = row_allsum(swapsum16(b0, b1)); out[1] = row_allsum(swapsum16(b2, b3));
-    // the ninth: row totals, then the two cross-row steps as FUSED DPP adds (rows outside row_mask keep their value; written through
-    // update_dpp(0, ...) + add the compiler spends a zero register, a v_mov_dpp and an add on each)
-    float t = row_allsum(v[8]);
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(t));
-    out[2] = t;      // lane 63: the wave total
-}
-// which of the ten values a lane publishes after wave_reduce10: lanes 16r+s, s<3 -> value index, else -1
-__device__ inline int reduce10_slot(int lane)
+__device__ inline int reduce10_slot(int lane)      // which of the ten values a lane publishes, else -1
 {
     const int r = lane >> 4, s = lane & 15;
     if (s == 0) return (r < 2) ? r : r + 3;        // 0,1,5,6
-    if (s == 1) return (r < 2) ? r + 2 : r + 5;    // 2,3,7,8
-    if (s == 2) return (r == 0) ? 4 : (r == 2 ? 9 : -1);
+    if (s == 8) return (r < 2) ? r + 2 : r + 5;    // 2,3,7,8
+    if (s == 12) return (r == 0) ? 4 : (r == 2 ? 9 : -1);
     return -1;
 }
-// ... after wave_reduce9 (index into ITS nine inputs): lanes 16r -> out[0] (v0 v1 v4 v5), 16r+1 -> out[1] (v2 v3 v6 v7), lane 63 -> out[2] (v8)
-__device__ inline int reduce9_slot(int lane)
+// Nine values (the depth-free instantiation of the composite backward): eight go through the two swap levels, the ninth through DPP steps only
+// (it rides in bank 3 of the packed register and is summed across the rows by the two row_bcast steps): lanes 16r hold v0 v1 v4 v5,
+// lanes 16r + 8 v2 v3 v6 v7, lane 63 v8.  6 swaps + 6 adds + 9 DPP adds.
+__device__ inline float wave_reduce9(const float *v)
+{
+    const float b0 = swapsum32(v[0], v[4]), b1 = swapsum32(v[1], v[5]), b2 = swapsum32(v[2], v[6]), b3 = swapsum32(v[3], v[7]);
+    return rows_packed_sum(swapsum16(b0, b1), swapsum16(b2, b3), v[8], true);
+}
+__device__ inline int reduce9_slot(int lane)       // index into wave_reduce9's nine inputs, else -1
 {
     const int r = lane >> 4, s = lane & 15;
     if (s == 0) return (r < 2) ? r : r + 2;        // 0,1,4,5
-    if (s == 1) return (r < 2) ? r + 2 : r + 4;    // 2,3,6,7
+    if (s == 8) return (r < 2) ? r + 2 : r + 4;    // 2,3,6,7
     return lane == 63 ? 8 : -1;
 }
 
