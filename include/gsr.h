@@ -115,7 +115,8 @@ typedef struct GsrLayout {
     size_t total;        /* total bytes */
 } GsrLayout;
 
-/* Size/offsets of the workspace for (dims, pair_capacity).  Returns GSR_OK or GSR_EINVAL. */
+/* Size/offsets of the workspace for (dims, pair_capacity).  Returns GSR_OK or GSR_EINVAL.
+ * Limits: pair_capacity < 2^32; G * 48 bytes < 2^32 (the composite kernels address one view's records with 32-bit byte offsets). */
 int gsr_workspace_layout(const GsrDims *dims, int64_t pair_capacity, GsrLayout *out);
 
 /*
