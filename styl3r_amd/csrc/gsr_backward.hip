@@ -121,7 +121,6 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             const float4 b = s_q[j * 3 + 1];                // C, opacity, depth, id
             const float4 c = s_q[j * 3 + 2];                // r, g, b, quad
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            const float kop = -0.5f * b.y;
             float s[10];
             // "Defined" here by an empty asm: on the paths the compiler cannot rule out (an accumulating quadrant without an assigning one)
             // the sums would otherwise be the PREVIOUS entry's, i.e. live across the reduction -- ten v_mov copies in front of its swaps
@@ -141,13 +140,14 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 //  alpha and Gv are selected to 0 by `valid`, and v_min_f32 returns the number of (0.99, NaN))
                 const float Graw = footprint_exp(power);
                 const float araw = fminf(0.99f, b.y * Graw);
-                const bool c1 = entry < last[k], c2 = power <= 0.f, c3 = araw >= (1.f / 255.f);
-                const bool valid = c1 && c2 && c3;
-                // (the ballot of the AND is a v_cndmask + v_cmp round trip through a register; the AND of the compares' own masks is scalar.
-                //  Measured and dropped: a chain of VALU selects instead of the scalar AND in front of the two selects, 0.887 vs 0.871 ms)
-                anym |= __builtin_amdgcn_ballot_w64(c1) & __builtin_amdgcn_ballot_w64(c2) & __builtin_amdgcn_ballot_w64(c3);
-                const float alpha = valid ? araw : 0.f;
-                const float Gv = valid ? Graw : 0.f;
+                // validity as a SCALAR lane mask: the AND of the compares' own ballots (the ballot of a per-lane AND is a v_cndmask + v_cmp round trip
+                // through a register), the two selects read it from its SGPR pair.
+                // (Measured and dropped: a chain of VALU selects instead of the scalar AND in front of the two selects, 0.887 vs 0.871 ms)
+                const unsigned long long vm = __builtin_amdgcn_ballot_w64(entry < last[k]) & __builtin_amdgcn_ballot_w64(power <= 0.f) &
+                                              __builtin_amdgcn_ballot_w64(araw >= (1.f / 255.f));
+                anym |= vm;
+                const float alpha = sel0_f(vm, araw);
+                const float Gv = sel0_f(vm, Graw);
                 const float inv = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp) for both 1/(1-alpha) uses
                 Tr[k] *= inv;
                 const float w = alpha * Tr[k];
@@ -159,8 +159,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
                 // hx = sum(-dL_dG/2 * G dx), hy = sum(-dL_dG/2 * G dy), which the conic gradients need anyway: accumulate
                 // those (two adds per evaluation instead of six multiply-adds) and apply A, B, C once per Gaussian in K7
                 const float t = Gv * dL_dalpha;            // dL/dopacity term; dL_dG * G = opacity * t
-                const float hgG = kop * t;                  // -1/2 dL_dG G, kop = -opacity / 2 (per entry)
-                const float hx = hgG * dx, hy = hgG * dy;
+                // (the factor -opacity / 2 of dL_dG G = opacity t is per Gaussian and view: K7 applies it to the five summed moments)
+                const float hx = t * dx, hy = t * dy;
                 if (FIRST) {
                     s[GR_RGB + 0] = w * g0[k]; s[GR_RGB + 1] = w * g1[k]; s[GR_RGB + 2] = w * g2[k];
                     if (DEPTH) s[GR_DEPTH] = w * gd[k];
@@ -408,8 +408,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd_rows(GsrDims d, const GsrV
         const float dL_dalpha = Tr * u - S * inv;
         S += w * u;
         const float tt = Gv * dL_dalpha;
-        const float hgG = (-0.5f * b.y) * tt;
-        const float hx = hgG * dx, hy = hgG * dy;
+        const float hx = tt * dx, hy = tt * dy;      // (x -opacity / 2 in K7)
         // the sums travel with the item: shifted in from the left neighbour (0 into the row's first lane), plus this pixel's share
         const float first = (W == 16 || s != 0) ? 1.f : 0.f;     // rows narrower than a DPP row: their lane 0 must not inherit
         auto carry = [&](float vprev, float add) { return W == 16 ? dpp_prev_f<W>(vprev) + add : dpp_prev_f<W>(vprev) * first + add; };
@@ -545,7 +544,11 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
             const float a = ge.a, bb = ge.b, c = ge.c;
             const float denom = a * c - bb * bb;
             const float k2 = 1.0f / (denom * denom + 0.0000001f);
-            const float gA = gr[GR_CA], gB = gr[GR_CB], gC = gr[GR_CC];
+            // K6 leaves the moments of t = dL/dalpha G over the splat's pixels: sum t dx, sum t dy, sum t dx^2, sum t dx dy, sum t dy^2;
+            // dL_dG G = opacity t, and the conic / mean terms carry -1/2 of it: one factor per (view, Gaussian), applied here
+            const float4 q1 = reinterpret_cast<const float4 *>(ws.records + vg)[1];      // A, B, C, opacity
+            const float kop = -0.5f * q1.w;
+            const float gA = kop * gr[GR_CA], gB = kop * gr[GR_CB], gC = kop * gr[GR_CC];
             const float ga = k2 * (-c * c * gA + 2.0f * bb * c * gB + (denom - a * c) * gC);
             const float gc = k2 * (-a * a * gC + 2.0f * a * bb * gB + (denom - a * c) * gA);
             const float gb = k2 * 2.0f * (bb * c * gA - (denom + 2.0f * bb * bb) * gB + a * bb * gC);
@@ -599,8 +602,7 @@ __global__ void __launch_bounds__(256) k_preprocess_bwd(GsrDims d, const GsrView
             const float mw = 1.0f / (hw + 0.0000001f);
             const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
             {   // K6 accumulated hx = sum(-dL_dG/2 G dx), hy likewise: mean2D gradient = (A hx + B hy) W, (C hy + B hx) H
-                const float4 q1 = reinterpret_cast<const float4 *>(ws.records + vg)[1];
-                const float sx = gr[GR_MX], sy = gr[GR_MY];
+                const float sx = kop * gr[GR_MX], sy = kop * gr[GR_MY];
                 g2x = (q1.x * sx + q1.y * sy) * (float)d.W;
                 g2y = (q1.z * sy + q1.y * sx) * (float)d.H;
             }
