@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 composite-kernel clean-up A/B (GPU box): rasterizer parity tests on the product library, then the raster-only bench line with every
-# prebuilt variant (GSR_LIB_NAME builds made in the build container: head = the previous commit, r10 = ten-value reduction, expe = exp() on the
-# unscaled conic, maskv = VALU select chain).  usage: bash tools/exp_k6r5.sh <tag> [lib names ...] -> gpurun_out/<tag>_*
+# prebuilt variant library named on the command line (GSR_LIB_NAME / GSR_HIPCC_EXTRA builds made in the build container, e.g. an older commit's
+# sources, -DGSR_K6_R10 = ten-value reduction, -DGSR_EXP_E = exp() on the unscaled conic, -DGSR_K5_BRANCHY = the exec-mask-branch forward).  usage: bash tools/exp_k6r5.sh <tag> [lib names ...] -> gpurun_out/<tag>_*
 set -u
 TAG=${1:-k6r5}; shift; O=gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
