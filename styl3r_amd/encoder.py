@@ -169,16 +169,28 @@ class CrocoTrunk(nn.Module):
 
 
 class AsymmetricCroCoMulti(CrocoTrunk):
+    supports_decoder_embedding = False
+
     def __init__(self, cfg: BackboneCrocoCfg, d_in: int = 3, params: Optional[dict] = None):
         super().__init__(**(params or CROCO_PARAMS[cfg.model]))
-        # intrinsics embedding (backbone_croco_multiview.py:59-78,129-135,199-206): 'token' (every documented run; the style encoders
-        # require it) and 'linear' (the embedding added to every patch token), or none at all.  'pixelwise' (ray-direction / real-SH
-        # channels concatenated to the image, a 3 + d channel patch embed) and the decoder-side location are not built: they need the
-        # reference's generated SH tables (src/misc/sht.py) and no shipped config selects them.
-        if cfg.intrinsics_embed_type == "pixelwise" and cfg.intrinsics_embed_loc != "none" or cfg.intrinsics_embed_loc == "decoder":
-            raise NotImplementedError("intrinsics_embed_type='pixelwise' / intrinsics_embed_loc='decoder' are not built "
-                                      "(config/model/encoder/backbone/croco.yaml uses loc='encoder', type='token'; 'linear' and loc='none' are available)")
-        self.intrinsics_embed_type = cfg.intrinsics_embed_type if cfg.intrinsics_embed_loc == "encoder" else "none"
+        # intrinsics embedding (backbone_croco_multiview.py:59-78,129-135,199-206; backbone_croco.py:69-101,236-263): 'token' (every documented
+        # run; the style encoders require it), 'linear' (the embedding added to every patch token), 'pixelwise' (camera-frame ray directions,
+        # or their real-SH expansion, as extra IMAGE channels in front of a 3 + d channel patch embed -- loc 'encoder' -- or as extra FEATURE
+        # channels in front of decoder_embed -- loc 'decoder', pairwise backbone only), or none at all.
+        pr = params or CROCO_PARAMS[cfg.model]
+        pix = (cfg.intrinsics_embed_degree + 1) ** 2 if cfg.intrinsics_embed_degree > 0 else 3
+        self.intrinsics_embed_degree = cfg.intrinsics_embed_degree
+        self.pix_enc_dim = pix if (cfg.intrinsics_embed_loc == "encoder" and cfg.intrinsics_embed_type == "pixelwise") else 0
+        self.pix_dec_dim = pix if (cfg.intrinsics_embed_loc == "decoder" and cfg.intrinsics_embed_type == "pixelwise") else 0
+        if cfg.intrinsics_embed_loc == "decoder" and not (self.pix_dec_dim and self.supports_decoder_embedding):
+            # (the reference builds these modules, but its forward cannot run them: the multi-view trunk never hands the embedding to its
+            #  decoder, backbone_croco_multiview.py:217, and a non-pixelwise decoder-side embedding does not fit decoder_embed, backbone_croco.py:99-101)
+            raise NotImplementedError("intrinsics_embed_loc='decoder' exists for the pairwise `croco` backbone with intrinsics_embed_type='pixelwise' only")
+        if self.pix_enc_dim:
+            self.patch_embed = PatchEmbedDust3R(pr["img_size"], 16, 3 + self.pix_enc_dim, pr["enc_embed_dim"])
+        if self.pix_dec_dim:
+            self.decoder_embed = nn.Linear(pr["enc_embed_dim"] + self.pix_dec_dim, pr["dec_embed_dim"], bias=True)
+        self.intrinsics_embed_type = cfg.intrinsics_embed_type if (cfg.intrinsics_embed_loc == "encoder" and cfg.intrinsics_embed_type != "pixelwise") else "none"
         if cfg.asymmetry_decoder:
             self.dec_blocks2 = copy.deepcopy(self.dec_blocks)
         if cfg.intrinsics_embed_type in ("linear", "token"):          # (the reference creates it whatever the location, :77-78)
@@ -216,7 +228,7 @@ class AsymmetricCroCoMulti(CrocoTrunk):
 
     branch_streams = False   # inference option (set by the encoder's `head_streams`): decoder 2 on its own HIP stream
 
-    def _decoder_split(self, feat: Tensor, pos: Tensor):
+    def _decoder_split(self, feat: Tensor, pos: Tensor, extra: Optional[Tensor] = None):
         """The dual decoders (:147-188) with view 0 and views 1.. kept as SEPARATE tensors from start to end:
         returns a list of 13 pairs (first (b,l,c), rest (b*(v-1),l,c)).  The reference -- and round 1 of this build --
         re-assembles a (b,v,l,c) tensor after every block and re-slices it for the next one (the "ctx concat" copies
@@ -224,7 +236,7 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         view 0's cross-attention, "all other views in view order", IS the rest tensor viewed as (b, (v-1) l, c); at v = 2
         the memory of the other decoder is the first tensor itself, so the C2 / C3 path copies nothing at all.  For
         v > 2 the memory of view i >= 1 (view 0 followed by the other rest views) is gathered once per layer."""
-        st = self._decoder_begin(feat, pos)
+        st = self._decoder_begin(feat, pos, extra)
         # Serving (`branch_streams`, no-grad, device tensors): within a layer the two decoders only read each other's PREVIOUS outputs, and
         # at batch 1 neither fills the chip -- decoder 2 runs on its own stream, forked and joined once per layer (the critical path of a
         # C2 forward drops from 24 encoder + 24 decoder block-times to 24 + 12).
@@ -247,10 +259,19 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         return self._decoder_end(st)
 
     # The pieces of `_decoder_split`, also driven one by one by graphs.StreamGraphedEncoder (one hipGraph per piece and stream)
-    def _decoder_begin(self, feat: Tensor, pos: Tensor):
+    def _decoder_begin(self, feat: Tensor, pos: Tensor, extra: Optional[Tensor] = None):
         from types import SimpleNamespace
         b, v, l, c = feat.shape
-        cur = _linear(self.decoder_embed, feat)
+        # (`extra`: the decoder-side pixelwise embedding (b, v, l, d), concatenated in front of decoder_embed only: output 0 stays the bare features)
+        if extra is None:
+            cur = _linear(self.decoder_embed, feat)
+        else:
+            x = torch.cat((feat, extra.to(feat.dtype)), dim=-1)
+            if x.is_cuda and x.dtype == torch.float32:      # 1024 + d columns: the contraction is zero-padded to a multiple of 16 (as _intrinsics_token)
+                pad = (0, (-x.shape[-1]) % 16)
+                cur = fused_linear(torch.nn.functional.pad(x, pad), torch.nn.functional.pad(self.decoder_embed.weight, pad), self.decoder_embed.bias)
+            else:
+                cur = self.decoder_embed(x)
         st = SimpleNamespace(b=b, v=v, l=l, f1=cur[:, 0].contiguous(), f2=cur[:, 1:].reshape(b * (v - 1), l, -1),
                              p1=pos[:, 0].contiguous(), p2=pos[:, 1:].reshape(b * (v - 1), l, 2),
                              pm1=pos[:, 1:].reshape(b, (v - 1) * l, 2),                    # memory positions of view 0
@@ -288,10 +309,17 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         b, v, l, _ = feat.shape
         return [torch.cat((a.unsqueeze(1), r.view(b, v - 1, l, -1)), dim=1) for a, r in self._decoder_split(feat, pos)]
 
+    def _input_images(self, context: dict) -> Tensor:
+        """the images the patch embed sees: with the encoder-side pixelwise embedding, 3 + d channels (:199-201)"""
+        if not self.pix_enc_dim:
+            return context["image"]
+        from .camera import intrinsic_embedding
+        return torch.cat((context["image"], intrinsic_embedding(context, self.intrinsics_embed_degree).to(context["image"].dtype)), dim=2)
+
     def encode(self, context: dict):
         """first half of forward(): the 24 encoder blocks over all views -> (feat (b,v,l,c), pos (b,v,l,2))"""
         b, v, _, h, w = context["image"].shape
-        images = context["image"].reshape(b * v, -1, h, w)
+        images = self._input_images(context).reshape(b * v, -1, h, w)
         token = None
         if self.intrinsics_embed_type != "none":
             token = _intrinsics_token(self.intrinsic_encoder, context["intrinsics"]).reshape(b * v, 1, -1)
@@ -303,9 +331,9 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         outs = self._decoder(feat, pos)
         return [t[:, :, :-1] for t in outs] if self.intrinsics_embed_type == "token" else outs
 
-    def decode_split(self, feat: Tensor, pos: Tensor):
+    def decode_split(self, feat: Tensor, pos: Tensor, extra: Optional[Tensor] = None):
         """the same as pairs (view 0 (b,l-1,c), views 1.. (b*(v-1),l-1,c)) -- what the per-view-group heads consume, no re-assembly"""
-        outs = self._decoder_split(feat, pos)
+        outs = self._decoder_split(feat, pos, extra)
         return [(a[:, :-1], r[:, :-1]) for a, r in outs] if self.intrinsics_embed_type == "token" else outs
 
     def forward(self, context: dict):
@@ -313,7 +341,7 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         feat, pos = self.encode(context)
         dec_feat = self.decode(feat, pos)
         shape = torch.tensor([h, w]).repeat(b, v, 1)
-        return feat, pos, dec_feat, shape, context["image"]
+        return feat, pos, dec_feat, shape, self._input_images(context)     # (the reference returns the images WITH the pixelwise channels, :218)
 
 
 class AsymmetricCroCo(AsymmetricCroCoMulti):
@@ -323,15 +351,22 @@ class AsymmetricCroCo(AsymmetricCroCoMulti):
     tensors (b, l, c), the intrinsics token stripped (:259-263).  Pinned by tests/golden/backbone_variants.npz (the reference's
     AsymmetricCroCo.forward on the same weights)."""
 
+    supports_decoder_embedding = True
+
     def forward(self, context: dict, return_views: bool = False):
         b, v, _, h, w = context["image"].shape
         assert v == 2, "the `croco` backbone is the 2-view (pairwise) trunk; `croco_multi` takes any number of views"
         feat, pos = self.encode(context)
-        outs = self.decode_split(feat, pos)
+        extra = None
+        if self.pix_dec_dim:       # one embedding row per token: the ray through the centre of its 16 x 16 patch (:260-263, downsample 16)
+            from .camera import intrinsic_embedding
+            extra = intrinsic_embedding(context, self.intrinsics_embed_degree, downsample=16, merge_hw=True)
+        outs = self.decode_split(feat, pos, extra)
         dec1, dec2 = [a for a, _ in outs], [r for _, r in outs]
         shape = torch.tensor([h, w]).repeat(b, 1)
         if return_views:
-            return dec1, dec2, shape, shape, {"img": context["image"][:, 0]}, {"img": context["image"][:, 1]}
+            img = self._input_images(context)
+            return dec1, dec2, shape, shape, {"img": img[:, 0]}, {"img": img[:, 1]}
         return dec1, dec2, shape, shape
 
 
