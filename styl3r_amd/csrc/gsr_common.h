@@ -22,6 +22,7 @@ struct alignas(16) SplatRec {
     float r, g, b;
     uint32_t ext;           // half extents (pixels, rounded up) of the alpha >= 1/255 footprint: hx | hy << 16
 };
+constexpr int LDS_TILES_MAX = 4096;   // K1 / K3 keep per-tile counters of one view in LDS up to this many tiles (1024 x 1024 pixels); larger images bin with global atomics
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 
 // 48-byte list entry as the composite kernels park it in LDS (three float4 per entry): the splat record re-ordered for
@@ -398,30 +399,15 @@ __device__ inline uint32_t wave_agg_inc(uint32_t *__restrict__ counters, uint32_
     return base + rank;
 }
 
-// ---- ten-value wave reduction for the composite backward ------------------------
-// Sums a[0..9] over the 64 lanes in 8 lane-swaps + 20 adds (a plain per-value DPP
-// reduction costs 60): level 1 pairs (a_i, a_{i+5}) with v_permlane32_swap so each
-// half-wave keeps one value of the pair, level 2 does the same across 16-lane rows with
-// v_permlane16_swap, level 3 finishes inside the rows with DPP.  Afterwards EVERY lane of
-// row r = lane>>4 holds, in out[0..2], the totals of values
-//     out[0]: {0,1,5,6}[r]   out[1]: {2,3,7,8}[r]   out[2]: {4,-,9,-}[r]
-// (inline asm, not __builtin_amdgcn_permlane{32,16}_swap: hipcc 7.2 folds r[0]+r[1] of the builtin's
-// result pair into r[0]+r[0] -- tools/probes/permlane_probe.hip.  `s_nop 1` = the two wait states the gfx950 rule
-// "VALU write -> v_permlane*_swap read" asks for (what hipcc emits in front of the builtin; it pads nothing inside asm).
-// NOT v_nop: one v_nop holds the SIMD's VALU port for ~9.5 ns (~20 cycles) against 0.55 ns for an s_nop state
-// (tools/probes/issue_cost3.hip, profiles/r02_issue_cost.md) -- four of them were a fifth of the composite backward.)
-__device__ inline float swap_add32(float x, float y)
-{
-    // x' = [x.lo, y.lo], y' = [x.hi, y.hi]  ->  x'+y' = [sum of x pair, sum of y pair]
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-__device__ inline float swap_add16(float x, float y)
-{
-    // rows: x' = [x.r0, y.r0, x.r2, y.r2], y' = [x.r1, y.r1, x.r3, y.r3]
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
+// ---- wave reductions of the composite backward -------------------------------------
+// Sums nine / ten per-lane values over the 64 lanes: level 1 pairs values with v_permlane32_swap so that each half-wave keeps one value of
+// the pair, level 2 does the same across the 16-lane rows with v_permlane16_swap, level 3 finishes inside the rows with bank-packed DPP adds
+// (rows_packed_sum).  A plain per-value DPP reduction costs 6 DPP adds per value.
+// The swaps are the compiler builtins (round 5; inline asm before): the compiler places their wait states (s_nop, never v_nop: one v_nop
+// holds the SIMD's VALU port for ~9.5 ns against 0.55 ns for an s_nop state, profiles/r02_issue_cost.md) and, unlike asm operands tied
+// "+v", they do not force copies of the inputs.  Round 2 saw a hipcc build fold the builtin's result pair r[0] + r[1] into r[0] + r[0];
+// tests/test_host_boundary.py::test_swap_reductions_add_both_results checks the generated ISA of THIS build (every swap's two registers
+// feed one v_add_f32), and the gradient parity tests would not survive a wrong sum.
 __device__ inline float row_allsum(float v)
 {
     v += dpp_mov<0xb1, 0xf, 0xf, true>(v);   // quad_perm [1,0,3,2]

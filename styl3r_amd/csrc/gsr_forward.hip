@@ -38,8 +38,9 @@ template <int DEG>   // active SH degree 0..4, -1 = precomputed colours: the SH 
 __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__restrict__ views,
                                                     const float *__restrict__ means, const float *__restrict__ cov6,
                                                     const float *__restrict__ opac, const float *__restrict__ shs,
-                                                    Ptrs ws, int32_t *__restrict__ radii)
+                                                    Ptrs ws, int32_t *__restrict__ radii, int lds_tiles)
 {
+    extern __shared__ uint32_t s_tiles[];      // lds_tiles != 0: this workgroup's per-tile counts of the current view (T words)
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     const bool live = g < d.G;   // no early return: the tile counting below is a wave-level operation
@@ -50,6 +51,10 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
     const float op = opac[sg];
     const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
     constexpr int NC = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+    if (lds_tiles) {
+        for (int t = threadIdx.x; t < T; t += 256) s_tiles[t] = 0u;
+        __syncthreads();
+    }
 
     for (int j = 0; j < d.Vt; ++j) {
         const int v = b * d.Vt + j;
@@ -123,8 +128,22 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
             }
             rec.A = ge.c * det_inv; rec.B = -ge.b * det_inv; rec.C = ge.a * det_inv; rec.opacity = op;
         }
-        // per-tile list lengths: k-th tile of every lane's rect, one aggregated atomic per distinct tile
-        {
+        // per-tile list lengths.  A workgroup's 256 Gaussians are neighbours (pixel-aligned Gaussians of one image row) and fall into a few
+        // dozen tiles of a view: they are counted in an LDS histogram (one ds_add_u32 per lane and covered tile) and only the non-zero bins
+        // go to the global counters (round 5; before: every wavefront grouped its lanes by target tile with ballot loops, ~10 instructions per
+        // distinct tile and covered-tile index, and issued one global atomic per group -- still the path for images of more than
+        // LDS_TILES_MAX tiles)
+        if (lds_tiles) {
+            const int rw = maxx - minx, area = ok ? rw * (maxy - miny) : 0;
+            for (int k = 0; k < area; ++k) atomicAdd(&s_tiles[(miny + k / rw) * gx + minx + k % rw], 1u);
+            __syncthreads();
+            uint32_t *cnt = ws.tile_count + (size_t)v * T;
+            for (int t = threadIdx.x; t < T; t += 256) {
+                const uint32_t c = s_tiles[t];
+                if (c) { atomicAdd(cnt + t, c); s_tiles[t] = 0u; }
+            }
+            __syncthreads();
+        } else {
             const int rw = maxx - minx, area = ok ? rw * (maxy - miny) : 0;
             int amax = area;
 #pragma unroll
@@ -308,6 +327,41 @@ __global__ void __launch_bounds__(256) k_scatter(GsrDims d, Ptrs ws)
     }
 }
 #pragma clang fp contract(fast)
+
+// K3 with the slots handed out from LDS (images of up to LDS_TILES_MAX tiles): count the workgroup's pairs per tile in LDS, reserve ONE range per
+// non-empty (workgroup, tile) in the global cursor, then every pair takes base + a returning LDS add.  ~2.5 x fewer global atomics than one per
+// (wavefront, distinct tile), and no ballot loops.  The order of a tile's pairs before the sort is arbitrary either way.
+__global__ void __launch_bounds__(256) k_scatter_lds(GsrDims d, Ptrs ws)
+{
+    if (ws.status[GSR_ST_OVERFLOW]) return;
+    extern __shared__ uint32_t s_sc[];          // [T] counts, later running offsets ; [T] bases
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = blockIdx.y;
+    const bool live = g < d.G;
+    const size_t vg = (size_t)v * d.G + (live ? g : 0);
+    const float4 q0 = reinterpret_cast<const float4 *>(ws.records + vg)[0];
+    const int rad = live ? (int)(__float_as_uint(q0.w) & 0xffffffu) : 0;
+    const int gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
+    uint32_t *s_cnt = s_sc, *s_base = s_sc + T;
+    for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0u;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (rad > 0) tile_rect(q0.x, q0.y, rad, gx, gy, minx, miny, maxx, maxy);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(q0.z) << 32) | (unsigned)g;
+    const size_t tb = (size_t)v * T;
+    const int rw = maxx - minx, area = rw * (maxy - miny);
+    __syncthreads();
+    for (int k = 0; k < area; ++k) atomicAdd(&s_cnt[(miny + k / rw) * gx + minx + k % rw], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const uint32_t c = s_cnt[t];
+        if (c) { s_base[t] = ws.tile_offset[tb + t] + atomicAdd(ws.tile_cursor + tb + t, c); s_cnt[t] = 0u; }
+    }
+    __syncthreads();
+    for (int k = 0; k < area; ++k) {
+        const int tl = (miny + k / rw) * gx + minx + k % rw;
+        ws.pairs[s_base[tl] + atomicAdd(&s_cnt[tl], 1u)] = key;
+    }
+}
 
 // ------------------------------------------------------------------ K4
 // Normalised bitonic network (every compare-exchange is ascending, so entries at or
@@ -830,13 +884,16 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     if (bin && render) return GSR_EINVAL;
     StageTimer tm(d.profile, true, stream, render);
     const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
+    // K1 / K3 bin through LDS histograms when a view's tiles fit (GSR_BIN=ballot: the wave-aggregated global atomics of rounds 1 - 4, the A/B)
+    const char *bin_env = getenv("GSR_BIN");
+    const int lds_tiles = (T <= LDS_TILES_MAX && !(bin_env && !strcmp(bin_env, "ballot"))) ? T : 0;
     if (render) goto render_phase;   // K1-K2 of this workspace were enqueued by the PHASE_BIN call
 
     if (!hip_ok(hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream))) return GSR_ELAUNCH;
     if (ntouch && !hip_ok(hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream))) return GSR_ELAUNCH;
 
     tm.begin(GSR_STAGE_PREPROCESS);
-#define GSR_LAUNCH_K1(DEG) hipLaunchKernelGGL(k_preprocess<DEG>, gG, dim3(256), 0, stream, d, views, means, cov6, opac, shs, ws, radii)
+#define GSR_LAUNCH_K1(DEG) hipLaunchKernelGGL(k_preprocess<DEG>, gG, dim3(256), lds_tiles * 4, stream, d, views, means, cov6, opac, shs, ws, radii, lds_tiles)
     switch (d.M > 0 ? d.sh_degree : -1) {
         case -1: GSR_LAUNCH_K1(-1); break;
         case 0: GSR_LAUNCH_K1(0); break;
@@ -852,7 +909,8 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     if (bin) return launch_status();  // status is final here: the host can size / retry before the heavy stages
 render_phase:
     tm.begin(GSR_STAGE_SCATTER);
-    hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
+    if (lds_tiles) hipLaunchKernelGGL(k_scatter_lds, gV, dim3(256), lds_tiles * 8, stream, d, ws);
+    else hipLaunchKernelGGL(k_scatter, gV, dim3(256), 0, stream, d, ws);
     tm.end(GSR_STAGE_SCATTER); tm.begin(GSR_STAGE_SORT);
     {
         // LDS budget of the per-tile sort: 1024 / 2048 / 4096 keys (8 / 16 / 32 KiB).  The host passes the longest list it

@@ -548,3 +548,33 @@ def test_prezeroed_gradient_accumulators_equal_the_memset_path_and_survive_a_sec
     for x, y, z, name in zip(a, a2, b, ("means", "cov", "sh", "opac")):
         assert_close_rel(x.cpu().numpy(), z.cpu().numpy(), 2e-5, f"prezero vs memset d{name}")
         assert_close_rel(y.cpu().numpy(), z.cpu().numpy(), 2e-5, f"second backward d{name}")
+
+
+def test_lds_histogram_binning_equals_the_wave_aggregated_one(monkeypatch):
+    """K1 / K3 bin through LDS histograms when a view has at most LDS_TILES_MAX tiles (round 5); GSR_BIN=ballot selects the wave-aggregated
+    global atomics of rounds 1 - 4, which larger images still take.  Both must leave the same sorted lists: images, radii, depth, n_contrib and
+    gradients are compared bit for bit (the composite kernels are deterministic given the lists; the backward's atomics are summed in
+    tile-schedule order in both runs: 1e-6)."""
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder
+    from styl3r_amd.scenes import make_scene
+    dev = torch.device("cuda:0")
+    scs = [make_scene(n_ctx=1, grid_hw=(96, 96), n_views=3, image_hw=(112, 144), sh_degree=1, seed=500 + i) for i in range(2)]
+    st = lambda n: torch.stack([getattr(s, n) for s in scs]).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.2, 0.1, 0.3], True)).to(dev)
+    w = torch.rand(2, 3, 3, 112, 144, device=dev, generator=torch.Generator(dev).manual_seed(5))
+
+    def run():
+        g = Gaussians(*(st(n).requires_grad_(True) for n in ("means", "covariances", "harmonics", "opacities")))
+        out = dec.forward(g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (112, 144))
+        grads = torch.autograd.grad((out.color * w).sum() + out.depth.sum(), (g.means, g.covariances, g.harmonics, g.opacities))
+        nc = ws_view("n_contrib", np.int32, 2 * 3 * 112 * 144).copy()
+        return out.color.detach().clone(), out.depth.detach().clone(), nc, int(rz.LAST_DEBUG["num_pairs"]), [x.clone() for x in grads]
+
+    monkeypatch.delenv("GSR_BIN", raising=False)
+    a = run()
+    monkeypatch.setenv("GSR_BIN", "ballot")
+    b = run()
+    assert a[3] == b[3] and a[3] > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for x, y, name in zip(a[4], b[4], ("means", "cov", "sh", "opac")):
+        assert_close_rel(x.cpu().numpy(), y.cpu().numpy(), 1e-6, f"lds vs ballot binning d{name}")

@@ -180,3 +180,29 @@ def test_published_maxima_registry_never_outlives_its_tensor():
         assert vit_ops._known_amax(v) is None                                     # the A/B switch
     finally:
         vit_ops.PUBLISH_AMAX = keep
+
+
+def test_swap_reductions_add_both_results(tmp_path):
+    """The composite backward's wave reductions use __builtin_amdgcn_permlane{32,16}_swap; a hipcc build was once seen to fold the builtin's
+    result pair r[0] + r[1] into r[0] + r[0] (gsr_common.h).  This compiles gsr_backward.hip to gfx950 assembly with the product's flags
+    (no GPU needed) and checks that every swap's two registers feed one v_add_f32, and that there are as many swaps as the two tile-kernel
+    instantiations need (ten-value: 5 + 3, nine-value: 4 + 2)."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if Path("/opt/rocm/bin/hipcc").exists() else None)
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    src = Path(_lib.__file__).resolve().parent / "csrc" / "gsr_backward.hip"
+    out = tmp_path / "gsr_backward.s"
+    flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", str(src), "-o", str(out)], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    swaps = 0
+    for i, line in enumerate(lines):
+        m = re.search(r"v_permlane(?:32|16)_swap_b32\S* (v\d+), (v\d+)", line)
+        if not m:
+            continue
+        swaps += 1
+        regs = {m.group(1), m.group(2)}
+        assert any((mm := re.search(r"v_add_f32\S* v\d+, (v\d+), (v\d+)", lines[k])) and {mm.group(1), mm.group(2)} == regs
+                   for k in range(i + 1, min(i + 20, len(lines)))), f"swap at line {i}: no v_add_f32 of both results: {line.strip()}"
+    assert swaps == 14, swaps
