@@ -806,89 +806,38 @@ __global__ void __launch_bounds__(256, 2) k_conv3h_x6(const float *__restrict__ 
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
     // halo row of this lane's pixel in fragment column j: patch row 2 wn + j, patch column `col`  (tap (ky, kx) adds ky * HX + kx)
     const int hp0 = (2 * wn) * HX + col;
-    // fragments of one (tap, slab) tile: A = this wave's 64 weight rows, B = its two patch rows at the tap's offset
-    struct Frag { bf16x8 fa[2][3], fb[2][3]; };
-    auto load_frags = [&](Frag &f, int abuf, int pbuf, int tap) {
+    auto compute = [&](int abuf, int pbuf, int tap) {
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const uint4 *a = sA[abuf] + (wm * 64 + col) * ROWQ;
+        bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) f.fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
+            for (int p = 0; p < 3; ++p) fa[i][p] = __builtin_bit_cast(bf16x8, a[i * 32 * ROWQ + swz(col, half * 3 + p)]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int hp = hp0 + (j + ky) * HX + kx;
             const uint4 *b = sP[pbuf] + hp * ROWQ;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) f.fb[j][p] = __builtin_bit_cast(bf16x8, b[swz(hp, half * 3 + p)]);
+            for (int p = 0; p < 3; ++p) fb[j][p] = __builtin_bit_cast(bf16x8, b[swz(hp, half * 3 + p)]);
         }
-    };
-    auto mma_block = [&](const Frag &f) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x16 cc = acc[i][j];
                 if (NPROD == 6) {
-                    cc = mma<NPROD>(f.fa[i][2], f.fb[j][0], cc);
-                    cc = mma<NPROD>(f.fa[i][1], f.fb[j][1], cc);
-                    cc = mma<NPROD>(f.fa[i][0], f.fb[j][2], cc);
+                    cc = mma<NPROD>(fa[i][2], fb[j][0], cc);
+                    cc = mma<NPROD>(fa[i][1], fb[j][1], cc);
+                    cc = mma<NPROD>(fa[i][0], fb[j][2], cc);
                 }
-                cc = mma<NPROD>(f.fa[i][1], f.fb[j][0], cc);
-                cc = mma<NPROD>(f.fa[i][0], f.fb[j][1], cc);
-                cc = mma<NPROD>(f.fa[i][0], f.fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][1], fb[j][0], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][1], cc);
+                cc = mma<NPROD>(fa[i][0], fb[j][0], cc);
                 acc[i][j] = cc;
             }
     };
-    auto compute = [&](int abuf, int pbuf, int tap) { Frag f; load_frags(f, abuf, pbuf, tap); mma_block(f); };
 
-#ifdef VIT_CONV3H_NOPREFETCH
-    constexpr bool PREFETCH = false;
-#else
-    constexpr bool PREFETCH = NPROD != 6;      // (six products: three fragment pieces per operand, the second register set spills 40 registers)
-#endif
-    if constexpr (PREFETCH) {
-    // Round 5: the fragments of tile it + 1 are read from LDS WHILE the MFMAs of tile it run (two register sets, alternating): a wave no longer
-    // sits between a barrier and its first MFMA waiting for twelve ds_read_b128.  For that the weight images run one step further ahead -- tile
-    // it + 2 is stored (into the image tile it was read from one step earlier) and tile it + 4 fetched while tile it multiplies; the halo patch of
-    // the next slab is in LDS four taps before its first fragment read, as before.  Same MFMAs in the same order: results are bit-identical.
-    if (nit > 0) {
-        halo_gload(0);
-        H6_AGLOAD(0, 0);
-        H6_AGLOAD(1, 1);
-        halo_store(0);
-        H6_ASTORE(0, 0);
-        H6_AGLOAD(0, 2);
-        H6_ASTORE(1, 1);
-        H6_AGLOAD(1, 3);
-        __syncthreads();
-        Frag f0, f1;
-        load_frags(f0, 0, 0, 0);
-        __syncthreads();      // every wave has read tile 0 before anyone stores tile 2 over it
-        int s = 0, tap = 0;
-        // step `it` (weight image / register stage T = it & 1, fragments in F_CUR): prefetch tile it + 1 into F_NXT from image T ^ 1, multiply
-        // F_CUR, store register stage T (tile it + 2) into image T, refill the stage with tile it + 4
-#define H6_PSTEP(T, F_CUR, F_NXT, it_)                                                                                \
-    do {                                                                                                              \
-        if (tap == 0 && s + 1 < ns) halo_gload(s + 1);                                                                \
-        const int tap1_ = tap == 8 ? 0 : tap + 1, s1_ = tap == 8 ? s + 1 : s;                                         \
-        if ((it_) + 1 < nit) load_frags(F_NXT, (T) ^ 1, s1_ & 1, tap1_);                                              \
-        mma_block(F_CUR);                                                                                             \
-        H6_ASTORE(T, T);                                                                                              \
-        H6_AGLOAD(T, (it_) + 4);                                                                                      \
-        if (tap == 4 && s + 1 < ns) halo_store((s + 1) & 1);                                                          \
-        __syncthreads();                                                                                              \
-        tap = tap1_; s = s1_;                                                                                         \
-    } while (0)
-        int it = 0;
-        for (; it + 1 < nit; it += 2) {
-            H6_PSTEP(0, f0, f1, it);
-            H6_PSTEP(1, f1, f0, it + 1);
-        }
-        if (it < nit) mma_block(f0);      // (nit odd: the last tile's fragments sit in set 0)
-#undef H6_PSTEP
-    }
-    } else {
     if (nit > 0) {
         halo_gload(0);
         H6_AGLOAD(0, 0);
@@ -917,7 +866,6 @@ __global__ void __launch_bounds__(256, 2) k_conv3h_x6(const float *__restrict__ 
         }
         if (it < nit) compute(0, s & 1, tap);      // (nit odd: the last tile sits in weight image 0)
 #undef H6_STEP
-    }
     }
 #undef H6_AGLOAD
 #undef H6_ASTORE
