@@ -14,7 +14,11 @@
 
 namespace gsr {
 
-constexpr int MSE_BLOCK = 256, MSE_MAX_GROUPS = 512;
+constexpr int MSE_BLOCK = 256, MSE_MAX_GROUPS = 512, MSE_FWD_GROUPS = 256;
+// Forward: few, fat workgroups.  Every workgroup ends with a device-scope release (__threadfence: an L2 write-back on this multi-die part) and a
+// ticket; measured on the headline image batch (7.9 M floats): 2 048 workgroups 108 us, 512 (one ticket for all) 24.7, 256 19.4, 128 20.4.
+// Tickets: one per cluster of MSE_CLUSTER workgroups, each on its own 128-byte line, and one for the clusters.
+constexpr int MSE_CLUSTER = 32, MSE_TICKET_STRIDE = 32, MSE_MAX_CLUSTERS = MSE_MAX_GROUPS / MSE_CLUSTER;
 
 __device__ inline float block_sum_256(float v, float *sh)
 {
@@ -35,8 +39,7 @@ __global__ void __launch_bounds__(MSE_BLOCK) k_mse_fwd(const float *__restrict__
     const long long n4 = n >> 2;
     const float4 *p4 = reinterpret_cast<const float4 *>(pred), *t4 = reinterpret_cast<const float4 *>(target);
     float acc = 0.f;
-    // few, fat workgroups: the ticket below is one same-address atomic per workgroup and those serialise at the L2
-    // (4096 of them cost 100 us); the loop keeps four 16-byte loads per operand in flight instead
+    // (the loop keeps four 16-byte loads per operand in flight)
     const long long stride = (long long)gridDim.x * MSE_BLOCK;
     long long i = (long long)blockIdx.x * MSE_BLOCK + threadIdx.x;
     for (; i + 3 * stride < n4; i += 4 * stride) {
@@ -59,11 +62,20 @@ __global__ void __launch_bounds__(MSE_BLOCK) k_mse_fwd(const float *__restrict__
         if (i < n) { const float d = pred[i] - target[i]; acc += d * d; }
     }
     const float s = block_sum_256(acc, sh);
-    unsigned *ticket = reinterpret_cast<unsigned *>(scratch + MSE_MAX_GROUPS);
+    unsigned *tickets = reinterpret_cast<unsigned *>(scratch + MSE_MAX_GROUPS);      // [cluster] at stride MSE_TICKET_STRIDE, then the clusters' ticket
     if (threadIdx.x == 0) {
         scratch[blockIdx.x] = s;
         __threadfence();
-        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+        const unsigned cl = blockIdx.x / MSE_CLUSTER, ncl = (gridDim.x + MSE_CLUSTER - 1) / MSE_CLUSTER;
+        const unsigned members = min((unsigned)MSE_CLUSTER, gridDim.x - cl * MSE_CLUSTER);
+        unsigned *t1 = tickets + cl * MSE_TICKET_STRIDE, *t2 = tickets + MSE_MAX_CLUSTERS * MSE_TICKET_STRIDE;
+        unsigned l = 0u;
+        if (atomicAdd(t1, 1u) == members - 1u) {        // last of its cluster: re-arm the cluster's ticket, take the second level
+            *t1 = 0u;
+            __threadfence();
+            if (atomicAdd(t2, 1u) == ncl - 1u) { *t2 = 0u; l = 1u; }
+        }
+        last = l;
     }
     __syncthreads();
     if (!last) return;
@@ -72,7 +84,7 @@ __global__ void __launch_bounds__(MSE_BLOCK) k_mse_fwd(const float *__restrict__
     for (int i = threadIdx.x; i < (int)gridDim.x; i += MSE_BLOCK) t += __builtin_nontemporal_load(scratch + i);
     __syncthreads();                                    // sh reuse
     t = block_sum_256(t, sh);
-    if (threadIdx.x == 0) { out[0] = weight * (t / (float)n); *ticket = 0u; }   // ticket re-armed for the next launch
+    if (threadIdx.x == 0) out[0] = weight * (t / (float)n);      // (the tickets were re-armed by their last arrivers)
 }
 
 __global__ void __launch_bounds__(MSE_BLOCK) k_mse_bwd(const float *__restrict__ pred, const float *__restrict__ target,
@@ -93,13 +105,13 @@ __global__ void __launch_bounds__(MSE_BLOCK) k_mse_bwd(const float *__restrict__
     }
 }
 
-static int mse_groups(long long n) { long long g = (n / 4 + MSE_BLOCK - 1) / MSE_BLOCK; return (int)(g < 1 ? 1 : (g > MSE_MAX_GROUPS ? MSE_MAX_GROUPS : g)); }
+static int mse_groups(long long n, int cap) { long long g = (n / 4 + MSE_BLOCK - 1) / MSE_BLOCK; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 }  // namespace gsr
 
 extern "C" {
 
-__attribute__((visibility("default"))) size_t gsr_mse_scratch_bytes(void) { return (gsr::MSE_MAX_GROUPS + 1) * 4; }
+__attribute__((visibility("default"))) size_t gsr_mse_scratch_bytes(void) { return (gsr::MSE_MAX_GROUPS + (gsr::MSE_MAX_CLUSTERS + 1) * gsr::MSE_TICKET_STRIDE) * 4; }
 
 __attribute__((visibility("default"))) int gsr_mse_forward(const float *pred, const float *target, int64_t n, float weight,
                                                            void *scratch, float *loss, void *stream)
@@ -107,7 +119,7 @@ __attribute__((visibility("default"))) int gsr_mse_forward(const float *pred, co
     if (!pred || !target || !scratch || !loss || n <= 0) return GSR_EINVAL;
     if ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15) return GSR_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gsr::k_mse_fwd, dim3(gsr::mse_groups(n)), dim3(gsr::MSE_BLOCK), 0, static_cast<hipStream_t>(stream), pred,
+    hipLaunchKernelGGL(gsr::k_mse_fwd, dim3(gsr::mse_groups(n, gsr::MSE_FWD_GROUPS)), dim3(gsr::MSE_BLOCK), 0, static_cast<hipStream_t>(stream), pred,
                        target, (long long)n, weight, static_cast<float *>(scratch), loss);
     return gsr::launch_status();
 }
@@ -119,7 +131,7 @@ __attribute__((visibility("default"))) int gsr_mse_backward(const float *pred, c
     if ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad_pred)) & 15)
         return GSR_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gsr::k_mse_bwd, dim3(gsr::mse_groups(n)), dim3(gsr::MSE_BLOCK), 0, static_cast<hipStream_t>(stream), pred,
+    hipLaunchKernelGGL(gsr::k_mse_bwd, dim3(gsr::mse_groups(n, gsr::MSE_MAX_GROUPS)), dim3(gsr::MSE_BLOCK), 0, static_cast<hipStream_t>(stream), pred,
                        target, grad_loss, (long long)n, weight, grad_pred);
     return gsr::launch_status();
 }
