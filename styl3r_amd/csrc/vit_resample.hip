@@ -16,6 +16,32 @@ extern thread_local hipError_t g_last_hip_error;
 // ADD: out = upsample(in) + max(addend, 0) -- the 'gs' head's `feat_up(path_1) + input_merger(imgs)` (dpt_gs_head.py:146-148) with the
 // input merger's ReLU applied while its pre-activation is read, in the same pass that writes the up-sampled map
 template <bool ADD>
+__device__ inline void upsample2x_quad(const float *__restrict__ in, const float *__restrict__ addend, float *__restrict__ out, int64_t pl, int oy,
+                                       int ox4, int H, int W, float rh, float rw)
+{
+    const int OH = 2 * H, OW = 2 * W;
+    const float h1r = rh * (float)oy;
+    const int h1 = (int)h1r, h1p = (h1 < H - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    const float *r0 = in + (pl * H + h1) * W, *r1 = r0 + (int64_t)h1p * W;
+    float4 o;
+    float *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ox = ox4 * 4 + e;
+        const float w1r = rw * (float)ox;
+        const int w1 = (int)w1r, w1p = (w1 < W - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        po[e] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
+    }
+    if (ADD) {
+        const float4 c = *reinterpret_cast<const float4 *>(addend + (pl * OH + oy) * OW + ox4 * 4);
+        o.x += fmaxf(c.x, 0.f); o.y += fmaxf(c.y, 0.f); o.z += fmaxf(c.z, 0.f); o.w += fmaxf(c.w, 0.f);
+    }
+    *reinterpret_cast<float4 *>(out + (pl * OH + oy) * OW + ox4 * 4) = o;
+}
+
+template <bool ADD>
 __global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in, const float *__restrict__ addend, float *__restrict__ out,
                                                     int64_t planes, int H, int W, float rh, float rw)
 {
@@ -24,28 +50,21 @@ __global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int ox4 = (int)(idx % OW4);
         const int64_t t = idx / OW4;
-        const int oy = (int)(t % OH);
-        const int64_t pl = t / OH;
-        const float h1r = rh * (float)oy;
-        const int h1 = (int)h1r, h1p = (h1 < H - 1) ? 1 : 0;
-        const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
-        const float *r0 = in + (pl * H + h1) * W, *r1 = r0 + (int64_t)h1p * W;
-        float4 o;
-        float *po = reinterpret_cast<float *>(&o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ox = ox4 * 4 + e;
-            const float w1r = rw * (float)ox;
-            const int w1 = (int)w1r, w1p = (w1 < W - 1) ? 1 : 0;
-            const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-            po[e] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
-        }
-        if (ADD) {
-            const float4 c = *reinterpret_cast<const float4 *>(addend + (pl * OH + oy) * OW + ox4 * 4);
-            o.x += fmaxf(c.x, 0.f); o.y += fmaxf(c.y, 0.f); o.z += fmaxf(c.z, 0.f); o.w += fmaxf(c.w, 0.f);
-        }
-        *reinterpret_cast<float4 *>(out + (pl * OH + oy) * OW + ox4 * 4) = o;
+        upsample2x_quad<ADD>(in, addend, out, t / OH, (int)(t % OH), ox4, H, W, rh, rw);
     }
+}
+
+// The same for output rows of a power-of-two number of 16-byte groups (every map of the DPT heads) and fewer than 2^31 output rows: a
+// workgroup covers 256 / OW4 whole rows, the (row, group) split is a shift and a mask and the (plane, y) split ONE 32-bit division -- the
+// generic kernel above spends three 64-bit divisions per thread on it, more instructions than the interpolation itself (round 5).
+template <bool ADD>
+__global__ void __launch_bounds__(256) k_upsample2x_p2(const float *__restrict__ in, const float *__restrict__ addend, float *__restrict__ out,
+                                                       uint32_t rows, int H, int W, float rh, float rw, int log2_ow4)
+{
+    const uint32_t row = (blockIdx.x << (8 - log2_ow4)) + (threadIdx.x >> log2_ow4);
+    if (row >= rows) return;
+    const uint32_t OH = 2u * (uint32_t)H, pl = row / OH;
+    upsample2x_quad<ADD>(in, addend, out, (int64_t)pl, (int)(row - pl * OH), (int)(threadIdx.x & ((1u << log2_ow4) - 1u)), H, W, rh, rw);
 }
 
 // 7x7 / stride 1 / padding 3 patches of a 3-channel image as 160 "channels" (147 = 3 x 7 x 7 taps in the weight's (ci, ky, kx)
@@ -82,57 +101,77 @@ __global__ void __launch_bounds__(256) k_im2col7(const float *__restrict__ img, 
 // output rows / columns whose source cell touches it.  With scale (H-1)/(2H-1) < 1/2 those are among the six candidates
 // 2i-2 .. 2i+3; each candidate's cell index is recomputed with the forward's own float arithmetic, so forward and
 // backward agree on every floor() decision.  One pass: dout read once (cached across neighbours), din written once.
+__device__ inline float upsample2x_bwd_pixel(const float *__restrict__ dout, int64_t pl, int iy, int ix, int H, int W, float rh, float rw)
+{
+    const int OH = 2 * H, OW = 2 * W;
+    float wx[6];
+    int ox0 = 2 * ix - 2;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {            // weight of output column ox0 + e on input column ix
+        const int ox = ox0 + e;
+        float wgt = 0.f;
+        if (ox >= 0 && ox < OW) {
+            const float w1r = rw * (float)ox;
+            const int w1 = (int)w1r, w1p = (w1 < W - 1) ? 1 : 0;
+            const float w1l = w1r - (float)w1;
+            if (w1 == ix) wgt += 1.f - w1l;
+            if (w1 + w1p == ix) wgt += w1l;   // (w1p = 0 at the last column: both terms land on it, as in the forward)
+        }
+        wx[e] = wgt;
+    }
+    float acc = 0.f;
+    const int oy0 = 2 * iy - 2;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int oy = oy0 + f;
+        if (oy < 0 || oy >= OH) continue;
+        const float h1r = rh * (float)oy;
+        const int h1 = (int)h1r, h1p = (h1 < H - 1) ? 1 : 0;
+        const float h1l = h1r - (float)h1;
+        float wy = 0.f;
+        if (h1 == iy) wy += 1.f - h1l;
+        if (h1 + h1p == iy) wy += h1l;
+        if (wy == 0.f) continue;
+        const float *row = dout + (pl * OH + oy) * OW;
+        float r = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {    // branch-free: columns outside the row read a clamped address and are SELECTED away
+            const float t = wx[e] * row[min(max(ox0 + e, 0), OW - 1)];   // (v_cndmask, not a multiply by 0: 0 * Inf of an overflowed border gradient would be NaN)
+            r += wx[e] != 0.f ? t : 0.f;
+        }
+        acc += wy * r;
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) k_upsample2x_bwd(const float *__restrict__ dout, float *__restrict__ din, int64_t planes,
                                                         int H, int W, float rh, float rw)
 {
-    const int OH = 2 * H, OW = 2 * W;
     const int64_t total = planes * H * W;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int ix = (int)(idx % W);
         const int64_t t = idx / W;
-        const int iy = (int)(t % H);
-        const int64_t pl = t / H;
-        float wx[6];
-        int ox0 = 2 * ix - 2;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) {            // weight of output column ox0 + e on input column ix
-            const int ox = ox0 + e;
-            float wgt = 0.f;
-            if (ox >= 0 && ox < OW) {
-                const float w1r = rw * (float)ox;
-                const int w1 = (int)w1r, w1p = (w1 < W - 1) ? 1 : 0;
-                const float w1l = w1r - (float)w1;
-                if (w1 == ix) wgt += 1.f - w1l;
-                if (w1 + w1p == ix) wgt += w1l;   // (w1p = 0 at the last column: both terms land on it, as in the forward)
-            }
-            wx[e] = wgt;
-        }
-        float acc = 0.f;
-        const int oy0 = 2 * iy - 2;
-#pragma unroll
-        for (int f = 0; f < 6; ++f) {
-            const int oy = oy0 + f;
-            if (oy < 0 || oy >= OH) continue;
-            const float h1r = rh * (float)oy;
-            const int h1 = (int)h1r, h1p = (h1 < H - 1) ? 1 : 0;
-            const float h1l = h1r - (float)h1;
-            float wy = 0.f;
-            if (h1 == iy) wy += 1.f - h1l;
-            if (h1 + h1p == iy) wy += h1l;
-            if (wy == 0.f) continue;
-            const float *row = dout + (pl * OH + oy) * OW;
-            float r = 0.f;
-#pragma unroll
-            for (int e = 0; e < 6; ++e) {    // branch-free: columns outside the row read a clamped address and are SELECTED away
-                const float t = wx[e] * row[min(max(ox0 + e, 0), OW - 1)];   // (v_cndmask, not a multiply by 0: 0 * Inf of an overflowed border gradient would be NaN)
-                r += wx[e] != 0.f ? t : 0.f;
-            }
-            acc += wy * r;
-        }
-        din[idx] = acc;
+        din[idx] = upsample2x_bwd_pixel(dout, t / H, (int)(t % H), ix, H, W, rh, rw);
     }
 }
+
+// power-of-two width, fewer than 2^31 input pixels: shift / mask / one 32-bit division instead of two 64-bit divisions (see k_upsample2x_p2)
+__global__ void __launch_bounds__(256) k_upsample2x_bwd_p2(const float *__restrict__ dout, float *__restrict__ din, uint32_t total, int H, int W,
+                                                           float rh, float rw, int log2_w)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t t = idx >> log2_w, pl = t / (uint32_t)H;
+    din[idx] = upsample2x_bwd_pixel(dout, (int64_t)pl, (int)(t - pl * (uint32_t)H), (int)(idx & ((1u << log2_w) - 1u)), H, W, rh, rw);
+}
 #pragma clang fp contract(fast)
+
+// the fast kernels' precondition: 2W / 4 a power of two in 1 .. 256, fewer than 2^31 output rows
+static bool upsample_p2_ok(int64_t planes, int H, int W)
+{
+    const int ow4 = 2 * W / 4;
+    return ow4 >= 1 && ow4 <= 256 && (ow4 & (ow4 - 1)) == 0 && planes * 2 * H < (int64_t)0x7fffffff;
+}
 
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream)
 {
@@ -140,8 +179,12 @@ int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, 
     const float rh = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, rw = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
     const int64_t blocks = (planes * H * W + 255) / 256;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_upsample2x_bwd, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, dout, din,
-                       planes, H, W, rh, rw);
+    if ((W & (W - 1)) == 0 && planes * H * W < (int64_t)0x7fffffff)
+        hipLaunchKernelGGL(k_upsample2x_bwd_p2, dim3((unsigned)blocks), dim3(256), 0, stream, dout, din, (uint32_t)(planes * H * W), H, W, rh, rw,
+                           __builtin_ctz((unsigned)W));
+    else
+        hipLaunchKernelGGL(k_upsample2x_bwd, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, dout, din,
+                           planes, H, W, rh, rw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
@@ -154,8 +197,14 @@ int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hi
     const int64_t total = planes * 2 * H * (2 * W / 4);
     const int64_t blocks = (total + 255) / 256;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_upsample2x<false>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in,
-                       (const float *)nullptr, out, planes, H, W, rh, rw);
+    if (upsample_p2_ok(planes, H, W)) {
+        const int l2 = __builtin_ctz((unsigned)(2 * W / 4));
+        const int64_t rows = planes * 2 * H;
+        hipLaunchKernelGGL(k_upsample2x_p2<false>, dim3((unsigned)((rows + (256 >> l2) - 1) >> (8 - l2))), dim3(256), 0, stream, in,
+                           (const float *)nullptr, out, (uint32_t)rows, H, W, rh, rw, l2);
+    } else
+        hipLaunchKernelGGL(k_upsample2x<false>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in,
+                           (const float *)nullptr, out, planes, H, W, rh, rw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
@@ -211,8 +260,14 @@ int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, in
     const int64_t total = planes * 2 * H * (2 * W / 4);
     const int64_t blocks = (total + 255) / 256;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_upsample2x<true>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in, addend,
-                       out, planes, H, W, rh, rw);
+    if (upsample_p2_ok(planes, H, W)) {
+        const int l2 = __builtin_ctz((unsigned)(2 * W / 4));
+        const int64_t rows = planes * 2 * H;
+        hipLaunchKernelGGL(k_upsample2x_p2<true>, dim3((unsigned)((rows + (256 >> l2) - 1) >> (8 - l2))), dim3(256), 0, stream, in, addend,
+                           out, (uint32_t)rows, H, W, rh, rw, l2);
+    } else
+        hipLaunchKernelGGL(k_upsample2x<true>, dim3((unsigned)(blocks > 65536 * 16 ? 65536 * 16 : blocks)), dim3(256), 0, stream, in, addend,
+                           out, planes, H, W, rh, rw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
