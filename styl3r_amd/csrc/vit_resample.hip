@@ -54,17 +54,49 @@ __global__ void __launch_bounds__(256) k_upsample2x(const float *__restrict__ in
     }
 }
 
-// The same for output rows of a power-of-two number of 16-byte groups (every map of the DPT heads) and fewer than 2^31 output rows: a
-// workgroup covers 256 / OW4 whole rows, the (row, group) split is a shift and a mask and the (plane, y) split ONE 32-bit division -- the
-// generic kernel above spends three 64-bit divisions per thread on it, more instructions than the interpolation itself (round 5).
+// The same for output rows of a power-of-two number (<= 256) of 16-byte groups -- every map of the DPT heads -- and fewer than 2^31 output rows.
+// A workgroup covers 256 / OW4 whole output rows.  The two input rows an output row interpolates between (2 W floats) are fetched by THAT row's
+// OW4 = W / 2 threads with ONE coalesced 16-byte load each and parked in LDS (4 KiB per workgroup whatever W is); the sixteen values a thread
+// needs then come out of LDS.  The generic kernel gathers them with sixteen 4-byte global loads per thread: it runs at 1.9 TB/s of algorithmic
+// traffic where a copy of the same bytes runs at 5.3 (tools/probes/upsample_lab.py) -- the load instructions, not the bytes, are its limit.
+// (row, group) is a shift and a mask, (plane, y) one 32-bit division.  Same arithmetic in the same order: bit-identical outputs.
 template <bool ADD>
 __global__ void __launch_bounds__(256) k_upsample2x_p2(const float *__restrict__ in, const float *__restrict__ addend, float *__restrict__ out,
                                                        uint32_t rows, int H, int W, float rh, float rw, int log2_ow4)
 {
-    const uint32_t row = (blockIdx.x << (8 - log2_ow4)) + (threadIdx.x >> log2_ow4);
-    if (row >= rows) return;
+    __shared__ float4 s_rows[256];                       // [row of the workgroup][input row 0 / 1][W floats] = 256 x 16 bytes
+    const uint32_t rloc = threadIdx.x >> log2_ow4, c = threadIdx.x & ((1u << log2_ow4) - 1u);
+    const uint32_t row = min((blockIdx.x << (8 - log2_ow4)) + rloc, rows - 1u);      // (clamped, not returned: the barrier below is for everyone)
+    const bool live = (blockIdx.x << (8 - log2_ow4)) + rloc < rows;
     const uint32_t OH = 2u * (uint32_t)H, pl = row / OH;
-    upsample2x_quad<ADD>(in, addend, out, (int64_t)pl, (int)(row - pl * OH), (int)(threadIdx.x & ((1u << log2_ow4) - 1u)), H, W, rh, rw);
+    const int oy = (int)(row - pl * OH), OW = 2 * W;
+    const float h1r = rh * (float)oy;
+    const int h1 = (int)h1r, h1p = (h1 < H - 1) ? 1 : 0;
+    const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
+    {   // thread c of the row: 16-byte group c of the 2 W floats [row h1 | row h1 + h1p]
+        const int w4 = W >> 2, which = (int)c >= w4 ? 1 : 0, g4 = (int)c - which * w4;
+        const float *src = in + ((int64_t)pl * H + h1 + which * h1p) * W + 4 * g4;
+        s_rows[threadIdx.x] = *reinterpret_cast<const float4 *>(src);
+    }
+    __syncthreads();
+    if (!live) return;
+    const float *r0 = reinterpret_cast<const float *>(s_rows + (rloc << log2_ow4)), *r1 = r0 + W;
+    float4 o;
+    float *po = reinterpret_cast<float *>(&o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ox = (int)c * 4 + e;
+        const float w1r = rw * (float)ox;
+        const int w1 = (int)w1r, w1p = (w1 < W - 1) ? 1 : 0;
+        const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        po[e] = h0l * (w0l * r0[w1] + w1l * r0[w1 + w1p]) + h1l * (w0l * r1[w1] + w1l * r1[w1 + w1p]);
+    }
+    const int64_t obase = ((int64_t)pl * OH + oy) * OW + (int64_t)c * 4;
+    if (ADD) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(addend + obase);
+        o.x += fmaxf(a4.x, 0.f); o.y += fmaxf(a4.y, 0.f); o.z += fmaxf(a4.z, 0.f); o.w += fmaxf(a4.w, 0.f);
+    }
+    *reinterpret_cast<float4 *>(out + obase) = o;
 }
 
 // 7x7 / stride 1 / padding 3 patches of a 3-channel image as 160 "channels" (147 = 3 x 7 x 7 taps in the weight's (ci, ky, kx)
@@ -101,7 +133,8 @@ __global__ void __launch_bounds__(256) k_im2col7(const float *__restrict__ img, 
 // output rows / columns whose source cell touches it.  With scale (H-1)/(2H-1) < 1/2 those are among the six candidates
 // 2i-2 .. 2i+3; each candidate's cell index is recomputed with the forward's own float arithmetic, so forward and
 // backward agree on every floor() decision.  One pass: dout read once (cached across neighbours), din written once.
-__device__ inline float upsample2x_bwd_pixel(const float *__restrict__ dout, int64_t pl, int iy, int ix, int H, int W, float rh, float rw)
+// `rows0`: the address of output row `oy_base` of the pixel's plane (global memory, or the workgroup's LDS copy of a band of rows)
+__device__ inline float upsample2x_bwd_pixel(const float *__restrict__ rows0, int oy_base, int iy, int ix, int H, int W, float rh, float rw)
 {
     const int OH = 2 * H, OW = 2 * W;
     float wx[6];
@@ -132,7 +165,7 @@ __device__ inline float upsample2x_bwd_pixel(const float *__restrict__ dout, int
         if (h1 == iy) wy += 1.f - h1l;
         if (h1 + h1p == iy) wy += h1l;
         if (wy == 0.f) continue;
-        const float *row = dout + (pl * OH + oy) * OW;
+        const float *row = rows0 + (int64_t)(oy - oy_base) * OW;
         float r = 0.f;
 #pragma unroll
         for (int e = 0; e < 6; ++e) {    // branch-free: columns outside the row read a clamped address and are SELECTED away
@@ -151,7 +184,7 @@ __global__ void __launch_bounds__(256) k_upsample2x_bwd(const float *__restrict_
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int ix = (int)(idx % W);
         const int64_t t = idx / W;
-        din[idx] = upsample2x_bwd_pixel(dout, t / H, (int)(t % H), ix, H, W, rh, rw);
+        din[idx] = upsample2x_bwd_pixel(dout + (t / H) * (int64_t)(4 * H) * W, 0, (int)(t % H), ix, H, W, rh, rw);
     }
 }
 
@@ -162,15 +195,36 @@ __global__ void __launch_bounds__(256) k_upsample2x_bwd_p2(const float *__restri
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= total) return;
     const uint32_t t = idx >> log2_w, pl = t / (uint32_t)H;
-    din[idx] = upsample2x_bwd_pixel(dout, (int64_t)pl, (int)(t - pl * (uint32_t)H), (int)(idx & ((1u << log2_w) - 1u)), H, W, rh, rw);
+    din[idx] = upsample2x_bwd_pixel(dout + (int64_t)pl * (4 * H) * W, 0, (int)(t - pl * (uint32_t)H), (int)(idx & ((1u << log2_w) - 1u)), H, W, rh, rw);
+}
+
+// The backward through LDS (power-of-two W <= 256 and H, at least 256 pixels per plane): a workgroup owns R = 256 / W input rows of one plane; the
+// 2 R + 4 output rows they collect from are copied to LDS with coalesced 16-byte loads, and the 36 candidate taps of a pixel come out of LDS
+// instead of 36 four-byte global loads per thread (the forward's finding, k_upsample2x_p2).  Same taps, same order: bit-identical gradients.
+__global__ void __launch_bounds__(256) k_upsample2x_bwd_lds(const float *__restrict__ dout, float *__restrict__ din, int H, int W, float rh, float rw,
+                                                            int log2_w)
+{
+    extern __shared__ float4 s_band4[];
+    const int R = 256 >> log2_w, OH = 2 * H, OW = 2 * W;
+    const int bands = H / R;                                   // workgroups per plane
+    const uint32_t pl = blockIdx.x / (uint32_t)bands;
+    const int iy0 = (int)(blockIdx.x - pl * (uint32_t)bands) * R;
+    const int oy_lo = max(2 * iy0 - 2, 0), oy_hi = min(2 * (iy0 + R - 1) + 3, OH - 1);
+    const float *plane = dout + (int64_t)pl * OH * OW;
+    const int n4 = (oy_hi - oy_lo + 1) * (OW >> 2);
+    const float4 *src = reinterpret_cast<const float4 *>(plane + (int64_t)oy_lo * OW);
+    for (int i = threadIdx.x; i < n4; i += 256) s_band4[i] = src[i];
+    __syncthreads();
+    const int ix = (int)(threadIdx.x & ((1u << log2_w) - 1u)), iy = iy0 + (int)(threadIdx.x >> log2_w);
+    din[((int64_t)pl * H + iy) * W + ix] = upsample2x_bwd_pixel(reinterpret_cast<const float *>(s_band4), oy_lo, iy, ix, H, W, rh, rw);
 }
 #pragma clang fp contract(fast)
 
-// the fast kernels' precondition: 2W / 4 a power of two in 1 .. 256, fewer than 2^31 output rows
+// the fast forward kernel's precondition: W a multiple of 4, 2W / 4 a power of two <= 256, fewer than 2^31 output rows
 static bool upsample_p2_ok(int64_t planes, int H, int W)
 {
     const int ow4 = 2 * W / 4;
-    return ow4 >= 1 && ow4 <= 256 && (ow4 & (ow4 - 1)) == 0 && planes * 2 * H < (int64_t)0x7fffffff;
+    return (W & 3) == 0 && ow4 <= 256 && (ow4 & (ow4 - 1)) == 0 && planes * 2 * H < (int64_t)0x7fffffff;
 }
 
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream)
@@ -179,7 +233,11 @@ int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, 
     const float rh = H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.f, rw = W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.f;
     const int64_t blocks = (planes * H * W + 255) / 256;
     (void)hipGetLastError();
-    if ((W & (W - 1)) == 0 && planes * H * W < (int64_t)0x7fffffff)
+    const int R = (W & (W - 1)) == 0 && W <= 256 && W >= 2 ? 256 / W : 0;
+    if (R && (H & (H - 1)) == 0 && H >= R && planes * (H / R) < (int64_t)0x7fffffff)
+        hipLaunchKernelGGL(k_upsample2x_bwd_lds, dim3((unsigned)(planes * (H / R))), dim3(256), (size_t)(2 * R + 4) * 2 * W * sizeof(float), stream, dout,
+                           din, H, W, rh, rw, __builtin_ctz((unsigned)W));
+    else if ((W & (W - 1)) == 0 && planes * H * W < (int64_t)0x7fffffff)
         hipLaunchKernelGGL(k_upsample2x_bwd_p2, dim3((unsigned)blocks), dim3(256), 0, stream, dout, din, (uint32_t)(planes * H * W), H, W, rh, rw,
                            __builtin_ctz((unsigned)W));
     else
