@@ -553,8 +553,8 @@ def test_prezeroed_gradient_accumulators_equal_the_memset_path_and_survive_a_sec
 def test_lds_histogram_binning_equals_the_wave_aggregated_one(monkeypatch):
     """K1 / K3 bin through LDS histograms when a view has at most LDS_TILES_MAX tiles (round 5); GSR_BIN=ballot selects the wave-aggregated
     global atomics of rounds 1 - 4, which larger images still take.  Both must leave the same sorted lists: images, radii, depth, n_contrib and
-    gradients are compared bit for bit (the composite kernels are deterministic given the lists; the backward's atomics are summed in
-    tile-schedule order in both runs: 1e-6)."""
+    are compared bit for bit (the composite forward is deterministic given the lists); the gradients at 2e-5 (the backward's per-tile atomics
+    arrive in whatever order the tiles finish)."""
     from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder
     from styl3r_amd.scenes import make_scene
     dev = torch.device("cuda:0")
@@ -577,4 +577,4 @@ def test_lds_histogram_binning_equals_the_wave_aggregated_one(monkeypatch):
     assert a[3] == b[3] and a[3] > 0
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for x, y, name in zip(a[4], b[4], ("means", "cov", "sh", "opac")):
-        assert_close_rel(x.cpu().numpy(), y.cpu().numpy(), 1e-6, f"lds vs ballot binning d{name}")
+        assert_close_rel(x.cpu().numpy(), y.cpu().numpy(), 2e-5, f"lds vs ballot binning d{name}")      # (the bar of the prezero / memset test below: atomics arrive in any order)
