@@ -191,6 +191,10 @@ typedef struct GsrProfile GsrProfile;
 GsrProfile *gsr_profile_create(int max_calls);
 void gsr_profile_destroy(GsrProfile *prof);
 int gsr_profile_read(GsrProfile *prof, float *ms_sum /* [GSR_N_STAGES] */, int32_t *count /* [GSR_N_STAGES] */);
+/* Restrict the timing to the stages whose bit (1 << GSR_STAGE_*) is set in `stage_mask` (default: all).  Every timed stage puts two event
+ * records between kernels that would otherwise follow each other back to back (~5 us per boundary); a caller that wants the duration of the
+ * composite kernels INSIDE a wall-clock-timed region asks for those two only.  Stages outside the mask read back with count 0. */
+int gsr_profile_set_stages(GsrProfile *prof, uint32_t stage_mask);
 
 /* Text of the HIP error behind the calling thread's last GSR_ELAUNCH ("" if none). */
 const char *gsr_last_error(void);

@@ -105,7 +105,7 @@ GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7
 STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
 EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
-           "gsr_profile_destroy", "gsr_profile_read", "gsr_last_error", "gsr_build_views", "gsr_mse_scratch_bytes",
+           "gsr_profile_destroy", "gsr_profile_read", "gsr_profile_set_stages", "gsr_last_error", "gsr_build_views", "gsr_mse_scratch_bytes",
            "gsr_mse_forward", "gsr_mse_backward")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
           -2: "GSR_ENOSPACE (workspace too small)", -3: "GSR_ELAUNCH (kernel launch failed)"}
@@ -150,6 +150,8 @@ def load() -> C.CDLL:
     lib.gsr_profile_destroy.argtypes = [C.c_void_p]
     lib.gsr_profile_destroy.restype = None
     lib.gsr_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.gsr_profile_set_stages.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gsr_profile_set_stages.restype = C.c_int
     lib.gsr_profile_read.restype = C.c_int
     _lib = lib
     return lib
@@ -174,6 +176,11 @@ class StageProfile:
         self.handle = load().gsr_profile_create(int(max_calls))
         if not self.handle:
             raise RuntimeError("gsr_profile_create failed")
+
+    def set_stages(self, names=None):
+        """time only the named stages (None = all): every timed stage costs two event records between otherwise back-to-back kernels"""
+        mask = (1 << GSR_N_STAGES) - 1 if names is None else sum(1 << STAGE_NAMES.index(n) for n in names)
+        check(load().gsr_profile_set_stages(self.handle, mask), "gsr_profile_set_stages")
 
     def read(self) -> dict:
         ms = (C.c_float * GSR_N_STAGES)()

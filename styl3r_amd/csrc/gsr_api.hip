@@ -190,7 +190,7 @@ __attribute__((visibility("default"))) GsrProfile *gsr_profile_create(int max_ca
     if (max_calls <= 0) return nullptr;
     GsrProfile *p = new (std::nothrow) GsrProfile;
     if (!p) return nullptr;
-    p->max_calls = max_calls; p->next_fwd = p->next_bwd = 0;
+    p->max_calls = max_calls; p->next_fwd = p->next_bwd = 0; p->mask = (1u << GSR_N_STAGES) - 1u;
     const size_t n = (size_t)max_calls * GSR_N_STAGES * 2;
     p->ev = new (std::nothrow) hipEvent_t[n];
     if (!p->ev) { delete p; return nullptr; }
@@ -214,6 +214,7 @@ __attribute__((visibility("default"))) int gsr_profile_read(GsrProfile *p, float
     if (!p || !ms_sum || !count) return GSR_EINVAL;
     for (int s = 0; s < GSR_N_STAGES; ++s) { ms_sum[s] = 0.f; count[s] = 0; }
     for (int s = 0; s < GSR_N_STAGES; ++s) {
+        if (!((p->mask >> s) & 1u)) continue;
         const int n = (s <= GSR_STAGE_COMPOSITE_FWD) ? p->next_fwd : p->next_bwd;
         for (int c = 0; c < n; ++c) {
             float ms = 0.f;
@@ -223,6 +224,13 @@ __attribute__((visibility("default"))) int gsr_profile_read(GsrProfile *p, float
         }
     }
     p->next_fwd = p->next_bwd = 0;
+    return GSR_OK;
+}
+
+__attribute__((visibility("default"))) int gsr_profile_set_stages(GsrProfile *p, uint32_t stage_mask)
+{
+    if (!p || p->next_fwd || p->next_bwd) return GSR_EINVAL;      // between reads only: a half-recorded profile cannot change its stages
+    p->mask = stage_mask & ((1u << GSR_N_STAGES) - 1u);
     return GSR_OK;
 }
 

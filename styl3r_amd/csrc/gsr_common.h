@@ -54,6 +54,7 @@ struct Ptrs {             // carved workspace
 struct GsrProfile {
     int max_calls;
     int next_fwd, next_bwd;
+    uint32_t mask;   // stages that record events (gsr_profile_set_stages)
     hipEvent_t *ev;  // [max_calls][GSR_N_STAGES][2]
     hipEvent_t &at(int call, int stage, int which) { return ev[((size_t)call * GSR_N_STAGES + stage) * 2 + which]; }
 };
@@ -87,8 +88,8 @@ struct StageTimer {
         if (resume) { if (n > 0 && n <= p->max_calls) slot = n - 1; }
         else if (n < p->max_calls) slot = n++;
     }
-    void begin(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 0), s); }
-    void end(int stage) { if (slot >= 0) (void)hipEventRecord(p->at(slot, stage, 1), s); }
+    void begin(int stage) { if (slot >= 0 && ((p->mask >> stage) & 1u)) (void)hipEventRecord(p->at(slot, stage, 0), s); }
+    void end(int stage) { if (slot >= 0 && ((p->mask >> stage) & 1u)) (void)hipEventRecord(p->at(slot, stage, 1), s); }
 };
 
 __host__ __device__ inline int tiles_x(int W) { return (W + TILE - 1) / TILE; }
