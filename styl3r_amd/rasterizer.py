@@ -255,11 +255,19 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is None:
             cov3D_precomp = _cov6_from_scale_rot(scales, rotations, float(s.scale_modifier))
         f32 = dict(dtype=torch.float32, device=dev)
-        tanx = torch.as_tensor(s.tanfovx, **f32).reshape(1)
-        tany = torch.as_tensor(s.tanfovy, **f32).reshape(1)
-        views = pack_views(s.viewmatrix.to(**f32)[None], s.projmatrix.to(**f32)[None],
-                           s.projmatrix_raw.to(**f32)[None], s.campos.to(**f32)[None], tanx, tany,
-                           s.bg.to(**f32)[None])
+        if isinstance(s.tanfovx, (int, float)) and isinstance(s.tanfovy, (int, float)):
+            # the reference's call pattern (cuda_splatting.py:101-114): Python floats for the two tangents, device tensors for the rest.  One host
+            # row [tanx, tany, 1 (scale), 0 x 7 (padding)] -> ONE host-to-device copy, and the 64-float view row is ONE concatenation
+            # (round 5; before: two copies and pack_views' zero fill + eight slice assignments, ~10 tiny launches per view of a per-view loop)
+            tail = torch.tensor([float(s.tanfovx), float(s.tanfovy), 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32).to(dev)
+            views = torch.cat((s.viewmatrix.to(**f32).reshape(16), s.projmatrix.to(**f32).reshape(16), s.projmatrix_raw.to(**f32).reshape(16),
+                               s.campos.to(**f32).reshape(3), tail[0:2], s.bg.to(**f32).reshape(3), tail[2:10]))[None]
+        else:
+            tanx = torch.as_tensor(s.tanfovx, **f32).reshape(1)
+            tany = torch.as_tensor(s.tanfovy, **f32).reshape(1)
+            views = pack_views(s.viewmatrix.to(**f32)[None], s.projmatrix.to(**f32)[None],
+                               s.projmatrix_raw.to(**f32)[None], s.campos.to(**f32)[None], tanx, tany,
+                               s.bg.to(**f32)[None])
         use_sh = shs is not None
         colors = shs if use_sh else colors_precomp
         th = theta.reshape(1, 3) if theta is not None else None
