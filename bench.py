@@ -250,8 +250,16 @@ def raster_leg(args, rank, world, dev, dist):
     def step():
         for t in (g.means, g.covariances, g.harmonics, g.opacities):
             t.grad = None
+        # LossMse (src/loss/loss_mse.py:22-31) computed inside the composite kernels (DecoderOutput.loss_mse, round 6)
+        out = dec.forward(g, cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (H, W), mse_target=target)
+        out.loss_mse.backward()
+        return out.loss_mse
+
+    def step_unfused():       # the round-5 step: decoder, then LossMse as the stand-alone gsr_mse_forward / gsr_mse_backward kernels
+        for t in (g.means, g.covariances, g.harmonics, g.opacities):
+            t.grad = None
         out = dec.forward(g, cams["extrinsics"], cams["intrinsics"], cams["near"], cams["far"], (H, W))
-        loss = mse_loss(out.color, target)              # LossMse (src/loss/loss_mse.py:22-31) on gsr_mse_forward/backward
+        loss = mse_loss(out.color, target)
         loss.backward()
         return loss
 
@@ -285,6 +293,19 @@ def raster_leg(args, rank, world, dev, dist):
         for name, val in prof.read().items():
             if not name.startswith("composite"):
                 stage_ms[name] = val
+        rz.PROFILE = None
+        # A/B in the same run: the same workload with the loss as two kernels of its own (what `value` was measured on up to round 5)
+        n_ab = min(args.steps, 100)
+        for _ in range(5):
+            step_unfused()
+        torch.cuda.synchronize(dev)
+        t_ab = time.perf_counter()
+        for _ in range(n_ab):
+            step_unfused()
+        torch.cuda.synchronize(dev)
+        unfused = {"ms_per_step": round(1e3 * (time.perf_counter() - t_ab) / n_ab, 4), "steps": n_ab,
+                   "what": "decoder forward, then LossMse as the stand-alone gsr_mse_forward / gsr_mse_backward kernels (the step of rounds 1-5)"}
+        loss_fused, loss_unfused = float(step().item()), float(step_unfused().item())
     finally:
         gc.enable()
     rz.PROFILE = None
@@ -340,13 +361,14 @@ def raster_leg(args, rank, world, dev, dist):
         "value": round(dist_utils.aggregate_throughput(V, args.steps, world, dt), 2), "unit": "views/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE): {B} scenes x {Vt} target views/GPU/step, "
+        "config": {"workload": f"rasterizer fwd+bwd (decoder API + MSE, the loss computed inside the composite kernels): {B} scenes x {Vt} target views/GPU/step, "
                                f"{H}x{W}, G={G} Gaussians/scene ({args.ctx} ctx view x {args.grid}x{args.grid}), sh_degree="
                                f"{args.sh_degree}, make_scale_invariant, all views in one batched launch; outputs the decoder discards are not computed "
                                f"(decoder_splatting_cuda.py:37-68 drops radii / opacity / n_touched, MSE sends no depth gradient: the composite kernels run "
                                f"their n_touched-free / depth-gradient-free instantiations -- the consumed results are identical)",
                    "views_per_step_per_gpu": V, "gaussians_per_scene": G, "parallelism": f"dp{world} (scenes sharded)"},
         "roofline": roofline, "roofline_composite_fwd": roofline_cf,
+        "mse_stand_alone_kernels": dict(unfused, views_per_s=round(V / (unfused["ms_per_step"] * 1e-3), 1), loss=loss_unfused, loss_fused=loss_fused),
     }
     if rank == 0 and not getattr(args, "no_dropin_leg", False):
         try:

@@ -83,6 +83,8 @@ typedef struct GsrDims {
                                     accumulators (126 MB at the headline size; that kernel is VALU-bound, HBM is idle under it).
                                     gsr_backward with the same flag then skips its own memset.  Valid for the FIRST backward
                                     after the forward only: the backward leaves the accumulators dirty. */
+#define GSR_FLAG_BIN_BALLOT 32    /* K1 / K3 bin with wave-aggregated global atomics (the path of images beyond 4 096 tiles per view) even where
+                                    the per-workgroup LDS histograms apply: A/B runs and the equivalence test */
 #define GSR_FLAG_SORT_KEYS_SHIFT 8   /* bits 8-9: LDS budget of the per-tile depth sort: 0 = 4096 keys (default), 1 = 1024,
                                        2 = 2048.  Pick the smallest budget >= the longest per-tile list expected
                                        (status[GSR_ST_MAX_TILE] of an earlier call): more workgroups fit a CU.  Longer lists
@@ -102,21 +104,29 @@ typedef struct GsrLayout {
     size_t tile_offset;  /* uint32[V*T+1]   exclusive scan; ranges[t] = [off[t], off[t+1]) */
     size_t tile_cursor;  /* uint32[V*T]     scatter cursors */
     size_t pairs;        /* uint64[cap]     (depth_bits << 32 | id), bucketed by (view, tile) */
-    size_t point_list;   /* uint32[cap]     per-tile depth-sorted Gaussian ids */
+    size_t point_list;   /* uint32[cap]     per-tile depth-sorted Gaussian ids in bits 0..27 (GSR_ID_MASK; G < 2^28 by the record-offset limit
+                            below).  Bits 28..31 are written by the composite forward and read by the backward: bit 28 + q = the entry's
+                            alpha >= 1/255 footprint can reach 8x8 quadrant q (TL, TR, BL, BR) of its tile -- what the forward hands
+                            the backward instead of a separate mask stream (round 6; rounds 2-5: a byte, then a 32-bit word per entry) */
     size_t final_T;      /* float[V*H*W] */
     size_t n_contrib;    /* uint32[V*H*W] */
     size_t grad_rec;     /* float[V*G*12]   backward per-(view,Gaussian) accumulators */
     size_t status;       /* int32[GSR_STATUS_WORDS] internal copy */
     size_t tile_order;   /* uint32[V*T]     (view*T + tile) ids, longest list first: launch order of the composite kernels */
     size_t pairs_alt;    /* uint64[cap]     bucket space of the per-tile sort for lists longer than its LDS budget */
-    size_t block_mask;   /* uint32[cap]     per list entry: the 2-row x 4-column pixel blocks of its tile the entry was composited into,
-                            bit 8 q + 2 by + BX (8x8 quadrant q = TL,TR,BL,BR; by = 0..3, BX = 0..1 inside it): forward -> backward,
-                            whose rows walk exactly these (entry, block) items */
+    size_t loss_partial; /* float[V*T + V]  fused MSE: per-tile sums of squared errors, then per-view sums (fixed-order reduction) */
+    size_t loss_ticket;  /* uint32[V + 1]   fused MSE: arrival counters of a view's tiles / of the views; zeroed by the tile scan */
+    size_t loss_diff;    /* float[V*3*H*W]  fused MSE: image - target as the composite forward had it in registers; the backward scales it
+                            to dL/dimage (one 12-byte read per pixel, as with a dL_dimage from outside) */
     size_t total;        /* total bytes */
 } GsrLayout;
 
+#define GSR_ID_MASK 0x0fffffffu
+#define GSR_QUAD_SHIFT 28
+
 /* Size/offsets of the workspace for (dims, pair_capacity).  Returns GSR_OK or GSR_EINVAL.
- * Limits: pair_capacity < 2^32; G * 48 bytes < 2^32 (the composite kernels address one view's records with 32-bit byte offsets). */
+ * Limits: pair_capacity < 2^32; G * 48 bytes < 2^32 (the composite kernels address one view's records with 32-bit byte offsets; hence
+ * ids < 2^27 and the four mask bits of a point_list word are free). */
 int gsr_workspace_layout(const GsrDims *dims, int64_t pair_capacity, GsrLayout *out);
 
 /*
@@ -126,7 +136,8 @@ int gsr_workspace_layout(const GsrDims *dims, int64_t pair_capacity, GsrLayout *
  *   shs     float (B,G,M,3) or, when M == 0, RGB (B,G,3)
  * Outputs: image (V,3,H,W), depth (V,H,W), opacity (V,H,W), radii int32 (V,G),
  *          n_touched int32 (V,G) (may be NULL unless GSR_FLAG_NTOUCHED),
- *          status int32[GSR_STATUS_WORDS].
+ *          status int32[GSR_STATUS_WORDS] -- device memory, or device-accessible pinned HOST memory: the tile scan stores the
+ *          words there directly and the host reads them behind an event, no copy kernel.
  * The call only enqueues work on `stream` (no host sync).  If status[GSR_ST_OVERFLOW]
  * is set the images are invalid and the call must be repeated with
  * pair_capacity >= status[GSR_ST_PAIRS].
@@ -148,6 +159,37 @@ int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means, 
                  const float *shs, int64_t pair_capacity, void *workspace, size_t workspace_bytes,
                  const float *dL_dimage, const float *dL_ddepth, float *dL_dmeans, float *dL_dcov6,
                  float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau, void *stream);
+
+/*
+ * The same two calls with the per-step host / launch overhead folded into the kernels (round 6).  `fx` may be NULL (= the plain calls).
+ *   tile_count   optional PERSISTENT per-tile counters, uint32[V*T] of device memory the caller zeroed ONCE at allocation and keeps per
+ *                stream: the preprocess counts into them and the tile scan leaves them zero again, so no memset runs in front of the
+ *                forward.  NULL: the counters of the workspace, zeroed by the call itself.
+ *   mse_target   optional (V,3,H,W): `LossMse.forward` (src/loss/loss_mse.py:22-31) fused into the composite kernels --
+ *                forward: the composite kernel sums (image - target)^2 per tile while the pixels are still in registers, the last tile of
+ *                  every view and the last view add the partials in index order (deterministic), mse_loss[0] = mse_weight * mean;
+ *                backward: the composite kernel forms dL/dimage = dL_dimage (may be NULL) + 2 mse_weight / n * mse_grad_loss[0] *
+ *                  (image - target) in its prologue from the difference the forward left in the workspace -- two kernels less than
+ *                  gsr_mse_forward / gsr_mse_backward around the plain calls, same values.  (The backward needs mse_target only as the
+ *                  "fused" switch and mse_weight / mse_grad_loss for the coefficient.)
+ *   mse_grad_loss  device fp32[1], the upstream gradient of the loss; NULL = 1.
+ */
+typedef struct GsrFused {
+    uint32_t *tile_count;
+    const float *mse_target;
+    float mse_weight;
+    float *mse_loss;             /* forward: out, device fp32[1] */
+    const float *mse_grad_loss;  /* backward: in */
+} GsrFused;
+int gsr_forward_fused(const GsrDims *dims, const GsrView *views, const float *means, const float *cov6,
+                      const float *opac, const float *shs, int64_t pair_capacity, void *workspace,
+                      size_t workspace_bytes, float *image, float *depth, float *opacity, int32_t *radii,
+                      int32_t *n_touched, int32_t *status, const GsrFused *fx, void *stream);
+int gsr_backward_fused(const GsrDims *dims, const GsrView *views, const float *means, const float *cov6,
+                       const float *shs, int64_t pair_capacity, void *workspace, size_t workspace_bytes,
+                       const float *dL_dimage, const float *dL_ddepth, float *dL_dmeans, float *dL_dcov6,
+                       float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau, const GsrFused *fx,
+                       void *stream);
 
 /*
  * Camera set-up of `render_cuda` (cuda_splatting.py:65-88) for V views in ONE launch: the 1/near rescale

@@ -91,7 +91,13 @@ class GsrDims(C.Structure):
 
 class GsrLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("records", "tile_count", "tile_offset", "tile_cursor", "pairs", "point_list",
-                                          "final_T", "n_contrib", "grad_rec", "status", "tile_order", "pairs_alt", "block_mask", "total")]
+                                          "final_T", "n_contrib", "grad_rec", "status", "tile_order", "pairs_alt", "loss_partial", "loss_ticket", "loss_diff", "total")]
+
+
+class GsrFused(C.Structure):
+    """include/gsr.h GsrFused: persistent tile counters + LossMse fused into the composite kernels"""
+    _fields_ = [("tile_count", C.c_void_p), ("mse_target", C.c_void_p), ("mse_weight", C.c_float), ("mse_loss", C.c_void_p),
+                ("mse_grad_loss", C.c_void_p)]
 
 
 GSR_FLAG_NTOUCHED = 1
@@ -99,12 +105,15 @@ GSR_FLAG_COV9 = 2
 GSR_FLAG_PHASE_BIN = 4
 GSR_FLAG_PHASE_RENDER = 8
 GSR_FLAG_PREZERO_GRADS = 16
+GSR_FLAG_BIN_BALLOT = 32
+GSR_ID_MASK = 0x0FFFFFFF
+GSR_QUAD_SHIFT = 28
 GSR_FLAG_SORT_KEYS_SHIFT = 8
 GSR_STATUS_WORDS = 8
 GSR_VIEW_FLOATS = 64
 GSR_N_STAGES = 7
 STAGE_NAMES = ("preprocess", "scan_tiles", "scatter", "tile_sort", "composite_fwd", "composite_bwd", "preprocess_bwd")
-EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_version", "gsr_profile_create",
+EXPORTS = ("gsr_workspace_layout", "gsr_forward", "gsr_backward", "gsr_forward_fused", "gsr_backward_fused", "gsr_version", "gsr_profile_create",
            "gsr_profile_destroy", "gsr_profile_read", "gsr_profile_set_stages", "gsr_last_error", "gsr_build_views", "gsr_mse_scratch_bytes",
            "gsr_mse_forward", "gsr_mse_backward")
 ERRORS = {-1: "GSR_EINVAL (bad dimension / null pointer / unsupported degree)",
@@ -135,6 +144,10 @@ def load() -> C.CDLL:
     lib.gsr_forward.restype = C.c_int
     lib.gsr_backward.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gsr_backward.restype = C.c_int
+    lib.gsr_forward_fused.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, C.POINTER(GsrFused), vp]
+    lib.gsr_forward_fused.restype = C.c_int
+    lib.gsr_backward_fused.argtypes = [C.POINTER(GsrDims), vp, vp, vp, vp, i64, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(GsrFused), vp]
+    lib.gsr_backward_fused.restype = C.c_int
     lib.gsr_version.restype = C.c_char_p
     lib.gsr_build_views.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.gsr_build_views.restype = C.c_int

@@ -7,11 +7,11 @@ namespace gsr {
 int layout(const GsrDims &d, long long cap, GsrLayout &L);
 int forward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *opac,
             const float *shs, long long cap, void *workspace, size_t workspace_bytes, float *image, float *depth,
-            float *opacity, int32_t *radii, int32_t *n_touched, int32_t *status, hipStream_t stream);
+            float *opacity, int32_t *radii, int32_t *n_touched, int32_t *status, const GsrFused *fx, hipStream_t stream);
 int backward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *shs,
              long long cap, void *workspace, size_t workspace_bytes, const float *dL_dimage, const float *dL_ddepth,
              float *dL_dmeans, float *dL_dcov6, float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau,
-             hipStream_t stream);
+             const GsrFused *fx, hipStream_t stream);
 }  // namespace gsr
 
 namespace gsr {
@@ -159,7 +159,18 @@ __attribute__((visibility("default"))) int gsr_forward(const GsrDims *dims, cons
 {
     if (!dims) return GSR_EINVAL;
     return gsr::forward(*dims, views, means, cov6, opac, shs, pair_capacity, workspace, workspace_bytes, image, depth,
-                        opacity, radii, n_touched, status, static_cast<hipStream_t>(stream));
+                        opacity, radii, n_touched, status, nullptr, static_cast<hipStream_t>(stream));
+}
+
+__attribute__((visibility("default"))) int gsr_forward_fused(const GsrDims *dims, const GsrView *views, const float *means,
+                                                             const float *cov6, const float *opac, const float *shs,
+                                                             int64_t pair_capacity, void *workspace, size_t workspace_bytes,
+                                                             float *image, float *depth, float *opacity, int32_t *radii,
+                                                             int32_t *n_touched, int32_t *status, const GsrFused *fx, void *stream)
+{
+    if (!dims) return GSR_EINVAL;
+    return gsr::forward(*dims, views, means, cov6, opac, shs, pair_capacity, workspace, workspace_bytes, image, depth,
+                        opacity, radii, n_touched, status, fx, static_cast<hipStream_t>(stream));
 }
 
 __attribute__((visibility("default"))) int gsr_backward(const GsrDims *dims, const GsrView *views, const float *means,
@@ -171,7 +182,19 @@ __attribute__((visibility("default"))) int gsr_backward(const GsrDims *dims, con
 {
     if (!dims) return GSR_EINVAL;
     return gsr::backward(*dims, views, means, cov6, shs, pair_capacity, workspace, workspace_bytes, dL_dimage, dL_ddepth,
-                         dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau, static_cast<hipStream_t>(stream));
+                         dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau, nullptr, static_cast<hipStream_t>(stream));
+}
+
+__attribute__((visibility("default"))) int gsr_backward_fused(const GsrDims *dims, const GsrView *views, const float *means,
+                                                              const float *cov6, const float *shs, int64_t pair_capacity,
+                                                              void *workspace, size_t workspace_bytes, const float *dL_dimage,
+                                                              const float *dL_ddepth, float *dL_dmeans, float *dL_dcov6,
+                                                              float *dL_dopac, float *dL_dshs, float *dL_dmeans2D,
+                                                              float *dL_dtau, const GsrFused *fx, void *stream)
+{
+    if (!dims) return GSR_EINVAL;
+    return gsr::backward(*dims, views, means, cov6, shs, pair_capacity, workspace, workspace_bytes, dL_dimage, dL_ddepth,
+                         dL_dmeans, dL_dcov6, dL_dopac, dL_dshs, dL_dmeans2D, dL_dtau, fx, static_cast<hipStream_t>(stream));
 }
 
 __attribute__((visibility("default"))) int gsr_build_views(const float *c2w, const float *K, const float *near,
@@ -234,6 +257,6 @@ __attribute__((visibility("default"))) int gsr_profile_set_stages(GsrProfile *p,
     return GSR_OK;
 }
 
-__attribute__((visibility("default"))) const char *gsr_version(void) { return "gsr-hip gfx950 0.1.0"; }
+__attribute__((visibility("default"))) const char *gsr_version(void) { return "gsr-hip gfx950 0.6.0"; }
 
 }  // extern "C"

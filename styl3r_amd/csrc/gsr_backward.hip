@@ -3,17 +3,20 @@
 //   K6 composite_bwd    same tiling as the forward (one wavefront per tile, 4 pixels per
 //                       lane); the tile's sorted id list is walked back-to-front from the
 //                       tile's deepest contributor, 64 entries at a time: each lane gathers ONE
-//                       entry's 48-byte record (and the quadrant mask the forward left in
-//                       `quad_mask`) into a wave-private LDS slot, then the wave evaluates the
-//                       batch from LDS broadcasts; each splat's ten partial gradients are
-//                       summed across the 64 lanes in registers (permlane swaps + DPP row
-//                       sums, no LDS) and leave the wave as ONE atomic per (tile, splat,
-//                       component).                                           (upstream R7)
+//                       entry's 48-byte record into a wave-private LDS slot (the quadrant mask
+//                       the forward left in the top bits of the list word rides along), then the
+//                       wave evaluates the batch from LDS broadcasts as straight-line code under
+//                       scalar lane masks; each splat's nine (ten with a depth gradient) partial
+//                       gradients are summed across the 64 lanes in registers (permlane swaps +
+//                       bank-packed DPP row sums, no LDS) and leave the wave as ONE atomic
+//                       instruction per (tile, splat), one lane per component.  Optional
+//                       prologue: dL/dimage of the fused LossMse from the forward's image.  (upstream R7)
 //   K7 preprocess_bwd   per Gaussian, loops over the scene's views and sums their
 //                       contributions in registers (no atomics, deterministic): conic ->
 //                       cov2D -> cov3D / mean, projection, depth, SH, pose (tau).   (R8)
-#include <cstdlib>
-#include <cstring>
+//
+// (The row-packed, systolic re-decomposition of K6 measured in round 5 -- DESIGN.md R5.1, 1.5 x slower than the tile kernel -- lives in
+//  tools/probes/k6_rows_experiment.patch, not in the product library.)
 #include <type_traits>
 
 #include "gsr_common.h"
@@ -29,10 +32,13 @@ enum { GR_RGB = 0, GR_DEPTH = 3, GR_MX = 4, GR_MY = 5, GR_CA = 6, GR_CB = 7, GR_
 // ten-value wave reduction per splat (wave_reduce10) and ten lanes issue the tile's single
 // atomic per component.  No LDS atomics, no workgroup barriers.
 // DEPTH = false: no dL/ddepth was passed (Styl3R trains on colour only): the depth terms drop out of the evaluation
+// MSE: dL/dimage += 2 weight / n * upstream gradient * (image - target), LossMse's backward (loss_mse.py:22-31), formed here from the difference
+// the composite forward left in the workspace (gsr_forward_fused with a target); dL_dimage may then be nullptr (nothing else consumed the image).
 template <bool DEPTH>
 __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      const float *__restrict__ dL_dimage,
-                                                     const float *__restrict__ dL_ddepth)
+                                                     const float *__restrict__ dL_ddepth,
+                                                     bool mse, float mse_weight, const float *__restrict__ mse_grad_loss)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
     __shared__ float4 s_q[64 * 3];
@@ -64,6 +70,8 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     float Tr[4], g0[4], g1[4], g2[4], gd[4], S[4];
     uint32_t last[4];
     uint32_t mx = 0;
+    // the coefficient of gsr_mse_backward, same expression: 2 weight / n * upstream gradient
+    const float mse_c = mse ? 2.0f * mse_weight / (float)((size_t)d.B * d.Vt * 3 * P) * (mse_grad_loss ? mse_grad_loss[0] : 1.f) : 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
@@ -71,9 +79,15 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         const size_t pix = (size_t)py * d.W + px;
         const float Tf = inside ? ws.final_T[v * P + pix] : 0.f;
         last[k] = inside ? ws.n_contrib[v * P + pix] : 0u;
-        g0[k] = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
-        g1[k] = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
-        g2[k] = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
+        g0[k] = (inside && dL_dimage) ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
+        g1[k] = (inside && dL_dimage) ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
+        g2[k] = (inside && dL_dimage) ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
+        if (mse && inside) {       // (mse: wave-uniform)
+            const float e0 = mse_c * ws.loss_diff[(v * 3 + 0) * P + pix], e1 = mse_c * ws.loss_diff[(v * 3 + 1) * P + pix],
+                        e2 = mse_c * ws.loss_diff[(v * 3 + 2) * P + pix];
+            if (dL_dimage) { g0[k] += e0; g1[k] += e1; g2[k] += e2; }
+            else { g0[k] = e0; g1[k] = e1; g2[k] = e2; }
+        }
         gd[k] = (DEPTH && inside) ? dL_ddepth[v * P + pix] : 0.f;
         S[k] = Tf * (vw.bg[0] * g0[k] + vw.bg[1] * g1[k] + vw.bg[2] * g2[k]);
         Tr[k] = Tf;
@@ -85,11 +99,7 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     const int max_last = __builtin_amdgcn_readfirstlane((int)mx);   // wave-uniform (all-lanes maximum): batch / entry counters and the loop controls stay scalar
     // DEPTH: ten sums, reduce10; depth-free: the nine live sums go through wave_reduce9 (GR_DEPTH's column of grad_rec keeps its zero)
-#ifdef GSR_K6_R10
-    constexpr bool NINE = false;
-#else
     constexpr bool NINE = !DEPTH;
-#endif
     int slot;                                   // the grad_rec column this lane publishes, -1: none
     if (NINE) { const int i9 = reduce9_slot(lane); slot = i9 < 0 ? -1 : (i9 < 3 ? i9 : i9 + 1); }      // v = s[0..2], s[4..9]
     else slot = reduce10_slot(lane);
@@ -105,9 +115,9 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
         asm volatile("" ::: "memory");
         uint32_t bm = 0;
         if (lane < cnt) {
-            bm = ws.block_mask[start + hi - 1 - lane];   // exact block masks of the forward, 8 bits per quadrant
-            const uint32_t quad = ((bm & 0xffu) ? 1u : 0u) | ((bm & 0xff00u) ? 2u : 0u) | ((bm & 0xff0000u) ? 4u : 0u) | ((bm >> 24) ? 8u : 0u);
-            stage_entry_bwd(recs, plist[hi - 1 - lane], quad, s_q + lane * 3);
+            const uint32_t word = plist[hi - 1 - lane];  // id | the forward's quadrant mask (entries it never staged or that miss the tile: 0)
+            bm = word >> GSR_QUAD_SHIFT;
+            stage_entry_bwd(recs, word & GSR_ID_MASK, bm, s_q + lane * 3);
         }
         // the slots whose footprint touches the tile at all, as a scalar bit mask: the entry loop visits only those (no per-entry LDS read
         // + readfirstlane + branch just to find out that there is nothing to evaluate, and the entry's record is read in one go)
@@ -196,250 +206,6 @@ __global__ void __launch_bounds__(64) k_composite_bwd(GsrDims d, const GsrView *
             }
         }
     }
-}
-
-// ------------------------------------------------------------------ K6, row-packed (round 5)
-// The tile kernel above evaluates one splat per wave instruction over an 8x8 quadrant: 25 % of the lanes pass alpha >= 1/255
-// (tests/analysis_block_items.py), and every splat pays a ten-value 64-lane reduction.  Here a wavefront owns ONE 8x8 quadrant
-// and runs as 64 / W independent rows of W lanes, one pixel per lane: W = 16 -> four 4x4 blocks, 8 -> eight 2x4 blocks,
-// 4 -> sixteen 2x2 blocks.  Each row walks only the list entries the forward composited into ITS block (the exact block masks
-// k_composite_fwd leaves behind), so one wave instruction evaluates 64 / W different (entry, block) items:
-//     block   items per (tile, entry) pair   valid lanes   steps per pair (unbounded window)
-//     4 x 4            2.87                     48 %              0.76
-//     2 x 4            4.61                     60 %              0.63
-//     2 x 2            7.34                     75 %              0.52          (tile kernel: 1.37 quadrant passes, 25 %)
-// The rows are systolic: lane s of a row evaluates the row's item i - s at step i, and the item's nine partial gradients
-// travel with it from lane to lane (DPP row shifts feeding the accumulating FMAs).  What leaves the row's last lane is the
-// item's total over the block's pixels: no butterfly reduction.  Pixels keep their own state (T, S) in registers: per pixel
-// the entries still arrive back to front, only skewed in time.
-// Records are gathered once per (quadrant, entry) into an LDS ring of three chunks of 32 compacted entries; a row pops items
-// from its bit mask of the chunk; a chunk slot is re-staged once every row's head and every lagging lane has left it.
-// Finished items are summed per ring slot in LDS (ds_add_f32 from the rows' last lanes) and leave the wave when their chunk
-// retires, 16 lanes per entry: ONE cache line per entry and atomic instruction -- the memory pipe executes an atomic
-// instruction line by line (9 four-lane atomics per step, or 9 instructions of 64 different Gaussians each, both measured at
-// 8 - 9 ms per launch), and the L2 retires about one dword atomic per channel and clock (2.87 x the tile kernel's atomics,
-// one per (block, entry), cost 0.5 ms): per (quadrant, entry) there are 1.37 x the tile kernel's.
-// LDS hand-offs inside the wave are ordered by its in-order LDS pipe (compiler barriers): a __syncthreads would drain the
-// gradient atomics (s_waitcnt vmcnt(0)) at every chunk.
-__device__ inline void lds_order() { asm volatile("" ::: "memory"); }     // same wave: LDS instructions execute in order
-
-template <int W> __device__ inline int dpp_prev_i(int old, int v);        // lane s <- lane s - 1 of its row; lane 0 keeps `old`
-template <> __device__ inline int dpp_prev_i<16>(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false); }  // row_shr:1
-template <> __device__ inline int dpp_prev_i<8>(int old, int v)  { return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xf, 0xf, false); }
-template <int W> __device__ inline float dpp_prev_f(float v) { return __builtin_bit_cast(float, dpp_prev_i<W>(0, __builtin_bit_cast(int, v))); }
-
-// the row bits of one list entry from its 8-bit quadrant mask (bit 2 by + BX: 2-row x 4-column blocks)
-template <int W> __device__ inline uint32_t row_bits(uint32_t fm);
-template <> __device__ inline uint32_t row_bits<8>(uint32_t fm) { return fm; }                 // row = 2 by + BX
-template <> __device__ inline uint32_t row_bits<16>(uint32_t fm)                               // row = 2 BY + BX: block rows 2 BY, 2 BY + 1
-{
-    const uint32_t t = fm | (fm >> 2);
-    return (t & 3u) | ((t >> 2) & 12u);
-}
-
-template <bool DEPTH, int W>
-__global__ void __launch_bounds__(64) k_composite_bwd_rows(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
-                                                          const float *__restrict__ dL_dimage,
-                                                          const float *__restrict__ dL_ddepth)
-{
-    if (ws.status[GSR_ST_OVERFLOW]) return;
-    constexpr int NR = 64 / W;                  // rows per wavefront
-    constexpr int CH = 32, NCH = 3, RING = CH * NCH;
-    __shared__ float4 s_rec[RING * 3];          // x, y, A, B | C, opacity, depth, id | r, g, b, list position
-    __shared__ float4 s_stash[64 * 3];          // finished items waiting for the next flush, in the gradient record's component order | id
-    __shared__ uint32_t s_bits[CH];
-    __shared__ uint32_t s_rowmask[NCH * NR];    // per resident chunk and row: which of the chunk's entries touch the row's block
-
-    const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
-    const uint32_t VT = (uint32_t)(d.B * d.Vt * T);
-    // 32 consecutive workgroups = 8 tiles x 4 quadrants, the quadrants of a tile 8 apart: they land on the same XCD
-    // (workgroup b -> XCD b % 8) and share the L2 that holds the tile's records
-    const uint32_t gb = blockIdx.x;
-    const uint32_t ti = (gb >> 5) * 8u + (gb & 7u), q = (gb >> 3) & 3u;
-    if (ti >= VT) return;
-    const uint32_t tv = ws.tile_order[ti];      // longest lists first
-    const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
-    const int lane = threadIdx.x, row = lane / W, s = lane % W;
-    int bx, by;                                 // the lane's pixel inside the quadrant
-    if (W == 16) { bx = (row & 1) * 4 + (s & 3); by = (row >> 1) * 4 + (s >> 2); }
-    else { bx = (row & 1) * 4 + (s & 3); by = (row >> 1) * 2 + (s >> 2); }
-    const int px = (tile % gx) * TILE + (int)(q & 1u) * 8 + bx;
-    const int py = (tile / gx) * TILE + (int)(q >> 1) * 8 + by;
-    const size_t P = (size_t)d.H * d.W;
-
-    const size_t t = (size_t)v * T + tile;
-    const uint32_t start = ws.tile_offset[t], end = ws.tile_offset[t + 1];
-    if (start == end) return;
-    const uint32_t *__restrict__ plist = ws.point_list + start;
-    const uint32_t *__restrict__ bmask = ws.block_mask + start;
-    const SplatRec *__restrict__ recs = ws.records + (size_t)v * d.G;
-    float *grad = ws.grad_rec + (size_t)v * d.G * GR_STRIDE;
-    const GsrView &vw = views[v];
-
-    const bool inside = px < d.W && py < d.H;
-    const size_t pix = (size_t)py * d.W + px;
-    float Tr = inside ? ws.final_T[v * P + pix] : 0.f;
-    const uint32_t last = inside ? ws.n_contrib[v * P + pix] : 0u;
-    const float g0 = inside ? dL_dimage[(v * 3 + 0) * P + pix] : 0.f;
-    const float g1 = inside ? dL_dimage[(v * 3 + 1) * P + pix] : 0.f;
-    const float g2 = inside ? dL_dimage[(v * 3 + 2) * P + pix] : 0.f;
-    const float gd = (DEPTH && inside) ? dL_ddepth[v * P + pix] : 0.f;
-    float S = Tr * (vw.bg[0] * g0 + vw.bg[1] * g1 + vw.bg[2] * g2);     // absolute suffix (see the tile kernel)
-    const float fpx = (float)px, fpy = (float)py;
-    uint32_t mx = last;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    if (mx == 0) return;
-    const float4 idle4 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-    if (lane < 3) s_rec[lane] = make_float4(0.f, 0.f, 0.f, 0.f);     // bubbles read slot 0 before anything is staged there: keep it finite
-    s_stash[lane * 3 + 2] = idle4;
-    lds_order();
-
-    int lp = __builtin_amdgcn_readfirstlane((int)mx);   // wave-uniform: list positions [0, lp) are not scanned yet (back to front)
-    int staged = 0, sslot = 0;   // wave-uniform: chunks staged so far; the ring slot (0 .. NCH-1) the next one goes to
-    int cc = -1, cslot = NCH - 1;// per row: the chunk its head is in, and that chunk's ring slot
-    uint32_t m = 0;              // per row: entries of chunk cc it still has to pop
-    int item = -1;               // per lane: ring slot of the entry evaluated in this step, -1 = bubble
-    constexpr int NA = DEPTH ? 10 : 9;
-    float acc[NA];
-#pragma unroll
-    for (int k = 0; k < NA; ++k) acc[k] = 0.f;
-    int drain = W - 1;
-
-    int step = 0;
-    constexpr int FLUSH = 64 / NR;   // steps between flushes: the stash holds 64 items, NR rows finish one each per step
-
-    // The memory pipe executes an atomic instruction one cache line at a time: what counts is the number of distinct lines per
-    // instruction, not the active lanes (9 NR-lane atomics per step, or 9 instructions of 64 different Gaussians each, both
-    // measured at 8 - 9 ms per launch), and LDS float atomics retire about one lane per two clocks per CU (summing the items per
-    // ring slot with ds_add_f32: 1.3 ms at W = 16, 1.7 at 8, 2.4 at 4).  So the rows park their finished items in an LDS stash
-    // with plain stores, in the gradient record's component order, and the wave flushes it 16 lanes per item: one line per
-    // item and atomic instruction, as the tile kernel does.
-    auto flush_stash = [&]() {
-        lds_order();
-        const float *sf = reinterpret_cast<const float *>(s_stash);
-        const int comp = lane & 15;
-        const bool comp_live = comp <= GR_OP && (DEPTH || comp != GR_DEPTH);
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int it = i * 4 + (lane >> 4);
-            const uint32_t id = __float_as_uint(sf[it * 12 + 11]);
-            const float val = sf[it * 12 + comp];
-#ifndef GSR_K6_NO_ATOMICS     /* experiment builds only (tools/exp_k6.sh): the kernel without its global atomics */
-            if (comp_live && id != 0xffffffffu) atomicAdd(grad + (size_t)id * GR_STRIDE + comp, val);
-#else
-            if (comp_live && id == 0xfffffffeu) atomicAdd(grad + comp, val);
-#endif
-        }
-        lds_order();
-        s_stash[lane * 3 + 2] = idle4;
-        lds_order();
-    };
-
-    for (;;) {
-        // ---- stage the next chunk as soon as its ring slot is free ----
-        if (lp > 0) {
-            bool free_slot = staged < NCH;
-            if (!free_slot) free_slot = __ballot(cc <= staged - NCH || (item >= 0 && item / CH == sslot)) == 0ull;
-            if (free_slot) {
-                const int cbase = sslot * CH;
-                int fill = 0;
-                while (fill < CH && lp > 0) {
-                    const int p = lp - 1 - lane;
-                    const uint32_t fm = p >= 0 ? ((bmask[p] >> (8u * q)) & 255u) : 0u;
-                    const unsigned long long rel = __ballot(fm != 0u);
-                    const int nrel = __popcll(rel), room = CH - fill;
-                    const int rank = (int)__popcll(rel & ((1ull << lane) - 1ull));
-                    const bool take = fm != 0u && rank < room;
-                    if (take) {
-                        const uint32_t id = plist[p];
-                        const float4 *rr = reinterpret_cast<const float4 *>(recs + id);
-                        const float4 q0 = rr[0], q1 = rr[1], q2 = rr[2];
-                        float4 *dst = s_rec + (cbase + fill + rank) * 3;
-                        dst[0] = make_float4(q0.x, q0.y, q1.x * CONIC_PRESCALE, q1.y * CONIC_PRESCALE);      // as stage_entry_bwd
-                        dst[1] = make_float4(q1.z * CONIC_PRESCALE, q1.w, q0.z, __uint_as_float(id));
-                        dst[2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float((uint32_t)p));
-                        s_bits[fill + rank] = row_bits<W>(fm);
-                    }
-                    if (nrel <= room) { fill += nrel; lp = max(lp - 64, 0); }
-                    else {   // the lane that took the last free slot: scanning resumes right below its position
-                        const unsigned long long lastm = __ballot(take && rank == room - 1);
-                        lp = __builtin_amdgcn_readfirstlane(lp - 1 - (__ffsll((long long)lastm) - 1));
-                        fill = CH;
-                    }
-                }
-                lds_order();
-                const uint32_t bb = (lane < fill) ? s_bits[lane] : 0u;
-                uint32_t mymask = 0u;
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    const uint32_t mk = (uint32_t)__ballot((bb >> k) & 1u);
-                    if (lane == k) mymask = mk;
-                }
-                if (lane < NR) s_rowmask[sslot * NR + lane] = mymask;
-                lds_order();
-                ++staged; sslot = sslot + 1 == NCH ? 0 : sslot + 1;
-            }
-        }
-        // ---- every row pops its next item (all lanes of a row compute the same head) ----
-        if (m == 0u && cc + 1 < staged) { ++cc; cslot = cslot + 1 == NCH ? 0 : cslot + 1; m = s_rowmask[cslot * NR + row]; }
-        int head = -1;
-        if (m != 0u) { head = cslot * CH + (__ffs((int)m) - 1); m &= m - 1u; }
-        item = dpp_prev_i<W>(head, item);
-        if (W != 16 && s == 0) item = head;      // (a 16-lane row is a DPP row: its lane 0 kept `head` in the shift itself)
-
-        // ---- evaluate the lane's (entry, pixel) pair; bubbles run with alpha = 0 and add exactly 0 ----
-        const int slot = max(item, 0);
-        const float4 a = s_rec[slot * 3 + 0];                // x, y, A, B
-        const float4 b = s_rec[slot * 3 + 1];                // C, opacity, depth, id
-        const float4 c = s_rec[slot * 3 + 2];                // r, g, b, list position
-        const float dx = a.x - fpx, dy = a.y - fpy;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float Graw = footprint_exp(fminf(power, 0.f));
-        const float araw = fminf(0.99f, b.y * Graw);
-        const bool valid = (item >= 0) && (__float_as_uint(c.w) < last) && (power <= 0.f) && (araw >= (1.f / 255.f));
-        const float alpha = valid ? araw : 0.f;
-        const float Gv = valid ? Graw : 0.f;
-        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-        Tr *= inv;
-        const float w = alpha * Tr;
-        float u = c.x * g0 + c.y * g1 + c.z * g2;
-        if (DEPTH) u += b.z * gd;
-        const float dL_dalpha = Tr * u - S * inv;
-        S += w * u;
-        const float tt = Gv * dL_dalpha;
-        const float hx = tt * dx, hy = tt * dy;      // (x -opacity / 2 in K7)
-        // the sums travel with the item: shifted in from the left neighbour (0 into the row's first lane), plus this pixel's share
-        const float first = (W == 16 || s != 0) ? 1.f : 0.f;     // rows narrower than a DPP row: their lane 0 must not inherit
-        auto carry = [&](float vprev, float add) { return W == 16 ? dpp_prev_f<W>(vprev) + add : dpp_prev_f<W>(vprev) * first + add; };
-        acc[0] = carry(acc[0], w * g0);      // accumulator order: rgb, opacity, mx, my, ca, cb, cc, (depth)
-        acc[1] = carry(acc[1], w * g1);
-        acc[2] = carry(acc[2], w * g2);
-        acc[3] = carry(acc[3], tt);
-        acc[4] = carry(acc[4], hx);
-        acc[5] = carry(acc[5], hy);
-        acc[6] = carry(acc[6], hx * dx);
-        acc[7] = carry(acc[7], hx * dy);
-        acc[8] = carry(acc[8], hy * dy);
-        if (DEPTH) acc[NA - 1] = carry(acc[NA - 1], w * gd);
-
-        // ---- the item leaving the row's last lane carries its block's totals ----
-#ifndef GSR_K6_NO_EXIT
-        if (s == W - 1) {
-            float4 *st = s_stash + ((step & (FLUSH - 1)) * NR + row) * 3;
-            st[0] = make_float4(acc[0], acc[1], acc[2], DEPTH ? acc[NA - 1] : 0.f);       // GR_RGB .. GR_DEPTH
-            st[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);                          // GR_MX, GR_MY, GR_CA, GR_CB
-            st[2] = make_float4(acc[8], acc[3], 0.f, item >= 0 ? b.w : __uint_as_float(0xffffffffu));   // GR_CC, GR_OP, -, id
-        }
-        if ((++step & (FLUSH - 1)) == 0) flush_stash();
-#endif
-
-        // ---- done when nothing is left to pop and the pipeline has drained ----
-        if (lp == 0 && __ballot(m != 0u || cc + 1 < staged) == 0ull) {
-            if (drain-- == 0) break;
-        }
-    }
-    flush_stash();
 }
 
 // ------------------------------------------------------------------ K7
@@ -705,13 +471,14 @@ Ptrs carve(void *base, const GsrLayout &L);
 int backward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *shs,
              long long cap, void *workspace, size_t workspace_bytes, const float *dL_dimage, const float *dL_ddepth,
              float *dL_dmeans, float *dL_dcov6, float *dL_dopac, float *dL_dshs, float *dL_dmeans2D, float *dL_dtau,
-             hipStream_t stream)
+             const GsrFused *fx, hipStream_t stream)
 {
     GsrLayout L;
     int rc = layout(d, cap, L);
     if (rc != GSR_OK) return rc;
-    if (!views || !means || !cov6 || !shs || !workspace || !dL_dimage || !dL_dmeans || !dL_dcov6 || !dL_dopac || !dL_dshs)
-        return GSR_EINVAL;
+    const float *mse_target = fx ? fx->mse_target : nullptr;
+    if (!views || !means || !cov6 || !shs || !workspace || !dL_dmeans || !dL_dcov6 || !dL_dopac || !dL_dshs) return GSR_EINVAL;
+    if (!dL_dimage && !mse_target) return GSR_EINVAL;        // some gradient of the image has to come from somewhere
     if (workspace_bytes < L.total) return GSR_ENOSPACE;
     Ptrs ws = carve(workspace, L);
     const int V = d.B * d.Vt, T = tiles_x(d.W) * tiles_y(d.H);
@@ -722,19 +489,12 @@ int backward(const GsrDims &d, const GsrView *views, const float *means, const f
         !hip_ok(hipMemsetAsync(ws.grad_rec, 0, (size_t)V * d.G * GR_STRIDE * 4, stream))) return GSR_ELAUNCH;
     if (dL_dtau && !hip_ok(hipMemsetAsync(dL_dtau, 0, (size_t)V * 6 * 4, stream))) return GSR_ELAUNCH;
     tm.begin(GSR_STAGE_COMPOSITE_BWD);
-    // GSR_K6=rows16 / rows8 select the round-5 row-packed kernels for A/B runs (the forward must have run under the same setting)
-    const char *k6_env = getenv("GSR_K6");       // read per call: the parity tests run both kernels in one process
-    const bool k6_tile = !(k6_env && !strncmp(k6_env, "rows", 4));   // default: the tile kernel
-    if (k6_tile) {
-        if (dL_ddepth) hipLaunchKernelGGL(k_composite_bwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
-        else hipLaunchKernelGGL(k_composite_bwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth);
-    } else {
-        const unsigned nb = (unsigned)(((size_t)V * T + 7) / 8 * 32);
-        const int w = (k6_env && !strcmp(k6_env, "rows16")) ? 16 : 8;
-#define GSR_LAUNCH_K6R(DEP, WW) hipLaunchKernelGGL((k_composite_bwd_rows<DEP, WW>), dim3(nb), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth)
-        if (dL_ddepth) { if (w == 16) GSR_LAUNCH_K6R(true, 16); else GSR_LAUNCH_K6R(true, 8); }
-        else { if (w == 16) GSR_LAUNCH_K6R(false, 16); else GSR_LAUNCH_K6R(false, 8); }
-#undef GSR_LAUNCH_K6R
+    {
+        const float *mg = fx ? fx->mse_grad_loss : nullptr;
+        const float mw = fx ? fx->mse_weight : 0.f;
+        const bool mse = mse_target != nullptr;
+        if (dL_ddepth) hipLaunchKernelGGL(k_composite_bwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth, mse, mw, mg);
+        else hipLaunchKernelGGL(k_composite_bwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, dL_dimage, dL_ddepth, mse, mw, mg);
     }
     tm.end(GSR_STAGE_COMPOSITE_BWD); tm.begin(GSR_STAGE_PREPROCESS_BWD);
     const dim3 gG((d.G + 255) / 256, d.B);

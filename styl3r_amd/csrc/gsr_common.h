@@ -40,8 +40,10 @@ struct Ptrs {             // carved workspace
     SplatRec *records;
     uint32_t *tile_count, *tile_offset, *tile_cursor, *tile_order;
     unsigned long long *pairs, *pairs_alt;
-    uint32_t *point_list;
-    uint32_t *block_mask;
+    uint32_t *point_list;   // ids | quadrant mask << GSR_QUAD_SHIFT (the mask bits are the composite forward's)
+    float *loss_partial;    // fused MSE: [V*T] tile partials, [V] view partials
+    uint32_t *loss_ticket;  // fused MSE: [V] tiles arrived per view, [1] views arrived
+    float *loss_diff;       // fused MSE: image - target, (V,3,H,W)
     float *final_T;
     uint32_t *n_contrib;
     float *grad_rec;
@@ -292,18 +294,13 @@ __device__ inline uint32_t quadrant_mask(const float4 q0, const float4 q1, uint3
 // The composite kernels evaluate G = exp(power) as ONE v_exp_f32 (= 2^x): the conic is multiplied by log2(e) once per staged entry, so that
 // `power` comes out in base-2 units.  Both kernels stage through the functions below and evaluate the same expression, so the forward's and
 // the backward's alpha agree bit for bit (the backward re-derives which pixels a splat was composited into from it).
-// -DGSR_EXP_E: the round-2..4 form, exp(power) = v_mul(log2 e) + v_exp_f32 on the unscaled conic (A/B).
-#ifdef GSR_EXP_E
-#define CONIC_PRESCALE 1.0f
-__device__ inline float footprint_exp(float power) { return __expf(power); }
-#else
+// (the round-2..4 form, exp(power) = v_mul(log2 e) + v_exp_f32 on the unscaled conic, was the A/B of round 5: profiles/r05_k6_cleanup_ab.md)
 #define CONIC_PRESCALE 1.4426950408889634f
 __device__ inline float footprint_exp(float power) { return __builtin_amdgcn_exp2f(power); }
-#endif
 // One list entry of a composite batch: gather the splat record of Gaussian `id` (three dwordx4 loads) and park it as a
 // QueueRec in the three float4 LDS slots at `dst`.  The forward also marks the quadrants of the tile at (ox, oy) the
-// footprint can touch and leaves that mask in `quad_out` (one byte per list entry); the backward reads it back instead of
-// recomputing it (the mask code is ~150 instructions and 15 registers the backward's 8-waves-per-SIMD budget does not have).
+// footprint can touch; the kernel leaves that mask in the top four bits of the entry's point_list word and the backward reads it back
+// instead of recomputing it (the mask code is ~150 instructions and 15 registers the backward's 8-waves-per-SIMD budget does not have).
 __device__ inline uint32_t stage_entry_fwd(const SplatRec *__restrict__ recs, uint32_t id, int ox, int oy, float4 *dst)
 {
     const float4 *r = reinterpret_cast<const float4 *>(recs + id);

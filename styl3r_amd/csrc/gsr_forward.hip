@@ -2,10 +2,13 @@
 //
 //   K1 preprocess      per Gaussian, loops over the scene's views: cull, cov3D->2D, conic,
 //                      radius, tile rect, SH colour; writes one 48-B SplatRec per (view,
-//                      Gaussian) and bumps the per-tile counters.            (upstream R1)
-//   K2 scan_tiles      exclusive scan of the V*T tile counters (one workgroup).   (R2)
+//                      Gaussian) and counts the per-tile list lengths through a per-workgroup
+//                      LDS histogram (one global atomic per non-empty (workgroup, tile)). (upstream R1)
+//   K2 scan_tiles      exclusive scan of the V*T tile counters (one workgroup), the status
+//                      words (pair count, overflow, longest list), the longest-list-first
+//                      launch order of K4 - K6; re-arms persistent counters.             (R2)
 //   K3 scatter         every (view, Gaussian, tile) pair -> its tile bucket as
-//                      (depth_bits<<32 | id).                                     (R3)
+//                      (depth_bits<<32 | id), slots handed out from LDS.                 (R3)
 //   K4 tile_sort       per-tile depth sort in LDS: one MSD radix pass over the 8 most
 //                      significant VARYING depth bits of the tile (LDS-atomic histogram,
 //                      scan, scatter), then an exact rank inside each bucket on the full
@@ -14,10 +17,15 @@
 //   K5 composite_fwd   ONE WAVEFRONT per 16x16 tile, 4 pixels per lane (one per quadrant):
 //                      walks the sorted list 64 entries at a time -- each lane gathers one
 //                      entry's 48-B splat record, computes the 4-bit mask of the 8x8
-//                      quadrants its alpha>=1/255 footprint can reach, and parks both in a
-//                      wave-private LDS slot; the wave then reads the entries back as LDS
-//                      broadcasts, skips quadrants by scalar branch, and exits as soon as
-//                      its 256 pixels are saturated.  No workgroup barriers.         (R6)
+//                      quadrants its alpha>=1/255 footprint can reach (left in the top bits
+//                      of the entry's point_list word for the backward), and parks the
+//                      record in a wave-private LDS slot; the wave then reads the entries
+//                      back as LDS broadcasts and evaluates them as STRAIGHT-LINE code: the
+//                      four conditions of upstream's loop body are ballots combined in
+//                      SGPRs, the selects read those scalar lane masks, quadrants are
+//                      skipped by scalar branches on the mask; it exits as soon as its 256
+//                      pixels are saturated.  Optional epilogue: the tile's share of
+//                      LossMse, reduced in fixed order by last-arriver tickets.          (R6)
 //
 // The upstream design sorts all pairs of one view globally on 64-bit keys (6-8 radix
 // passes over HBM, ~120 B/pair) and reads R back to the host.  Here the tile id never
@@ -172,7 +180,9 @@ __global__ void __launch_bounds__(256) k_preprocess(GsrDims d, const GsrView *__
 // of the thread totals -- 6 barriers instead of 3 per 1 024 counters.
 constexpr int SCAN_PER_MAX = 16;
 
-__global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, Ptrs ws, int32_t *__restrict__ status)
+// `rearm`: the counters are the caller's persistent ones (GsrFused.tile_count): leave them zero for the next forward.
+// `nticket`: fused-MSE arrival counters of this workspace to zero (0 = none).
+__global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, Ptrs ws, int32_t *__restrict__ status, int rearm, int nticket)
 {
     __shared__ unsigned long long s_wave[16];
     __shared__ unsigned long long s_carry;
@@ -186,6 +196,8 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
     uint32_t c[SCAN_PER_MAX];
     if (fast) {
         for (int i = tid; i < per * 1024; i += 1024) s_cnt[i] = (i < n) ? ws.tile_count[i] : 0u;
+        if (rearm) for (int i = tid; i < n; i += 1024) ws.tile_count[i] = 0u;       // (read above by the same thread)
+        for (int i = tid; i < nticket; i += 1024) ws.loss_ticket[i] = 0u;
         __syncthreads();
         unsigned long long tot = 0;
 #pragma unroll
@@ -216,6 +228,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
         }
     } else {
         if (tid == 0) s_carry = 0;
+        for (int i = tid; i < nticket; i += 1024) ws.loss_ticket[i] = 0u;
         __syncthreads();
         for (int base = 0; base < n; base += 1024) {
             int i = base + tid;
@@ -294,6 +307,7 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(int n, long long capacity, 
         for (int i = tid; i < n; i += 1024) {
             const uint32_t pos = atomicAdd(&s_bin[255u - min(ws.tile_count[i] >> sh, 255u)], 1u);
             ws.tile_order[pos] = (uint32_t)i;
+            if (rearm) ws.tile_count[i] = 0u;      // its last read
         }
     }
 }
@@ -639,28 +653,38 @@ __global__ void __launch_bounds__(256) k_tile_sort(GsrDims d, Ptrs ws, uint32_t 
 // ------------------------------------------------------------------ K5
 // One wavefront per tile.  Lane l owns pixel (l&7, l>>3) of each 8x8 quadrant k = 0..3
 // (TL, TR, BL, BR), so a splat whose footprint misses a quadrant costs that quadrant nothing
-// (wave-uniform scalar branch on the queue's quadrant mask).
-// BLOCKS: also leave the exact per-entry block masks the row-packed backward (GSR_K6=rows16 / rows8) walks; otherwise the
-// geometric quadrant bits are expanded to the same format (a quadrant's byte = 0xff) for the tile backward.
-template <bool NTOUCH, bool BLOCKS>
+// (wave-uniform scalar branch on the entry's quadrant mask).
+//
+// Fused LossMse (mse_target != nullptr; src/loss/loss_mse.py:22-31): the tile's sum of (image - target)^2 is formed from the registers
+// that hold the finished pixels, published with a device-scope atomic, and the LAST tile of a view to arrive (ticket) adds the view's
+// T partials in index order; the last view adds the V view sums the same way and writes weight * total / n.  Fixed summation order =>
+// bitwise deterministic, no extra launch and no second pass over the image.  Publishing and reading go through returning agent-scope
+// atomics (performed at the coherence point of the eight per-XCD L2s) and an exact `s_waitcnt vmcnt(0)` in front of the ticket: the
+// release fence of the stand-alone kernel (an L2 write-back per workgroup) would be paid 10 240 times here.
+__device__ inline void agent_publish(float *p, float v)      // returning integer swap: vmcnt counts it, the value is at the coherence point when it is back
+{
+    (void)__hip_atomic_exchange(reinterpret_cast<uint32_t *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline float agent_read(float *p)
+{
+    return __uint_as_float(__hip_atomic_fetch_or(reinterpret_cast<uint32_t *>(p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <bool NTOUCH>
 __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *__restrict__ views, Ptrs ws,
                                                      float *__restrict__ image, float *__restrict__ out_depth,
-                                                     float *__restrict__ out_opacity, int32_t *__restrict__ n_touched)
+                                                     float *__restrict__ out_opacity, int32_t *__restrict__ n_touched,
+                                                     const float *__restrict__ mse_target, float mse_weight,
+                                                     float *__restrict__ mse_loss)
 {
     if (ws.status[GSR_ST_OVERFLOW]) return;
     __shared__ float4 s_q[64 * 3];
-    __shared__ uint4 s_hit[64 * 2];     // per entry of the batch 32 flag bytes: byte 8 q + 2 by + BX = the 2-row x 4-column pixel block (BX, by) of
-                                        // quadrant q composited it
 
     const int gx = tiles_x(d.W), T = gx * tiles_y(d.H);
     const uint32_t tv = ws.tile_order[blockIdx.y * gridDim.x + blockIdx.x];   // longest lists are launched first
     const int tile = (int)(tv % (uint32_t)T), v = (int)(tv / (uint32_t)T);
     const int lane = threadIdx.x;
     const int ox = (tile % gx) * TILE + (lane & 7), oy = (tile / gx) * TILE + (lane >> 3);
-    // lane l = (x, y) = (l & 7, l >> 3) of every quadrant: its pixels lie in block r = (y >= 4) * 2 + (x >= 4)
-    // lane l = (x, y) = (l & 7, l >> 3) of every quadrant: its pixels lie in block by = y >> 1, BX = x >> 2
-    uint8_t *hit_lane = reinterpret_cast<uint8_t *>(s_hit) + (((lane >> 4) << 1) | ((lane >> 2) & 1));
-    if (BLOCKS) { s_hit[lane * 2] = make_uint4(0u, 0u, 0u, 0u); s_hit[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u); }
 
     if (d.flags & GSR_FLAG_PREZERO_GRADS) {
         // side job: this wavefront's slice of the backward's gradient accumulators (stores only; the kernel's own work is
@@ -675,25 +699,20 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
     const size_t t = (size_t)v * T + tile;
     const uint32_t start = ws.tile_offset[t];
     const int n = (int)(ws.tile_offset[t + 1] - start);
-    const uint32_t *__restrict__ plist = ws.point_list + start;
+    uint32_t *__restrict__ plist = ws.point_list + start;
     const SplatRec *__restrict__ recs = ws.records + (size_t)v * d.G;
     const int tile_ox = (tile % gx) * TILE, tile_oy = (tile / gx) * TILE;
 
-    // (pixel coordinates from the lane's base + a per-quadrant constant, as in the backward, were measured here: the two extra
-    //  subtractions per evaluation cost 4 % and the 2 registers they free do not reach the next occupancy step)
-    float fx0 = (float)ox, fy0 = (float)oy;   // pixel = lane base + the quadrant's constant offset (round 5: the six registers this frees
-                                                     // are the sixth wave per SIMD now that the block flags took two)
+    // (pixel coordinates from the lane's base + a per-quadrant constant, as in the backward: the registers this frees are a wave per SIMD)
+    float fx0 = (float)ox, fy0 = (float)oy;
     asm volatile("" : "+v"(fx0), "+v"(fy0));     // (kept in registers: the compiler re-converted ox per list entry)
     float Tr[4], C0[4], C1[4], C2[4], D[4], O[4];
     uint32_t last[4];
     bool inside[4];
     // finished pixels (outside the image, or T fell below 1e-4) as SCALAR lane masks, one per quadrant: the evaluation below is straight-line
     // code whose selects read scalar masks (round 5; the round-1..4 form nested four exec-mask branches per evaluation -- done, power > 0,
-    // alpha < 1/255, T < 1e-4 -- and kept `done` as a register that every evaluation tested with two VALU instructions; -DGSR_K5_BRANCHY)
+    // alpha < 1/255, T < 1e-4 -- and kept `done` as a register that every evaluation tested with two VALU instructions)
     unsigned long long dmask[4];
-#ifdef GSR_K5_BRANCHY
-    bool done[4];
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int px = ox + (k & 1) * 8, py = oy + (k >> 1) * 8;
@@ -701,19 +720,17 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
         Tr[k] = 1.f; C0[k] = C1[k] = C2[k] = D[k] = O[k] = 0.f;
         last[k] = 0;
         dmask[k] = __builtin_amdgcn_ballot_w64(!inside[k]);
-#ifdef GSR_K5_BRANCHY
-        done[k] = !inside[k];
-#endif
     }
 
     for (int base = 0; base < n; base += 64) {
         const int cnt = __builtin_amdgcn_readfirstlane(min(64, n - base));     // (scalar loop control)
         __syncthreads();  // single-wave workgroup: orders this wave's LDS reads of the previous batch
         uint32_t qm = 0;
-        if (lane < cnt) {  // one list entry per lane; the geometric quadrant mask steers this kernel's own scalar skips
-            qm = stage_entry_fwd(recs, plist[base + lane], tile_ox, tile_oy, s_q + lane * 3);
-            if (!BLOCKS) ws.block_mask[start + base + lane] = ((qm & 1u) ? 0xffu : 0u) | ((qm & 2u) ? 0xff00u : 0u) |
-                                                              ((qm & 4u) ? 0xff0000u : 0u) | ((qm & 8u) ? 0xff000000u : 0u);
+        if (lane < cnt) {  // one list entry per lane; the geometric quadrant mask steers this kernel's own scalar skips and, through the top bits
+                           // of the entry's list word, the backward's (entries the footprint cannot reach keep their zero bits: nothing is written)
+            const uint32_t id = plist[base + lane] & GSR_ID_MASK;
+            qm = stage_entry_fwd(recs, id, tile_ox, tile_oy, s_q + lane * 3);
+            if (qm) plist[base + lane] = id | (qm << GSR_QUAD_SHIFT);
         }
         __syncthreads();
 
@@ -721,18 +738,12 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
         // (measured and dropped: handing the backward the quadrants that really composited something -- four scalar masks per batch -- instead of
         //  the geometric ones: K6 0.768 -> 0.761 ms, this kernel 0.394 -> 0.418: the ellipse-vs-rectangle test is already that tight)
         // (reading entry j + 1 ahead of entry j's evaluation was measured: +7 VGPRs, 8 -> 7 waves per SIMD, -6 %)
-#ifndef GSR_K5_BRANCHY
         for (unsigned long long todo = __builtin_amdgcn_ballot_w64(qm != 0u); todo; todo &= todo - 1ull) {
             const int j = __builtin_ctzll(todo);
-#else
-        for (int j = 0; j < cnt; ++j) {
-#endif
             const float4 a = s_q[j * 3 + 0];
             const float4 b = s_q[j * 3 + 1];
             const float4 c = s_q[j * 3 + 2];
             const uint32_t quad = __builtin_amdgcn_readfirstlane(__float_as_uint(c.w));
-            uint8_t *hit_j = hit_lane + j * 32;   // this entry's 32 block flags, at the lane's block of each quadrant
-#ifndef GSR_K5_BRANCHY
             uint32_t touched_tot = 0;             // scalar: pixels of this tile whose T stays above 1/2 behind the splat
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -757,74 +768,62 @@ __global__ void __launch_bounds__(64) k_composite_fwd(GsrDims d, const GsrView *
                 if (NTOUCH) touched_tot += (uint32_t)__popcll(comp & __builtin_amdgcn_ballot_w64(test_T > 0.5f));
                 Tr[k] = sel_f(comp, test_T, Tr[k]);
                 last[k] = sel_u(comp, (uint32_t)(base + j + 1), last[k]);
-                // the backward's rows walk exactly the (entry, pixel block) items that composited something: one LDS byte store
-                // under the exec mask of the lanes that did (same value from every lane of a block: stores to one address
-                // merge; an LDS atomic OR of 64 lanes on one word serialises -- measured: this kernel 0.50 -> 1.90 ms)
-                if (BLOCKS) { if (sel_u(comp, 1u, 0u)) hit_j[8 * k] = 1; }
             }
             if (NTOUCH) {   // one atomic per (tile, splat)
                 if (touched_tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)touched_tot);
             }
-#else
-            uint32_t touched = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!(quad & (1u << k))) continue;  // scalar branch
-                if (done[k]) continue;
-                const float dx = (a.x - fx0) - (float)((k & 1) * 8), dy = (a.y - fy0) - (float)((k >> 1) * 8);
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                if (power > 0.f) continue;
-                const float alpha = fminf(0.99f, b.y * footprint_exp(power));
-                if (alpha < (1.f / 255.f)) continue;
-                const float test_T = Tr[k] * (1.f - alpha);
-                if (test_T < 0.0001f) { done[k] = true; continue; }
-                const float w = alpha * Tr[k];
-                C0[k] += c.x * w; C1[k] += c.y * w; C2[k] += c.z * w;
-                D[k] += b.z * w;
-                O[k] += w;
-                if (NTOUCH) touched += (test_T > 0.5f) ? 1u : 0u;
-                Tr[k] = test_T;
-                last[k] = (uint32_t)(base + j + 1);
-                if (BLOCKS) hit_j[8 * k] = 1;
-            }
-            if (NTOUCH) {
-                // wave total of `touched` (0..4 per lane): three ballots, one atomic per (tile, splat)
-                const uint32_t tot = (uint32_t)__popcll(__ballot(touched & 1u)) + 2u * (uint32_t)__popcll(__ballot(touched & 2u)) +
-                                     4u * (uint32_t)__popcll(__ballot(touched & 4u));
-                if (tot && lane == 0) atomicAdd(n_touched + (size_t)v * d.G + (__float_as_uint(b.w)), (int)tot);
-            }
-#endif
         }
-        if (BLOCKS) {   // lane j: entry base + j's 32 flags -> 32-bit mask (bit 8 q + 2 by + BX), flags re-armed for the next batch
-            __syncthreads();
-            const uint4 f0 = s_hit[lane * 2], f1 = s_hit[lane * 2 + 1];
-            s_hit[lane * 2] = make_uint4(0u, 0u, 0u, 0u); s_hit[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);
-            auto nib = [](uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); };
-            if (lane < cnt)
-                ws.block_mask[start + base + lane] = nib(f0.x) | (nib(f0.y) << 4) | (nib(f0.z) << 8) | (nib(f0.w) << 12) |
-                                                      (nib(f1.x) << 16) | (nib(f1.y) << 20) | (nib(f1.z) << 24) | (nib(f1.w) << 28);
-        }
-#ifndef GSR_K5_BRANCHY
         if ((dmask[0] & dmask[1] & dmask[2] & dmask[3]) == ~0ull) break;
-#else
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
-#endif
     }
 
     const size_t P = (size_t)d.H * d.W;
     const GsrView &vw = views[v];
+    float sq = 0.f;             // fused MSE: this lane's sum of squared errors
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!inside[k]) continue;
         const size_t pix = (size_t)(oy + (k >> 1) * 8) * d.W + (ox + (k & 1) * 8);
         ws.final_T[v * P + pix] = Tr[k];
         ws.n_contrib[v * P + pix] = last[k];
-        image[(v * 3 + 0) * P + pix] = C0[k] + Tr[k] * vw.bg[0];
-        image[(v * 3 + 1) * P + pix] = C1[k] + Tr[k] * vw.bg[1];
-        image[(v * 3 + 2) * P + pix] = C2[k] + Tr[k] * vw.bg[2];
+        const float r0 = C0[k] + Tr[k] * vw.bg[0], r1 = C1[k] + Tr[k] * vw.bg[1], r2 = C2[k] + Tr[k] * vw.bg[2];
+        image[(v * 3 + 0) * P + pix] = r0;
+        image[(v * 3 + 1) * P + pix] = r1;
+        image[(v * 3 + 2) * P + pix] = r2;
         out_depth[v * P + pix] = D[k];
         out_opacity[v * P + pix] = O[k];
+        if (mse_target) {       // (wave-uniform)
+            const float e0 = r0 - mse_target[(v * 3 + 0) * P + pix], e1 = r1 - mse_target[(v * 3 + 1) * P + pix],
+                        e2 = r2 - mse_target[(v * 3 + 2) * P + pix];
+            sq += (e0 * e0 + e1 * e1) + e2 * e2;
+            ws.loss_diff[(v * 3 + 0) * P + pix] = e0; ws.loss_diff[(v * 3 + 1) * P + pix] = e1; ws.loss_diff[(v * 3 + 2) * P + pix] = e2;
+        }
     }
+    if (!mse_target) return;
+    const int V = d.B * d.Vt;
+    sq = wave_sum_to_lane63(sq);
+    uint32_t arrived = 0;
+    if (lane == 63) {
+        agent_publish(ws.loss_partial + t, sq);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the partial is at the coherence point before the ticket moves
+        arrived = __hip_atomic_fetch_add(ws.loss_ticket + v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    arrived = (uint32_t)__builtin_amdgcn_readlane((int)arrived, 63);
+    if (arrived != (uint32_t)T - 1u) return;
+    float s1 = 0.f;                                             // last tile of view v: the view's partials, lane-strided then one fixed tree
+    for (int i = lane; i < T; i += 64) s1 += agent_read(ws.loss_partial + (size_t)v * T + i);
+    s1 = wave_sum_to_lane63(s1);
+    arrived = 0;
+    if (lane == 63) {
+        agent_publish(ws.loss_partial + (size_t)V * T + v, s1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        arrived = __hip_atomic_fetch_add(ws.loss_ticket + V, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    arrived = (uint32_t)__builtin_amdgcn_readlane((int)arrived, 63);
+    if (arrived != (uint32_t)V - 1u) return;
+    float s2 = 0.f;                                             // last view: the V view sums
+    for (int i = lane; i < V; i += 64) s2 += agent_read(ws.loss_partial + (size_t)V * T + i);
+    s2 = wave_sum_to_lane63(s2);
+    if (lane == 63) mse_loss[0] = mse_weight * (s2 / (float)((size_t)V * 3 * P));
 }
 
 // ------------------------------------------------------------------ host
@@ -837,7 +836,9 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     if (d.M > 0 && (d.sh_degree + 1) * (d.sh_degree + 1) > d.M) return GSR_EINVAL;
     if (d.M == 0 && d.sh_degree != 0) return GSR_EINVAL;
     if (cap > 0xffffffffll) return GSR_EINVAL;
-    if ((long long)d.G * (long long)sizeof(SplatRec) > 0xffffffffll) return GSR_EINVAL;   // 32-bit byte offsets into one view's records / gradient records (G < 89 M)
+    // 32-bit byte offsets into one view's records / gradient records: G < 89 M < 2^27, so a point_list word has room for the 4 mask bits
+    if ((long long)d.G * (long long)sizeof(SplatRec) > 0xffffffffll) return GSR_EINVAL;
+    static_assert((0xffffffffull / sizeof(SplatRec)) < GSR_ID_MASK, "ids must leave the quadrant-mask bits of a point_list word free");
     const size_t V = (size_t)d.B * d.Vt, T = (size_t)tiles_x(d.W) * tiles_y(d.H), P = (size_t)d.H * d.W;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -853,7 +854,9 @@ int layout(const GsrDims &d, long long cap, GsrLayout &L)
     L.status = take(GSR_STATUS_WORDS * 4);
     L.tile_order = take(V * T * 4);
     L.pairs_alt = take((size_t)cap * 8);
-    L.block_mask = take((size_t)cap * 4);
+    L.loss_partial = take((V * T + V) * 4);
+    L.loss_ticket = take((V + 1) * 4);
+    L.loss_diff = take(V * 3 * P * 4);
     L.total = off;
     return GSR_OK;
 }
@@ -874,13 +877,15 @@ Ptrs carve(void *base, const GsrLayout &L)
     w.status = reinterpret_cast<int32_t *>(p + L.status);
     w.tile_order = reinterpret_cast<uint32_t *>(p + L.tile_order);
     w.pairs_alt = reinterpret_cast<unsigned long long *>(p + L.pairs_alt);
-    w.block_mask = reinterpret_cast<uint32_t *>(p + L.block_mask);
+    w.loss_partial = reinterpret_cast<float *>(p + L.loss_partial);
+    w.loss_ticket = reinterpret_cast<uint32_t *>(p + L.loss_ticket);
+    w.loss_diff = reinterpret_cast<float *>(p + L.loss_diff);
     return w;
 }
 
 int forward(const GsrDims &d, const GsrView *views, const float *means, const float *cov6, const float *opac,
             const float *shs, long long cap, void *workspace, size_t workspace_bytes, float *image, float *depth,
-            float *opacity, int32_t *radii, int32_t *n_touched, int32_t *status, hipStream_t stream)
+            float *opacity, int32_t *radii, int32_t *n_touched, int32_t *status, const GsrFused *fx, hipStream_t stream)
 {
     GsrLayout L;
     int rc = layout(d, cap, L);
@@ -890,19 +895,23 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     const bool ntouch = (d.flags & GSR_FLAG_NTOUCHED) != 0;
     if (ntouch && !n_touched) return GSR_EINVAL;
     if (workspace_bytes < L.total) return GSR_ENOSPACE;
+    const float *mse_target = fx ? fx->mse_target : nullptr;
+    if (mse_target && !fx->mse_loss) return GSR_EINVAL;
     Ptrs ws = carve(workspace, L);
+    const bool persistent_counters = fx && fx->tile_count;
+    if (persistent_counters) ws.tile_count = fx->tile_count;
     const int V = d.B * d.Vt, gx = tiles_x(d.W), gy = tiles_y(d.H), T = gx * gy;
     (void)hipGetLastError();  // drop stale (non-sticky) errors of earlier runtime calls, e.g. hipErrorNotReady polls
     const bool bin = (d.flags & GSR_FLAG_PHASE_BIN) != 0, render = (d.flags & GSR_FLAG_PHASE_RENDER) != 0;
     if (bin && render) return GSR_EINVAL;
     StageTimer tm(d.profile, true, stream, render);
     const dim3 gG((d.G + 255) / 256, d.B), gV((d.G + 255) / 256, V);
-    // K1 / K3 bin through LDS histograms when a view's tiles fit (GSR_BIN=ballot: the wave-aggregated global atomics of rounds 1 - 4, the A/B)
-    const char *bin_env = getenv("GSR_BIN");
-    const int lds_tiles = (T <= LDS_TILES_MAX && !(bin_env && !strcmp(bin_env, "ballot"))) ? T : 0;
+    // K1 / K3 bin through LDS histograms when a view's tiles fit (GSR_FLAG_BIN_BALLOT: the wave-aggregated global atomics of rounds 1 - 4, the
+    // path of larger images, forced for A/B runs and the equivalence test)
+    const int lds_tiles = (T <= LDS_TILES_MAX && !(d.flags & GSR_FLAG_BIN_BALLOT)) ? T : 0;
     if (render) goto render_phase;   // K1-K2 of this workspace were enqueued by the PHASE_BIN call
 
-    if (!hip_ok(hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream))) return GSR_ELAUNCH;
+    if (!persistent_counters && !hip_ok(hipMemsetAsync(ws.tile_count, 0, (size_t)V * T * 4, stream))) return GSR_ELAUNCH;
     if (ntouch && !hip_ok(hipMemsetAsync(n_touched, 0, (size_t)V * d.G * 4, stream))) return GSR_ELAUNCH;
 
     tm.begin(GSR_STAGE_PREPROCESS);
@@ -917,7 +926,7 @@ int forward(const GsrDims &d, const GsrView *views, const float *means, const fl
     }
 #undef GSR_LAUNCH_K1
     tm.end(GSR_STAGE_PREPROCESS); tm.begin(GSR_STAGE_SCAN);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, V * T, cap, ws, status, persistent_counters ? 1 : 0, mse_target ? V + 1 : 0);
     tm.end(GSR_STAGE_SCAN);
     if (bin) return launch_status();  // status is final here: the host can size / retry before the heavy stages
 render_phase:
@@ -935,13 +944,10 @@ render_phase:
     }
     tm.end(GSR_STAGE_SORT); tm.begin(GSR_STAGE_COMPOSITE_FWD);
     {
-        // GSR_K6=rows16 / rows8 (read per call, as in gsr_backward): the row-packed backward needs the exact block masks
-        const char *k6_env = getenv("GSR_K6");
-        const bool blocks = k6_env && !strncmp(k6_env, "rows", 4);
-#define GSR_LAUNCH_K5(NT, BL) hipLaunchKernelGGL((k_composite_fwd<NT, BL>), dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity, n_touched)
-        if (ntouch) { if (blocks) GSR_LAUNCH_K5(true, true); else GSR_LAUNCH_K5(true, false); }
-        else { if (blocks) GSR_LAUNCH_K5(false, true); else GSR_LAUNCH_K5(false, false); }
-#undef GSR_LAUNCH_K5
+        const float mse_weight = fx ? fx->mse_weight : 0.f;
+        float *mse_loss = fx ? fx->mse_loss : nullptr;
+        if (ntouch) hipLaunchKernelGGL(k_composite_fwd<true>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity, n_touched, mse_target, mse_weight, mse_loss);
+        else hipLaunchKernelGGL(k_composite_fwd<false>, dim3(T, V), dim3(64), 0, stream, d, views, ws, image, depth, opacity, n_touched, mse_target, mse_weight, mse_loss);
     }
     tm.end(GSR_STAGE_COMPOSITE_FWD);
     return launch_status();

@@ -21,7 +21,7 @@ import torch
 from torch import Tensor, nn
 
 from .camera import get_fov, get_projection_matrix
-from .rasterizer import pack_views, rasterize_views
+from .rasterizer import RasterMse, pack_views, rasterize_views
 
 DepthRenderingMode = Literal["depth", "disparity", "relative_disparity", "log"]
 
@@ -39,6 +39,9 @@ class Gaussians:
 class DecoderOutput:
     color: Tensor            # (b,v,3,h,w)
     depth: Optional[Tensor]  # (b,v,h,w)
+    # not in the reference's DecoderOutput: LossMse of `color` against the `mse_target` handed to forward(), computed inside the
+    # composite kernels (None without a target)
+    loss_mse: Optional[Tensor] = None
 
 
 @dataclass
@@ -91,9 +94,9 @@ def build_views_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: T
 def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape, background_color: Tensor,
                gaussians: Gaussians, views_per_scene: int, scale_invariant: bool = True, use_sh: bool = True,
                cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None,
-               torch_view_setup: bool = False):
+               torch_view_setup: bool = False, mse: Optional[RasterMse] = None):
     """Batched counterpart of `render_cuda`: (b*v) cameras, b un-replicated Gaussian sets.
-    Returns (color (b*v,3,h,w), depth (b*v,h,w))."""
+    Returns (color (b*v,3,h,w), depth (b*v,h,w)), plus the fused LossMse scalar when `mse` is given."""
     n = gaussians.harmonics.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussians.harmonics.permute(0, 1, 3, 2).contiguous()            # (b,g,n,3)  cuda_splatting.py:76
@@ -107,8 +110,8 @@ def render_hip(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor
         views = build_views_hip(extrinsics, intrinsics, near, far, background_color, scale_invariant)
     colors = shs if use_sh else shs[:, :, 0, :].contiguous()
     out = rasterize_views(gaussians.means, cov6, gaussians.opacities, colors, views, image_shape, views_per_scene,
-                          sh_degree=degree, use_sh=use_sh, theta=cam_rot_delta, rho=cam_trans_delta)
-    return out.image, out.depth
+                          sh_degree=degree, use_sh=use_sh, theta=cam_rot_delta, rho=cam_trans_delta, mse=mse)
+    return (out.image, out.depth) if mse is None else (out.image, out.depth, out.loss_mse)
 
 
 def render_hip_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor, image_shape,
@@ -155,20 +158,34 @@ class DecoderSplattingHIP(nn.Module):
         self.torch_view_setup = False
         self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
                              persistent=False)
+        self._bg_rows = None   # (key, (n,3) contiguous copy of the background): one expand-copy kernel per shape instead of one per call
+
+    def _background_rows(self, n: int) -> Tensor:
+        bg = self.background_color
+        key = (n, bg.device, bg.data_ptr(), bg._version)
+        if self._bg_rows is None or self._bg_rows[0] != key:
+            self._bg_rows = (key, bg.detach()[None].expand(n, 3).contiguous())
+        return self._bg_rows[1]
 
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape, depth_mode: Optional[DepthRenderingMode] = None,
-                cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None) -> DecoderOutput:
+                cam_rot_delta: Optional[Tensor] = None, cam_trans_delta: Optional[Tensor] = None,
+                mse_target: Optional[Tensor] = None, mse_weight: float = 1.0) -> DecoderOutput:
+        """`mse_target` (b,v,3,h,w), not in the reference's signature: the ground-truth images of `LossMse` (loss_mse.py:22-31).  The loss
+        is then computed inside the compositing kernels and returned as `DecoderOutput.loss_mse` -- equal to
+        `mse_weight * ((color - mse_target) ** 2).mean()`, its backward formed in the composite backward's prologue -- instead of by two more
+        kernels and a round trip of dL/dcolor through HBM."""
         b, v = extrinsics.shape[:2]
         flat = lambda t: t.reshape(b * v, *t.shape[2:])
-        color, depth = render_hip(
+        h, w = image_shape
+        mse = None if mse_target is None else RasterMse(mse_target.reshape(b * v, 3, h, w), mse_weight)
+        out = render_hip(
             flat(extrinsics), flat(intrinsics), flat(near), flat(far), image_shape,
-            self.background_color[None].expand(b * v, 3), gaussians, v,
+            self._background_rows(b * v), gaussians, v,
             scale_invariant=self.make_scale_invariant, torch_view_setup=self.torch_view_setup,
             cam_rot_delta=flat(cam_rot_delta) if cam_rot_delta is not None else None,
-            cam_trans_delta=flat(cam_trans_delta) if cam_trans_delta is not None else None)
-        h, w = image_shape
-        return DecoderOutput(color.reshape(b, v, 3, h, w), depth.reshape(b, v, h, w))
+            cam_trans_delta=flat(cam_trans_delta) if cam_trans_delta is not None else None, mse=mse)
+        return DecoderOutput(out[0].reshape(b, v, 3, h, w), out[1].reshape(b, v, h, w), out[2] if mse is not None else None)
 
 
 def get_decoder(cfg: DecoderSplattingCUDACfg) -> DecoderSplattingHIP:

@@ -83,14 +83,39 @@ class RasterOutput(NamedTuple):
     radii: Tensor      # (V,G) int32
     depth: Tensor      # (V,H,W)
     opacity: Tensor    # (V,H,W)
-    n_touched: Tensor  # (V,G) int32 (zeros unless requested)
+    n_touched: Tensor  # (V,G) int32 (an unwritten (1,1) placeholder unless requested)
+    loss_mse: Optional[Tensor] = None   # scalar, only with `mse=`: weight * mean((image - target)^2), computed by the composite kernel
+
+
+# persistent per-tile counters (GsrFused.tile_count), per (device, stream): zeroed once here, re-armed by every tile scan
+_COUNTERS: dict = {}
+# flags OR-ed into every call (tests / A-B tools: _lib.GSR_FLAG_BIN_BALLOT)
+EXTRA_FLAGS = 0
+# True: the tile scan stores the status words straight into pinned host memory (no copy kernel between the scan and the scatter);
+# False: device status words + an asynchronous copy (the round-1..5 form, kept for A/B runs)
+STATUS_DIRECT = True
+
+
+def _tile_counters(dev, stream_handle: int, n: int) -> Tensor:
+    key = (dev.index, stream_handle)
+    buf = _COUNTERS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _COUNTERS[key] = torch.zeros(max(n, 1 << 14), dtype=torch.int32, device=dev)
+    return buf
+
+
+class RasterMse(NamedTuple):
+    """LossMse (src/loss/loss_mse.py:22-31) fused into the composite kernels: target (V,3,H,W) ground truth, weight."""
+    target: Tensor
+    weight: float
 
 
 class _Rasterize(torch.autograd.Function):
     """V = B*Vt views of B scenes in one launch sequence (include/gsr.h)."""
 
     @staticmethod
-    def forward(ctx, means, cov6, opac, colors, views, means2D, theta, rho, H, W, Vt, sh_degree, use_sh, want_ntouched):
+    def forward(ctx, means, cov6, opac, colors, views, means2D, theta, rho, H, W, Vt, sh_degree, use_sh, want_ntouched,
+                mse_target, mse_weight):
         if not means.is_cuda:
             raise RuntimeError("styl3r_amd rasterizer needs tensors on an MI355X (HIP) device; there is no CPU path")
         lib = _lib.load()
@@ -109,7 +134,7 @@ class _Rasterize(torch.autograd.Function):
         # a backward will follow: the composite kernel zeroes the gradient accumulators on the side (GSR_FLAG_PREZERO_GRADS)
         prezero = any(ctx.needs_input_grad)
         flags = (_lib.GSR_FLAG_NTOUCHED if want_ntouched else 0) | (_lib.GSR_FLAG_COV9 if cov9 else 0) | \
-                (sort_sel << _lib.GSR_FLAG_SORT_KEYS_SHIFT) | (_lib.GSR_FLAG_PREZERO_GRADS if prezero else 0)
+                (sort_sel << _lib.GSR_FLAG_SORT_KEYS_SHIFT) | (_lib.GSR_FLAG_PREZERO_GRADS if prezero else 0) | EXTRA_FLAGS
         dims = _lib.GsrDims(B, Vt, G, H, W, M, sh_degree if use_sh else 0, flags,
                             PROFILE.handle if PROFILE is not None else None)
         dev = means.device
@@ -117,39 +142,55 @@ class _Rasterize(torch.autograd.Function):
         depth = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         opacity = torch.empty((V, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((V, G), dtype=torch.int32, device=dev)
-        n_touched = torch.zeros((V, G) if want_ntouched else (1, 1), dtype=torch.int32, device=dev)
-        status = torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)   # fully written by the tile scan
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        # (not requested: an unwritten placeholder, no fill kernel; requested: the library zeroes it)
+        n_touched = torch.empty((V, G) if want_ntouched else (1, 1), dtype=torch.int32, device=dev)
+        stream_handle = torch.cuda.current_stream(dev).cuda_stream
+        stream = C.c_void_p(stream_handle)
         cap = _CAP_HINT.get(key, max(4 * V * G, 1 << 16))
+        T = ((H + 15) // 16) * ((W + 15) // 16)
+        fx = _lib.GsrFused()
+        fx.tile_count = _tile_counters(dev, stream_handle, V * T).data_ptr()
+        loss = None
+        if mse_target is not None:
+            mse_target = mse_target.contiguous().float()
+            assert mse_target.numel() == V * 3 * H * W and not mse_target.requires_grad, "fused MSE: a ground-truth target of the image's size"
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            fx.mse_target, fx.mse_weight, fx.mse_loss = mse_target.data_ptr(), float(mse_weight), loss.data_ptr()
+        st, ev = _status_host(dev)
+        status = st if STATUS_DIRECT else torch.empty(_lib.GSR_STATUS_WORDS, dtype=torch.int32, device=dev)   # fully written by the tile scan
         # Two-phase forward: preprocess + tile scan first; the pair count they produce is the only thing the host has
-        # to see.  It is copied to pinned host memory right behind the scan and the render phase (scatter / sort /
-        # composite) is enqueued OPTIMISTICALLY behind that copy, so the GPU never waits for the host; the host then
-        # spins on the copy's event (ready ~0.1 ms after launch, while the render phase is still running).  On overflow
-        # the render kernels have exited early (they test the flag) and everything is re-issued with a larger capacity.
+        # to see.  The scan stores it in pinned host memory and the render phase (scatter / sort / composite) is enqueued
+        # OPTIMISTICALLY behind it, so the GPU never waits for the host; the host then spins on an event recorded behind the
+        # scan (ready ~0.1 ms after launch, while the render phase is still running).  On overflow the render kernels have
+        # exited early (they test the flag) and everything is re-issued with a larger capacity.
         def run(phase):
             dims.flags = flags | phase
-            rc = lib.gsr_forward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
-                                 cap, _ptr(ws), L.total, _ptr(image), _ptr(depth), _ptr(opacity), _ptr(radii),
-                                 _ptr(n_touched) if want_ntouched else None, _ptr(status), stream)
+            rc = lib.gsr_forward_fused(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
+                                       cap, _ptr(ws), L.total, _ptr(image), _ptr(depth), _ptr(opacity), _ptr(radii),
+                                       _ptr(n_touched) if want_ntouched else None, _ptr(status), C.byref(fx), stream)
             dims.flags = flags
             _lib.check(rc, "gsr_forward")
 
-        st, ev = _status_host(dev)
-        while True:
-            L = _lib.workspace_layout(dims, cap)
-            ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
-            run(_lib.GSR_FLAG_PHASE_BIN)
-            st.copy_(status, non_blocking=True)
-            ev.record(torch.cuda.current_stream(dev))
-            run(_lib.GSR_FLAG_PHASE_RENDER)
-            while not ev.query():
-                pass
-            R = (int(st[3]) << 32) | (int(st[0]) & 0xFFFFFFFF)
-            if int(st[1]) == 0:
-                break
-            if R > 0xFFFFFFFF:
-                raise RuntimeError(f"gsr_forward: {R} (tile, Gaussian) pairs exceed the 2^32 list limit")
-            cap = int(R * 1.25) + 1024
+        try:
+            while True:
+                L = _lib.workspace_layout(dims, cap)
+                ws = torch.empty(L.total, dtype=torch.uint8, device=dev)
+                run(_lib.GSR_FLAG_PHASE_BIN)
+                if not STATUS_DIRECT:
+                    st.copy_(status, non_blocking=True)
+                ev.record(torch.cuda.current_stream(dev))
+                run(_lib.GSR_FLAG_PHASE_RENDER)
+                while not ev.query():
+                    pass
+                R = (int(st[3]) << 32) | (int(st[0]) & 0xFFFFFFFF)
+                if int(st[1]) == 0:
+                    break
+                if R > 0xFFFFFFFF:
+                    raise RuntimeError(f"gsr_forward: {R} (tile, Gaussian) pairs exceed the 2^32 list limit")
+                cap = int(R * 1.25) + 1024
+        except BaseException:
+            _COUNTERS.pop((dev.index, stream_handle), None)     # the counters may be left half-counted: never reuse them
+            raise
         st = st.clone()
         _CAP_HINT[key] = max(_CAP_HINT.get(key, 0), min(int(R * 1.25) + 1024, 0xFFFFFFFF), 1 << 16)
         _MAX_TILE_HINT[key] = max(_MAX_TILE_HINT.get(key, 0), int(int(st[2]) * 1.25))
@@ -157,23 +198,35 @@ class _Rasterize(torch.autograd.Function):
         ctx.want_tau = theta is not None or rho is not None
         ctx.want_m2d = means2D is not None and means2D.requires_grad
         ctx.has = (theta is not None, rho is not None, means2D is not None)
+        ctx.mse_weight = float(mse_weight) if mse_target is not None else None
         ctx.save_for_backward(means, cov6, colors, views, ws)
+        ctx.mse_target = mse_target       # (a ground-truth tensor without a graph: kept as the backward's "fused" switch)
         ctx.mark_non_differentiable(radii, n_touched)
-        ctx.set_materialize_grads(False)   # unused outputs (depth, opacity) arrive as None instead of zero-filled tensors
+        ctx.set_materialize_grads(False)   # unused outputs (depth, opacity, the image under a fused loss) arrive as None instead of zero-filled tensors
         ctx.num_pairs = R
         LAST_STATS.update(pairs=R, views=V, gaussians_per_scene=G, longest_tile_list=int(st[2]))     # what the last forward rendered (benchmarks assert on it)
         if KEEP_DEBUG:
             LAST_DEBUG.update(ws=ws, layout=L, dims=dims, cap=cap, num_pairs=R, status=st)
-        return image, radii, depth, opacity, n_touched
+        return image, radii, depth, opacity, n_touched, loss
 
     @staticmethod
-    def backward(ctx, g_image, g_radii, g_depth, g_opacity, g_ntouched):
+    def backward(ctx, g_image, g_radii, g_depth, g_opacity, g_ntouched, g_loss):
         lib = _lib.load()
+        fused = ctx.mse_weight is not None
         means, cov6, colors, views, ws = ctx.saved_tensors
         dims = ctx.dims
         B, G, V = dims.B, dims.G, dims.B * dims.Vt
         dev = means.device
-        g_image = g_image.contiguous().float() if g_image is not None else torch.zeros((V, 3, dims.H, dims.W), dtype=torch.float32, device=dev)
+        fx = _lib.GsrFused()
+        if fused and g_loss is not None:       # (a loss nobody differentiated: the plain backward)
+            g_loss = g_loss.contiguous().float()
+            fx.mse_target, fx.mse_weight, fx.mse_grad_loss = ctx.mse_target.data_ptr(), ctx.mse_weight, g_loss.data_ptr()
+        else:
+            fused = False
+        if g_image is not None:
+            g_image = g_image.contiguous().float()
+        elif not fused:
+            g_image = torch.zeros((V, 3, dims.H, dims.W), dtype=torch.float32, device=dev)
         g_depth = g_depth.contiguous().float() if g_depth is not None else None
         d_means = torch.empty_like(means); d_cov6 = torch.empty_like(cov6)
         d_opac = torch.empty((B, G), dtype=torch.float32, device=dev)
@@ -181,27 +234,30 @@ class _Rasterize(torch.autograd.Function):
         d_m2d = torch.empty((V, G, 3), dtype=torch.float32, device=dev) if ctx.want_m2d else None
         d_tau = torch.empty((V, 6), dtype=torch.float32, device=dev) if ctx.want_tau else None
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = lib.gsr_backward(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(colors), ctx.cap, _ptr(ws),
-                              ctx.ws_bytes, _ptr(g_image), _ptr(g_depth), _ptr(d_means), _ptr(d_cov6), _ptr(d_opac),
-                              _ptr(d_colors), _ptr(d_m2d), _ptr(d_tau), stream)
+        rc = lib.gsr_backward_fused(C.byref(dims), _ptr(views), _ptr(means), _ptr(cov6), _ptr(colors), ctx.cap, _ptr(ws),
+                                    ctx.ws_bytes, _ptr(g_image), _ptr(g_depth), _ptr(d_means), _ptr(d_cov6), _ptr(d_opac),
+                                    _ptr(d_colors), _ptr(d_m2d), _ptr(d_tau), C.byref(fx), stream)
         _lib.check(rc, "gsr_backward")
         dims.flags &= ~_lib.GSR_FLAG_PREZERO_GRADS     # the accumulators are dirty now: a second backward (retain_graph) zeroes them itself
         has_theta, has_rho, has_m2d = ctx.has
         g_theta = d_tau[:, 3:6] if (ctx.want_tau and has_theta) else None
         g_rho = d_tau[:, 0:3] if (ctx.want_tau and has_rho) else None
         return (d_means, d_cov6, d_opac, d_colors, None, d_m2d if has_m2d else None, g_theta, g_rho,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, views: Tensor, image_hw,
                     views_per_scene: int, sh_degree: int = 0, use_sh: bool = True, means2D: Optional[Tensor] = None,
                     theta: Optional[Tensor] = None, rho: Optional[Tensor] = None,
-                    want_n_touched: bool = False) -> RasterOutput:
+                    want_n_touched: bool = False, mse: Optional[RasterMse] = None) -> RasterOutput:
     """Batched entry point: means (B,G,3), cov6 (B,G,6) or full covariances (B,G,3,3), opacities (B,G), colors = SH (B,G,M,3) or RGB (B,G,3),
-    views (B*Vt, 64) packed with `pack_views`; theta/rho (B*Vt, 3) receive the pose gradient."""
+    views (B*Vt, 64) packed with `pack_views`; theta/rho (B*Vt, 3) receive the pose gradient.
+    `mse`: also return LossMse of the image against a ground-truth target, computed inside the composite kernels (forward: in the epilogue
+    of the compositing pass; backward: dL/dimage formed in the prologue) -- same value and gradients as `losses.mse_loss(out.image, target)`."""
     H, W = image_hw
     out = _Rasterize.apply(means, cov6, opacities, colors, views, means2D, theta, rho, int(H), int(W),
-                           int(views_per_scene), int(sh_degree), bool(use_sh), bool(want_n_touched))
+                           int(views_per_scene), int(sh_degree), bool(use_sh), bool(want_n_touched),
+                           None if mse is None else mse.target, 1.0 if mse is None else float(mse.weight))
     return RasterOutput(*out)
 
 

@@ -122,10 +122,11 @@ class TrainStep:
         self._weights = [p for p in encoder.parameters() if id(p) in trainable and p.dim() == 2]
         self.global_step = 0
 
-    def _render(self, ctx, style, tgt):
+    def _render(self, ctx, style, tgt, mse_target=None):
         g = self.encoder(ctx, style, self.global_step)
         h, w = tgt["image"].shape[-2:]
-        return g, self.decoder.forward(g, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w))
+        kw = {} if mse_target is None else {"mse_target": mse_target}     # LossMse inside the composite kernels (DecoderOutput.loss_mse)
+        return g, self.decoder.forward(g, tgt["extrinsics"], tgt["intrinsics"], tgt["near"], tgt["far"], (h, w), **kw)
 
     def __call__(self, batch: dict) -> torch.Tensor:
         ctx, tgt = batch["context"], batch["target"]
@@ -135,9 +136,10 @@ class TrainStep:
             style = {"image": ctx["image"][:, 0]}                         # stylized=False: style := context view 0 (`:149-150`)
         self.reducer.wait_params()                                        # "rs_ag": the previous step's parameter all-gather must have landed
         self.reducer.prepare()
-        g, out = self._render(ctx, style, tgt)
+        fuse = self.losses is None and tgt["image"].is_cuda and not tgt["image"].requires_grad
+        g, out = self._render(ctx, style, tgt, tgt["image"] if fuse else None)
         if self.losses is None:
-            total = mse_loss(out.color, tgt["image"])                     # LossMse
+            total = out.loss_mse if fuse else mse_loss(out.color, tgt["image"])     # LossMse
         else:
             total = sum(fn(out, batch, g, self.global_step) for fn in self.losses)
         if self.identity_loss is not None:

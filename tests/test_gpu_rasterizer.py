@@ -38,7 +38,8 @@ def _check_forward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0), 
     assert np.array_equal(off[:-1][nonempty], st.ranges[nonempty, 0].astype(np.uint32)), "range starts"
     assert np.array_equal(np.diff(off.astype(np.int64)), st.ranges[:, 1] - st.ranges[:, 0]), "range lengths"
     pl = ws_view("point_list", np.uint32, max(st.R, 1))[:st.R]
-    assert np.array_equal(pl, st.point_list.astype(np.uint32)), "sorted (tile, id) list"
+    # bits 28..31 of a list word are the composite forward's quadrant mask for the backward (include/gsr.h GSR_ID_MASK)
+    assert np.array_equal(pl & np.uint32(0x0FFFFFFF), st.point_list.astype(np.uint32)), "sorted (tile, id) list"
     recs = ws_view("records", np.float32, G * 12).reshape(G, 12)
     vis = st.radii > 0
     assert np.array_equal(recs[vis, 0:2], st.xy[vis]) and np.array_equal(recs[vis, 2], st.depth[vis]), "xy / depth bits"
@@ -191,23 +192,14 @@ def _check_backward(means, cov6, opac, cam, shs=None, colors=None, bg=(0, 0, 0),
         assert_close_rel(theta.grad.cpu().numpy(), res["f64"]["theta"], max(2e-4, f64_rel), "d theta")
 
 
-@pytest.fixture(params=["tile", "rows16", "rows8"])
-def k6(request, monkeypatch):
-    """every composite-backward kernel against the same oracle bars: the one-wavefront-per-tile kernel (default) and the
-    round-5 row-packed kernels (GSR_K6=rows16 / rows8: a wavefront per 8x8 quadrant, four 4x4-block or eight 2x4-block systolic
-    rows walking the exact block masks of the forward).  libgsr_hip.so reads the variable per call."""
-    monkeypatch.setenv("GSR_K6", request.param)
-    return request.param
-
-
 @pytest.mark.parametrize("sh_degree", [0, 2, 4])
-def test_backward_parity(sh_degree, k6):
+def test_backward_parity(sh_degree):
     cam = simple_camera(64, 80, c2w=CAM_C2W)
     means, cov6, opac, shs = random_scene(1200, seed=60 + sh_degree, sh_degree=sh_degree, scale=(0.03, 0.15))
     _check_backward(means, cov6, opac, cam, shs=shs, sh_degree=sh_degree, bg=(0.3, 0.5, 0.2))
 
 
-def test_backward_parity_colors_precomp_and_pose(k6):
+def test_backward_parity_colors_precomp_and_pose():
     cam = simple_camera(48, 48, c2w=CAM_C2W)
     means, cov6, opac, shs = random_scene(600, seed=77, scale=(0.03, 0.15))
     _check_backward(means, cov6, opac, cam, colors=np.abs(shs[:, 0, :]), bg=(0.1, 0.1, 0.4), pose=True)
@@ -302,7 +294,7 @@ def _scene_view_cam(sc, views, i):
     return s, cov6, cam
 
 
-def test_full_size_workload_backward_parity_single_view(k6):
+def test_full_size_workload_backward_parity_single_view():
     """the BACKWARD at the headline size (G = 65 536, 256 x 256; lists of ~630 entries, multi-batch
     back-to-front walk) against the f32 and f64 oracles, every gradient, depth gradient included (k_composite_bwd<true>)."""
     from styl3r_amd.decoder import prepare_views
@@ -315,7 +307,7 @@ def test_full_size_workload_backward_parity_single_view(k6):
     # single alpha >= 1/255 decisions differ between the two precisions on 630-entry lists
 
 
-def test_c4_size_view_backward_parity(k6):
+def test_c4_size_view_backward_parity():
     """one view of the C4 workload: 4 context views x 256^2 = 262 144 Gaussians (lists of ~2 250, up to ~4 700 entries: beyond the
     tile sort's LDS budget), forward integer state + images and every gradient against the oracles"""
     from styl3r_amd.decoder import prepare_views
@@ -533,13 +525,13 @@ def test_prezeroed_gradient_accumulators_equal_the_memset_path_and_survive_a_sec
         return first, (torch.autograd.grad(loss, leaves) if twice else None)
 
     seen = []
-    real = _lib.load().gsr_backward
+    real = _lib.load().gsr_backward_fused
     import ctypes as C
-    class Spy:                                       # records the flag word every gsr_backward call receives
+    class Spy:                                       # records the flag word every gsr_backward_fused call receives
         def __call__(self, dims, *a):
             seen.append(C.cast(dims, C.POINTER(_lib.GsrDims)).contents.flags & _lib.GSR_FLAG_PREZERO_GRADS)
             return real(dims, *a)
-    monkeypatch.setattr(_lib.load(), "gsr_backward", Spy(), raising=False)
+    monkeypatch.setattr(_lib.load(), "gsr_backward_fused", Spy(), raising=False)
     a, a2 = grads(True)
     assert seen == [_lib.GSR_FLAG_PREZERO_GRADS, 0], seen      # first backward trusts the forward, the second one zeroes
     monkeypatch.setattr(_lib, "GSR_FLAG_PREZERO_GRADS", 0)     # memset path
@@ -551,7 +543,7 @@ def test_prezeroed_gradient_accumulators_equal_the_memset_path_and_survive_a_sec
 
 
 def test_lds_histogram_binning_equals_the_wave_aggregated_one(monkeypatch):
-    """K1 / K3 bin through LDS histograms when a view has at most LDS_TILES_MAX tiles (round 5); GSR_BIN=ballot selects the wave-aggregated
+    """K1 / K3 bin through LDS histograms when a view has at most LDS_TILES_MAX tiles (round 5); GSR_FLAG_BIN_BALLOT selects the wave-aggregated
     global atomics of rounds 1 - 4, which larger images still take.  Both must leave the same sorted lists: images, radii, depth, n_contrib and
     are compared bit for bit (the composite forward is deterministic given the lists); the gradients at 2e-5 (the backward's per-tile atomics
     arrive in whatever order the tiles finish)."""
@@ -570,11 +562,101 @@ def test_lds_histogram_binning_equals_the_wave_aggregated_one(monkeypatch):
         nc = ws_view("n_contrib", np.int32, 2 * 3 * 112 * 144).copy()
         return out.color.detach().clone(), out.depth.detach().clone(), nc, int(rz.LAST_DEBUG["num_pairs"]), [x.clone() for x in grads]
 
-    monkeypatch.delenv("GSR_BIN", raising=False)
+    from styl3r_amd import _lib
     a = run()
-    monkeypatch.setenv("GSR_BIN", "ballot")
+    monkeypatch.setattr(rz, "EXTRA_FLAGS", _lib.GSR_FLAG_BIN_BALLOT)
     b = run()
     assert a[3] == b[3] and a[3] > 0
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     for x, y, name in zip(a[4], b[4], ("means", "cov", "sh", "opac")):
         assert_close_rel(x.cpu().numpy(), y.cpu().numpy(), 2e-5, f"lds vs ballot binning d{name}")      # (the bar of the prezero / memset test below: atomics arrive in any order)
+
+
+def _mse_step(fused, dev, seed=0, weight=0.7, res=(112, 144), grid=(96, 96), status_direct=True):
+    """2 scenes x 3 views through the decoder + LossMse, fused into the composite kernels or as the stand-alone pair of kernels"""
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder
+    from styl3r_amd.losses import mse_loss
+    from styl3r_amd.scenes import make_scene
+    scs = [make_scene(n_ctx=1, grid_hw=grid, n_views=3, image_hw=res, sh_degree=1, seed=700 + seed + i) for i in range(2)]
+    st = lambda n: torch.stack([getattr(s, n) for s in scs]).to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.2, 0.1, 0.3], True)).to(dev)
+    target = torch.rand(2, 3, 3, *res, device=dev, generator=torch.Generator(dev).manual_seed(11 + seed))
+    g = Gaussians(*(st(n).requires_grad_(True) for n in ("means", "covariances", "harmonics", "opacities")))
+    args = (g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), res)
+    if fused:
+        out = dec.forward(*args, mse_target=target, mse_weight=weight)
+        loss = out.loss_mse
+    else:
+        out = dec.forward(*args)
+        loss = mse_loss(out.color, target, weight)
+    grads = torch.autograd.grad(loss, (g.means, g.covariances, g.harmonics, g.opacities))
+    return out.color.detach(), target, loss.detach(), [x.detach() for x in grads]
+
+
+def test_fused_mse_equals_the_stand_alone_loss_kernels_and_float64():
+    """LossMse inside the composite kernels (GsrFused.mse_target): the forward value against the float64 expression on the rendered image
+    (fixed-order fp32 partial sums: 1e-6) and bit-for-bit across repeats (deterministic); the image itself unchanged; the gradients against
+    the stand-alone gsr_mse_forward / gsr_mse_backward path -- the same dL/dimage bits enter the same composite backward, the atomics'
+    arrival order is the only difference (the 2e-5 bar of the prezero / memset test)."""
+    dev = torch.device("cuda:0")
+    img_f, target, loss_f, grads_f = _mse_step(True, dev)
+    img_u, _, loss_u, grads_u = _mse_step(False, dev)
+    assert torch.equal(img_f, img_u)
+    ref = 0.7 * ((img_f.double() - target.double()) ** 2).mean()
+    assert abs(loss_f.item() - ref.item()) <= 1e-6 * abs(ref.item()), (loss_f.item(), ref.item())
+    assert abs(loss_u.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    for _ in range(3):                                   # deterministic: the tickets fix nothing but WHO adds, never the order
+        assert _mse_step(True, dev)[2].item() == loss_f.item()
+    for x, y, name in zip(grads_f, grads_u, ("means", "cov", "sh", "opac")):
+        assert_close_rel(x.cpu().numpy(), y.cpu().numpy(), 2e-5, f"fused vs stand-alone MSE d{name}")
+
+
+def test_fused_mse_adds_to_an_image_gradient_from_elsewhere_and_survives_an_unused_loss():
+    """loss_mse + another consumer of the colour: the composite backward adds the two image gradients in its prologue; a fused forward whose
+    loss nobody differentiates takes the plain backward."""
+    from styl3r_amd.decoder import DecoderSplattingCUDACfg, Gaussians, get_decoder
+    from styl3r_amd.scenes import make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(n_ctx=1, grid_hw=(64, 64), n_views=2, image_hw=(64, 80), sh_degree=0, seed=41)
+    st = lambda n: getattr(sc, n)[None].to(dev)
+    dec = get_decoder(DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True)).to(dev)
+    target = torch.rand(1, 2, 3, 64, 80, device=dev, generator=torch.Generator(dev).manual_seed(3))
+    w = torch.rand(1, 2, 3, 64, 80, device=dev, generator=torch.Generator(dev).manual_seed(4))
+
+    def run(mode):
+        g = Gaussians(*(st(n).requires_grad_(True) for n in ("means", "covariances", "harmonics", "opacities")))
+        args = (g, st("extrinsics"), st("intrinsics"), st("near"), st("far"), (64, 80))
+        if mode == "fused+other":
+            out = dec.forward(*args, mse_target=target, mse_weight=2.0)
+            loss = out.loss_mse + (out.color * w).sum()
+        elif mode == "fused, loss unused":
+            out = dec.forward(*args, mse_target=target, mse_weight=2.0)
+            loss = (out.color * w).sum()
+        elif mode == "plain other":
+            loss = (dec.forward(*args).color * w).sum()
+        else:
+            out = dec.forward(*args)
+            loss = 2.0 * ((out.color - target) ** 2).mean() + (out.color * w).sum()
+        return [x.detach().cpu().numpy() for x in torch.autograd.grad(loss, (g.means, g.covariances, g.harmonics, g.opacities))]
+
+    a, b = run("fused+other"), run("torch")
+    for x, y, name in zip(a, b, ("means", "cov", "sh", "opac")):
+        assert_close_rel(x, y, 2e-5, f"fused MSE + other consumer d{name}")
+    a, b = run("fused, loss unused"), run("plain other")
+    for x, y, name in zip(a, b, ("means", "cov", "sh", "opac")):
+        assert_close_rel(x, y, 2e-5, f"unused fused loss d{name}")
+
+
+def test_status_words_in_pinned_host_memory_equal_the_copied_ones(monkeypatch):
+    """the tile scan stores the status words straight into pinned host memory (no copy kernel in the step); the round-1..5 form -- device
+    words + an asynchronous copy -- must read the same pair count and give the same image; persistent tile counters are re-armed by the
+    scan: a second forward on them sees the same lists."""
+    dev = torch.device("cuda:0")
+    a = _mse_step(True, dev, seed=5)
+    Ra = rz.LAST_STATS["pairs"]
+    a2 = _mse_step(True, dev, seed=5)
+    assert rz.LAST_STATS["pairs"] == Ra and torch.equal(a[0], a2[0])
+    monkeypatch.setattr(rz, "STATUS_DIRECT", False)
+    b = _mse_step(True, dev, seed=5)
+    assert rz.LAST_STATS["pairs"] == Ra and Ra > 0
+    assert torch.equal(a[0], b[0]) and a[2].item() == b[2].item()

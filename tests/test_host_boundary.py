@@ -40,6 +40,12 @@ def test_struct_sizes_match_header():
     assert fields == [n for n, _ in _lib.GsrLayout._fields_]          # same names, same order as include/gsr.h
     assert C.sizeof(_lib.GsrLayout) == len(fields) * C.sizeof(C.c_size_t)
     assert _lib.GSR_VIEW_FLOATS * 4 == 256
+    body = header[header.index("typedef struct GsrFused {"):header.index("} GsrFused;")]
+    fields = re.findall(r"(\w+);", body)
+    assert fields == [n for n, _ in _lib.GsrFused._fields_]           # same names, same order as include/gsr.h
+    assert C.sizeof(_lib.GsrFused) == 40                               # 2 pointers, float + padding, 2 pointers
+    assert f"#define GSR_ID_MASK 0x{_lib.GSR_ID_MASK:08x}u" in header and f"#define GSR_QUAD_SHIFT {_lib.GSR_QUAD_SHIFT}" in header
+    assert f"#define GSR_FLAG_BIN_BALLOT {_lib.GSR_FLAG_BIN_BALLOT} " in header
 
 
 def test_workspace_layout_and_argument_checks(lib):
@@ -58,6 +64,8 @@ def test_workspace_layout_and_argument_checks(lib):
     # null pointers are rejected before anything is launched (no GPU needed)
     assert lib.gsr_forward(C.byref(d), *([None] * 5), 1 << 20, None, 0, *([None] * 7)) == -1
     assert lib.gsr_backward(C.byref(d), *([None] * 4), 1 << 20, None, 0, *([None] * 9)) == -1
+    assert lib.gsr_forward_fused(C.byref(d), *([None] * 5), 1 << 20, None, 0, *([None] * 8)) == -1
+    assert lib.gsr_backward_fused(C.byref(d), *([None] * 4), 1 << 20, None, 0, *([None] * 10)) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -17,7 +17,8 @@ rows = cur.execute(f"select {name_col}, start, end from kernels order by start")
 idx = [i for i, r in enumerate(rows) if anchor in r[0] and "bwd" not in r[0]]
 if len(idx) < 3:
     sys.exit(f"anchor {anchor!r} seen {len(idx)} times")
-a, b = idx[-3], idx[-2]                      # a full step away from both ends of the trace
+k = len(idx) // 2 if len(idx) > 40 else len(idx) - 3      # a steady-state step from the middle of the timed region (the tail of a bench run is A/B legs and read-backs)
+a, b = idx[k], idx[k + 1]
 t0, prev_end, busy = rows[a][1], rows[a][1], 0
 lines = ["| # | kernel | start us | dur us | gap before us |", "|---|---|---|---|---|"]
 for i, (n, s, e) in enumerate(rows[a:b]):
