@@ -377,6 +377,14 @@ def raster_leg(args, rank, world, dev, dist):
             res["batched_full_outputs"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         try:
             res["dropin_per_view"] = dropin_leg(args, dev, g, cams, target)
+            # the same loop around a rasterizer that does nothing: what the reference's call pattern costs by itself (the split)
+            ref_only = dropin_leg(args, dev, g, cams, target, stub=True)
+            d = res["dropin_per_view"]
+            d["reference_pattern_alone_ms_per_step"] = ref_only["ms_per_step"]
+            d["module_share_ms_per_call"] = round((d["ms_per_step"] - ref_only["ms_per_step"]) / d["rasterizer_calls_per_step"], 4)
+            d["split"] = ("reference_pattern_alone = the identical loop with a do-nothing rasterizer (per-view settings, 2 .item() syncs, repeat / index / select "
+                          "autograd kernels, stack, loss); module_share = the rest per call: one-view launches of the composite kernels fill a quarter of the chip "
+                          "with one wave per SIMD (profiles/r06_dropin_kernel_stats.md), the module's host time is ~0.18 ms of it and hidden behind them")
         except Exception as e:
             res["dropin_per_view"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     del g, cams, target, dec
@@ -426,7 +434,7 @@ def full_outputs_leg(args, dev, g, cams, target, steps=50, warmup=5):
 
 
 # ------------------------------------------------------------------ drop-in leg (the reference's own call pattern)
-def dropin_leg(args, dev, g, cams, target, steps=8, warmup=2):
+def dropin_leg(args, dev, g, cams, target, steps=8, warmup=2, stub=False):
     """INTEGRATION.md section 1 ("zero source changes"): what `DecoderSplattingCUDA.forward` + `render_cuda` would drive 40 times per step
     through the drop-in module `diff_gaussian_rasterization` -- the Gaussian tensors replicated per target view
     (decoder_splatting_cuda.py:51-63), the 1/near rescale as tensor ops (cuda_splatting.py:65-72), and per view: two `.item()` host
@@ -438,6 +446,16 @@ def dropin_leg(args, dev, g, cams, target, steps=8, warmup=2):
     from math import isqrt
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from styl3r_amd.camera import get_fov, get_projection_matrix
+    if stub:
+        # the reference's call pattern ALONE: the same loop around a rasterizer that does nothing but hand back differentiable
+        # placeholders -- what the per-view settings / .item() syncs / gathers / stack / loss cost without any rasterization
+        class GaussianRasterizer(torch.nn.Module):      # noqa: F811
+            def __init__(self, st):
+                super().__init__(); self.st = st
+            def forward(self, means3D, means2D, shs, colors_precomp, opacities, cov3D_precomp, theta, rho):
+                z = (means3D.sum() + shs.sum() + opacities.sum() + cov3D_precomp.sum()) * 0
+                img = z.expand(3, self.st.image_height, self.st.image_width)
+                return img, None, None, None, None
     b, v = cams["extrinsics"].shape[:2]
     h = w = args.res
     bg = torch.zeros(b * v, 3, device=dev)
