@@ -600,7 +600,7 @@ def train_leg(args, rank, world, dev, dist):
         try:
             vit_ops.LINEAR_MODE = vit_ops.ATTENTION_ARITH = head_mode
             run = lambda: step(batch)
-            out["comm"] = comm_report(step.reducer, run, sync, steps=max(2, min(4, args.train_steps)))
+            out["comm"] = comm_report(step.reducer, run, sync, steps=max(2, min(4, args.train_steps)), destructive=True)
             modes = {step.dp_mode: {"ms_per_step": out["ms_per_step"], "value": out["value"]}}
             # the other data-parallel mode as an A/B: automatic in a one-rank group (that path has run on hardware); at N > 1 only with --dp-ab --
             # "rs_ag" has never run on more than one GPU (gloo world-2 and one-rank RCCL only), and a collective mismatch there would not fail, it
@@ -610,25 +610,23 @@ def train_leg(args, rank, world, dev, dist):
                 out["dp_mode"] = step.dp_mode
                 out["dp_ab_note"] = "rerun with --dp-ab for the all_reduce / rs_ag A/B at N > 1 (opt-in: untested on more than one GPU)"
                 broadcast_module_state(enc, dist, force_collective=forced)       # the no-collective steps of the report let the replicas drift
-                raise StopIteration
-            other_dp = "rs_ag" if step.dp_mode == "all_reduce" else "all_reduce"
-            step.reducer.close()
-            del step
-            if not cpu:
-                torch.cuda.empty_cache()
-            broadcast_module_state(enc, dist, force_collective=forced)       # the no-collective steps let the replicas drift apart
-            step = TrainStep(enc, dec, dist=dist, force_collective=forced, warm_up_steps=2000, dp_mode=other_dp)
-            for _ in range(max(2, args.train_warmup)):
-                step(batch)
-            n2 = args.train_steps
-            dt2 = dist_utils.timed_steps(lambda: step(batch), n2, sync, dist, dev)
-            modes[other_dp] = {"ms_per_step": round(1e3 * dt2 / n2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n2, world, dt2), 3),
-                               "comm": comm_report(step.reducer, lambda: step(batch), sync, steps=max(2, min(4, args.train_steps)))}
-            step.reducer.wait_params()
-            out["dp_modes"] = modes
-            out["dp_mode"] = [m for m in modes if m != other_dp][0]
-        except StopIteration:
-            pass
+            else:
+                other_dp = "rs_ag" if step.dp_mode == "all_reduce" else "all_reduce"
+                step.reducer.close()
+                del step
+                if not cpu:
+                    torch.cuda.empty_cache()
+                broadcast_module_state(enc, dist, force_collective=forced)       # the no-collective steps let the replicas drift apart
+                step = TrainStep(enc, dec, dist=dist, force_collective=forced, warm_up_steps=2000, dp_mode=other_dp)
+                for _ in range(max(2, args.train_warmup)):
+                    step(batch)
+                n2 = args.train_steps
+                dt2 = dist_utils.timed_steps(lambda: step(batch), n2, sync, dist, dev)
+                modes[other_dp] = {"ms_per_step": round(1e3 * dt2 / n2, 2), "value": round(dist_utils.aggregate_throughput(b * v_tgt, n2, world, dt2), 3),
+                                   "comm": comm_report(step.reducer, lambda: step(batch), sync, steps=max(2, min(4, args.train_steps)), destructive=True)}
+                step.reducer.wait_params()
+                out["dp_modes"] = modes
+                out["dp_mode"] = [m for m in modes if m != other_dp][0]
         except Exception as e:
             out["comm_error"] = f"{type(e).__name__}: {e}"[:300]
         finally:

@@ -117,6 +117,14 @@ class BucketedGradReducer:
                     off += p.numel()
         self._handles: list = []
         self._armed = False
+        # The per-step used / unused map is HOST data (which hooks fired): it is exchanged on a host-side (gloo) group, never through the
+        # device.  Round 5 sent it as one more RCCL all-reduce and read it back with .cpu(): a full drain of the GPU queue in the middle of
+        # every step (the read-back waits for the whole backward and every bucket), after which the clip, the optimizer pass and the next
+        # forward were enqueued onto an idle device -- the +11 ms of a one-rank RCCL step over the same step without a group
+        # (profiles/r05j_bench_torchrun1.json), which every rank of an N-GPU job paid as well.
+        self._host_group = None
+        if self.collective and dist.get_backend() != "gloo":
+            self._host_group = dist.new_group(backend="gloo")      # (collective: every rank constructs its reducer at the same point)
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._arrived: set = set()
         self._arrived_key = None        # the local arrival set the cached map was computed for
@@ -284,10 +292,11 @@ class BucketedGradReducer:
         # the used / unused exchange: unconditional and symmetric (same collective sequence on every rank, every step)
         used = None
         if self.collective:
-            used = torch.zeros(len(self.params), dtype=torch.int32, device=self.params[0].device if self.params else "cpu")
+            # host tensors on the host-side group: no device work, no device sync (a gloo default group -- the CPU tests -- serves itself)
+            used = torch.zeros(len(self.params), dtype=torch.int32)
             if self._arrived:
-                used[torch.tensor(sorted(self._arrived), device=used.device)] = 1
-            self._handles.append(self.dist.all_reduce(used, op=self.dist.ReduceOp.MAX, async_op=True))
+                used[torch.tensor(sorted(self._arrived))] = 1
+            self.dist.all_reduce(used, op=self.dist.ReduceOp.MAX, **({"group": self._host_group} if self._host_group is not None else {}))
         for h in self._handles:
             h.wait()
         self._handles.clear()
@@ -297,7 +306,7 @@ class BucketedGradReducer:
                 p._grad_slot = None            # a backward outside prepare()/finish() must not write into the buckets
         # parameters no rank produced a gradient for: grad = None (the optimizer skips them), as DDP(find_unused_parameters)
         if used is not None:
-            flags = used.cpu().tolist()            # 4 B per parameter; the optimizer step that follows needs the host anyway
+            flags = used.tolist()                  # (host memory already)
             used_now = {i for i, u in enumerate(flags) if u}
         else:
             used_now = self._arrived               # one rank: nothing to exchange
@@ -362,7 +371,7 @@ class BucketedGradReducer:
         self._hooks.clear()
 
 
-def comm_report(reducer: "BucketedGradReducer", run_step, sync, steps: int = 3) -> dict:
+def comm_report(reducer: "BucketedGradReducer", run_step, sync, steps: int = 3, destructive: bool = False) -> dict:
     """One-shot diagnosis of the gradient exchange of a data-parallel step (bench.py prints it when a process group exists, so the first
     multi-GPU run explains its own scaling number).  Backend-agnostic: nothing here looks inside RCCL.
       per_bucket_ms   each bucket's collective(s) ALONE on its real buffer, nothing else queued (sync-bracketed, MAX over ranks):
@@ -372,8 +381,15 @@ def comm_report(reducer: "BucketedGradReducer", run_step, sync, steps: int = 3) 
       step_ms_no_collectives   the same step with the collectives switched off (every rank steps on its local gradients: the
                       replicas DIVERGE -- the caller re-broadcasts the module state afterwards)
       overlap_frac    (step_ms_no_collectives + comm_alone_ms - step_ms) / comm_alone_ms clamped to [0, 1]: the share of the exchange
-                      that the compute hides; 1 = free, 0 = fully exposed."""
+                      that the compute hides; 1 = free, 0 = fully exposed.
+    DESTRUCTIVE: the no-collective steps are real optimizer steps on rank-local gradients -- parameters, moments and step
+    counters diverge across the ranks, and under "rs_ag" the moment shards keep those updates even after the caller re-broadcasts the
+    module.  The caller has to say so (`destructive=True`) and restore / discard the training state afterwards; a benchmark does, a
+    training loop must not call this."""
     import time
+    if not destructive:
+        raise RuntimeError("comm_report runs optimizer steps without the gradient exchange (the replicas diverge): pass destructive=True "
+                           "from a benchmark that re-broadcasts or discards the training state afterwards")
     dist = reducer.dist
 
     def timed(fn, n):

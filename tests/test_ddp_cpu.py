@@ -301,7 +301,8 @@ RSAG_WORKER = textwrap.dedent("""
     total = sum(b["n"] for b in rb.buckets)
     print(json.dumps(dict(rank=rank, err=err, norm_err=max(abs(x - y) / x for x, y in zip(na, nb)), same=all(torch.equal(gathered[0], g) for g in gathered),
                           owned=owned, total=total, unused_untouched=bool(torch.equal(pb[-1], torch.ones(5))), nbuckets=len(rb.buckets),
-                          kinds=[type(oa).__name__, type(ob).__name__], mom_err=mom_err, n_moments=len(mb), guard=xb)), flush=True)
+                          kinds=[type(oa).__name__, type(ob).__name__], mom_err=mom_err, n_moments=len(mb), guard=xb,
+                          bucket_n=[b["n"] for b in rb.buckets])), flush=True)
     dist.barrier(); dist.destroy_process_group()
 """) % str(ROOT)
 
@@ -325,6 +326,27 @@ def test_reduce_scatter_all_gather_mode_trains_like_the_all_reduce_mode(tmp_path
         # the consolidated moments equal the all-reduce mode's on every rank; state_dict() refused before the consolidation;
         # the guarded forward fenced a gather that was really in flight
         assert d["mom_err"] <= 1e-6 and d["n_moments"] >= 10 and d["guard"]["refused"] and d["guard"]["fenced"] and d["guard"]["pending"] > 0, d
+
+
+def test_reduce_scatter_all_gather_mode_at_world_4_with_buckets_that_need_padding(tmp_path):
+    """the same worker on FOUR ranks.  Its tensors have 67 x 16, 67, 64 x 67, 64, 9 x 64, 9 and 5 elements, so no bucket
+    length is a multiple of 4: every bucket is padded to the world size, shards straddle parameter boundaries, and a rank may own
+    nothing of a small tensor.  Same bars as the two-rank test; every rank owns about a quarter of the elements."""
+    script = tmp_path / "rsag4.py"; script.write_text(RSAG_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29556", WORLD_SIZE="4", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(4)]
+    owned = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-3000:]
+        d = json.loads(o.strip().splitlines()[-1])
+        assert d["err"] <= 1e-6 and d["norm_err"] <= 1e-6 and d["same"] and d["unused_untouched"], d
+        assert d["nbuckets"] >= 3 and abs(d["owned"] - d["total"] / 4) <= d["nbuckets"], d
+        assert any(b % 4 for b in d["bucket_n"]), d            # the point of the test: lengths that are not multiples of the world size
+        assert d["mom_err"] <= 1e-6 and d["guard"]["refused"] and d["guard"]["fenced"], d
+        owned.append(d["owned"])
+    assert sum(owned) == d["total"]                            # the shards partition the elements
 
 
 COMM_WORKER = textwrap.dedent("""
@@ -353,7 +375,7 @@ COMM_WORKER = textwrap.dedent("""
             red.finish(); red.clip_grad_norm_(0.5, defer_to=None if mode == "all_reduce" else opt)
             opt.step(); red.gather_params()
         step()
-        rep = comm_report(red, step, lambda: None, steps=2)
+        rep = comm_report(red, step, lambda: None, steps=2, destructive=True)
         red.wait_params()
         broadcast_module_state(model, dist)
         flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])

@@ -72,6 +72,24 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     assert d["scaling"] == "weak" and d["config"]["parallelism"].startswith("dp2")
 
 
+def test_bench_eight_rank_launch_path():
+    """the launch the driver uses on the 8-GPU node -- `python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8` -- in --dry-cpu mode (gloo, no kernels): eight ranks rendezvous on 127.0.0.1, shard the scenes disjointly, barrier,
+    and rank 0 alone prints the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "8", "--dry-cpu", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = __import__("json").loads(lines[0])
+    assert d["n_gpus"] == 8 and d["launch"]["ranks"] == 8 and d["launch"]["backend"] == "gloo"
+    assert d["config"]["first_scene_seed_per_rank"] == [1234 + 1000 * r for r in range(8)]
+    assert d["config"]["parallelism"].startswith("dp8") and d["dry_cpu"] is True and d["steps"] == 3
+
+
 def test_bench_single_process_line_unchanged_keys():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-cpu", "--steps", "2"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
