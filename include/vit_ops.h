@@ -145,6 +145,13 @@ int vit_split_weight(const float *w, void *packed, int rows, int cols, int trans
 size_t vit_split_weight_block_bytes(int rows, int cols, int transpose);
 int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream);
 /*
+ * The forward image AND the transposed (input-gradient) image of one Linear weight w (rows, cols) in ONE launch -- what a trainable layer
+ * needs again after every optimizer step; the fp32 weight is read once.  block_fwd / block_t: 1 = the block layout of vit_split_weight_block
+ * (size vit_split_weight_block_bytes(rows, cols, 0 / 1)), 0 = the row layout of vit_split_weight (vit_split_weight_bytes).  rows % 8 == 0,
+ * cols % 8 == 0.  f16x3: announce the weight's |max| word first (vit_x6_set_operand_amax(word, NULL)).  Bytes identical to the single calls.
+ */
+int vit_split_weight_pair(const float *w, void *packed_fwd, void *packed_t, int rows, int cols, int block_fwd, int block_t, void *stream);
+/*
  * Every weight image of a model in ONE launch (what an optimizer step invalidates): jobs = device array sorted by first_block, one per image.
  *   kind bit 0: pack w^T (as transpose = 1 above); bit 1: the BLOCK layout of vit_split_weight_block, else the layout of vit_split_weight.
  *   first_block / nbx: the job owns workgroups [first_block, first_block + nbx * ceil(R / 64)), nbx = ceil(Kc / 64), with R x Kc the

@@ -53,6 +53,7 @@ int x6_set_operand_amax(const void *a, const void *b);
 int x6_set_output_amax(void *word);
 int amax(const float *x, int64_t n, void *out, hipStream_t stream);
 int split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
+int split_weight_pair(const float *w, void *packed_f, void *packed_t, int rows, int cols, int block_f, int block_t, hipStream_t stream);
 int split_weights_many(const VitSplitJob *jobs_dev, int njobs, uint32_t total_blocks, hipStream_t stream);
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                    int K, int act, int cfg, hipStream_t stream);
@@ -127,6 +128,11 @@ VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose
 VIT_EXPORT int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
 {
     return vit::split_weight_block(w, packed, rows, cols, transpose, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_split_weight_pair(const float *w, void *packed_fwd, void *packed_t, int rows, int cols, int block_fwd, int block_t, void *stream)
+{
+    return vit::split_weight_pair(w, packed_fwd, packed_t, rows, cols, block_fwd, block_t, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_split_weights_many(const VitSplitJob *jobs_device, int n_jobs, uint32_t total_blocks, void *stream)

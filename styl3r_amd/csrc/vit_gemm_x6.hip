@@ -161,6 +161,9 @@ __device__ inline void split2h(float a, float b, uint32_t &p0, uint32_t &p1)
 // NPROD == 6 / 3: three bf16 pieces (the third unused by 3); NPROD == 2: two fp16 pieces of s * value (q2 is left alone)
 template <int NPROD> __device__ inline void split8s(const float4 &lo, const float4 &hi, float s, uint4 &q0, uint4 &q1, uint4 &q2)
 {
+#ifdef VIT_EXP_NOSPLIT   /* experiment builds only (tools/exp_nosplit.sh): the operand as if it arrived already split -- WRONG results, the same loads / LDS traffic / MFMAs */
+    if (NPROD == 2) { q0 = __builtin_bit_cast(uint4, lo); q1 = __builtin_bit_cast(uint4, hi); return; }
+#endif
     if (NPROD == 2) {
         split2h(lo.x * s, lo.y * s, q0.x, q1.x);
         split2h(lo.z * s, lo.w * s, q0.y, q1.y);

@@ -118,6 +118,9 @@ __device__ inline void split2h(float a, float b, uint32_t &p0, uint32_t &p1)
 }
 template <int NPROD, typename V4> __device__ inline void split8s(const V4 &lo, const V4 &hi, float s, bf16x8 &f0, bf16x8 &f1, bf16x8 &f2)
 {
+#ifdef VIT_EXP_NOSPLIT   /* experiment builds only (tools/exp_nosplit.sh): see vit_gemm_x6.hip */
+    if (NPROD == 2) { f0 = __builtin_bit_cast(bf16x8, lo); f1 = __builtin_bit_cast(bf16x8, hi); return; }
+#endif
     if constexpr (NPROD == 2) {
         uint4 q0, q1;
         split2h(lo.x * s, lo.y * s, q0.x, q1.x);
@@ -700,6 +703,78 @@ __global__ void __launch_bounds__(256) k_split_block(const float *__restrict__ w
         o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
     }
 }
+// BOTH images of one Linear weight in one launch (round 6): the forward image (output rows = rows of w, contraction along its columns) and
+// the transposed one for the input-gradient GEMM (output rows = columns of w), each in the block layout above (flag set) or in the
+// MFMA-order row layout of vit_split_weight (packed[row][k / 8][piece][8]).  After an optimizer step every trainable weight needs both
+// again; one launch per image read the fp32 weight twice and was ~1 270 launches / 12 ms of a 281 ms C3 step, launch-bound.  A workgroup owns
+// a 64 x 64 tile of w: it IS a 64-row x 64-k tile of the forward image and a 64-row x 64-k tile of the transposed one.  Same split
+// function on the same values: the bytes equal the single-image kernels' (tests/test_gpu_vit.py compares them).
+template <int NPROD>
+__global__ void __launch_bounds__(256) k_split_pair(const float *__restrict__ w, uint4 *__restrict__ pf, uint4 *__restrict__ pt, int rows, int cols,
+                                                    int block_f, int block_t, const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail_f,
+                                                    uint32_t *__restrict__ tail_t)
+{
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const uint32_t a = amax[threadIdx.x * AMAX_STRIDE];
+        tail_f[threadIdx.x * AMAX_STRIDE] = a; tail_t[threadIdx.x * AMAX_STRIDE] = a;
+    }
+    const float sw = NPROD == 2 ? f16_scale(amax_line(amax)) : 1.f;
+    __shared__ float s[64][65];                       // [row of w][column of w]
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if ((cols & 3) == 0) {                            // four columns per load (rows of w are 16-byte aligned)
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + r < rows && c0 + c4 < cols) v = *reinterpret_cast<const float4 *>(w + (int64_t)(r0 + r) * cols + c0 + c4);
+            s[r][c4] = v.x; s[r][c4 + 1] = v.y; s[r][c4 + 2] = v.z; s[r][c4 + 3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            s[r][c] = (r0 + r < rows && c0 + c < cols) ? w[(int64_t)(r0 + r) * cols + c0 + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- forward image: output row = row of w, k = column of w ----
+    {
+        const int KG = cols >> 3;
+        for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+            const int kg = block_f ? (i >> 6) : (i & 7), r = block_f ? (i & 63) : (i >> 3);
+            if (c0 + kg * 8 >= cols) continue;
+            const float4 lo = make_float4(s[r][kg * 8 + 0], s[r][kg * 8 + 1], s[r][kg * 8 + 2], s[r][kg * 8 + 3]);
+            const float4 hi = make_float4(s[r][kg * 8 + 4], s[r][kg * 8 + 5], s[r][kg * 8 + 6], s[r][kg * 8 + 7]);
+            bf16x8 f0, f1, f2;
+            split8s<NPROD>(lo, hi, sw, f0, f1, f2);
+            if (block_f) {
+                uint4 *o = pf + (((int64_t)blockIdx.y * KG + (c0 >> 3) + kg) * 3) * 64 + r;
+                o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
+            } else if (r0 + r < rows) {
+                uint4 *o = pf + ((int64_t)(r0 + r) * KG + (c0 >> 3) + kg) * 3;
+                o[0] = __builtin_bit_cast(uint4, f0); o[1] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[2] = __builtin_bit_cast(uint4, f2);
+            }
+        }
+    }
+    // ---- transposed image: output row = column of w, k = row of w ----
+    {
+        const int KG = rows >> 3;
+        for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+            const int rg = block_t ? (i >> 6) : (i & 7), c = block_t ? (i & 63) : (i >> 3);
+            if (r0 + rg * 8 >= rows) continue;
+            const float4 lo = make_float4(s[rg * 8 + 0][c], s[rg * 8 + 1][c], s[rg * 8 + 2][c], s[rg * 8 + 3][c]);
+            const float4 hi = make_float4(s[rg * 8 + 4][c], s[rg * 8 + 5][c], s[rg * 8 + 6][c], s[rg * 8 + 7][c]);
+            bf16x8 f0, f1, f2;
+            split8s<NPROD>(lo, hi, sw, f0, f1, f2);
+            if (block_t) {
+                uint4 *o = pt + (((int64_t)blockIdx.x * KG + (r0 >> 3) + rg) * 3) * 64 + c;
+                o[0] = __builtin_bit_cast(uint4, f0); o[64] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[128] = __builtin_bit_cast(uint4, f2);
+            } else if (c0 + c < cols) {
+                uint4 *o = pt + ((int64_t)(c0 + c) * KG + (r0 >> 3) + rg) * 3;
+                o[0] = __builtin_bit_cast(uint4, f0); o[1] = __builtin_bit_cast(uint4, f1); if (NPROD != 2) o[2] = __builtin_bit_cast(uint4, f2);
+            }
+        }
+    }
+}
+
 // All the weight images of a model in ONE launch (after an optimizer step every weight changed: the per-weight launches above were
 // 1 274 launches and 12 ms of a 285 ms train step at 1.4 TB/s -- launch-bound).  A job = one image of one weight; a workgroup = one
 // 64-row x 64-k tile of one job (binary search over the jobs' first-block table), staged through LDS exactly as k_split_block does, then
@@ -762,6 +837,31 @@ int split_weights_many(const VitSplitJob *jobs_dev, int njobs, uint32_t total_bl
     if (np == 2) hipLaunchKernelGGL(x6r::k_split_many<2>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
     else if (np == 3) hipLaunchKernelGGL(x6r::k_split_many<3>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
     else hipLaunchKernelGGL(x6r::k_split_many<6>, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, njobs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+// both images of a Linear weight (rows x cols) in one launch: see k_split_pair.  block_f / block_t: the block layout (1) or the row layout (0)
+// of the forward / the transposed image; sizes as vit_split_weight_block_bytes / vit_split_weight_bytes say.
+int split_weight_pair(const float *w, void *packed_f, void *packed_t, int rows, int cols, int block_f, int block_t, hipStream_t stream)
+{
+    if (!w || !packed_f || !packed_t || rows <= 0 || cols <= 0 || (rows % 8) != 0 || (cols % 8) != 0) return VIT_EINVAL;
+    (void)hipGetLastError();
+    const uint32_t *am, *unused;
+    x6_take_amax(am, unused);
+    auto tail_of = [](void *p, int R_, int K_, int block) {
+        const size_t pieces = block ? (size_t)((R_ + 63) / 64) * 64 * (size_t)K_ * 6 : (size_t)R_ * (size_t)K_ * 6;
+        return reinterpret_cast<uint32_t *>(static_cast<char *>(p) + pieces);
+    };
+    uint32_t *tf = tail_of(packed_f, rows, cols, block_f), *tt = tail_of(packed_t, cols, rows, block_t);
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    const int np = x6_products();
+    if (np == 2) {
+        if (!am) return VIT_EINVAL;        // f16x3: the weight's |max| word must be announced (vit_x6_set_operand_amax(word, NULL))
+        hipLaunchKernelGGL(x6r::k_split_pair<2>, grid, dim3(256), 0, stream, w, static_cast<uint4 *>(packed_f), static_cast<uint4 *>(packed_t), rows, cols, block_f, block_t, am, tf, tt);
+    } else
+        hipLaunchKernelGGL(x6r::k_split_pair<6>, grid, dim3(256), 0, stream, w, static_cast<uint4 *>(packed_f), static_cast<uint4 *>(packed_t), rows, cols, block_f, block_t, am, tf, tt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

@@ -273,10 +273,12 @@ class AsymmetricCroCoMulti(CrocoTrunk):
             else:
                 cur = self.decoder_embed(x)
         st = SimpleNamespace(b=b, v=v, l=l, f1=cur[:, 0].contiguous(), f2=cur[:, 1:].reshape(b * (v - 1), l, -1),
-                             p1=pos[:, 0].contiguous(), p2=pos[:, 1:].reshape(b * (v - 1), l, 2),
-                             pm1=pos[:, 1:].reshape(b, (v - 1) * l, 2),                    # memory positions of view 0
+                             # (contiguous ONCE here: a strided position view was copied by every attention call of the 24 decoder
+                             #  blocks, forward and backward -- ~100 of the step's framework copy launches)
+                             p1=pos[:, 0].contiguous(), p2=pos[:, 1:].reshape(b * (v - 1), l, 2).contiguous(),
+                             pm1=pos[:, 1:].reshape(b, (v - 1) * l, 2).contiguous(),       # memory positions of view 0
                              outs=[(feat[:, 0], feat[:, 1:].reshape(b * (v - 1), l, c))])
-        st.pm2 = self._mem_of_rest(st, st.p1, st.p2, 2)
+        st.pm2 = self._mem_of_rest(st, st.p1, st.p2, 2).contiguous()
         return st
 
     @staticmethod
@@ -394,7 +396,8 @@ class TokenStylizer(CrocoTrunk):
         b, v, l, c = content_feat.shape
         outs = [content_feat]
         cf = _linear(self.decoder_embed, content_feat.reshape(b, v * l, c))
-        cpos = content_pos.reshape(b, v * l, 2)
+        cpos = content_pos.reshape(b, v * l, 2).contiguous()
+        spos = spos.contiguous()
         for blk in self.dec_blocks:
             cf, _ = blk(cf, style_feat, cpos, spos)
             outs.append(cf.view(b, v, l, -1))

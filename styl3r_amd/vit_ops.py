@@ -39,7 +39,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / os.environ.get("VIT_LIB_NAME", "libvit_hip.so")     # VIT_LIB_NAME: kernel-experiment builds (tools/ only); the product is libvit_hip.so
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -52,7 +52,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     names = [s for s in _SOURCES if (_CSRC / s).exists()]
     srcs = [_CSRC / s for s in names]
     deps = srcs + [(_PKG.parent / "include" / "vit_ops.h")]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *names, "-o", LIB_PATH.name]
+    extra = os.environ.get("VIT_HIPCC_EXTRA", "").split()          # kernel-experiment builds (tools/ only, with VIT_LIB_NAME)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", *extra, *names, "-o", LIB_PATH.name]
     want = sources_digest(deps, cmd)
     stamp = LIB_PATH.with_suffix(".stamp")
     if not force and LIB_PATH.exists() and stamp.exists() and stamp.read_text().strip() == want:
@@ -65,7 +66,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     from concurrent.futures import ThreadPoolExecutor
     objdir = _PKG.parent / "build" / "obj"
     objdir.mkdir(parents=True, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", *extra]
     headers = sorted(_CSRC.glob("*.h")) + [(_PKG.parent / "include" / "vit_ops.h")]
     hdig = hashlib.sha256(b"".join(h.read_bytes() for h in headers) + " ".join(flags).encode()).hexdigest()
 
@@ -73,8 +74,9 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         dig = hashlib.sha256((_CSRC / name).read_bytes() + hdig.encode()).hexdigest()[:16]
         obj = objdir / f"{Path(name).stem}.{dig}.o"
         if not obj.exists() or force:
-            for stale in objdir.glob(f"{Path(name).stem}.*.o"):
-                stale.unlink()
+            if not extra:       # (experiment objects live beside the product's)
+                for stale in objdir.glob(f"{Path(name).stem}.*.o"):
+                    stale.unlink()
             c = [hipcc, *flags, "-c", name, "-o", str(obj)]
             if verbose:
                 print(" ".join(c), flush=True)
@@ -147,6 +149,8 @@ def load() -> C.CDLL:
     lib.vit_split_weight_block_bytes.restype = C.c_size_t
     lib.vit_split_weight_block.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight_block.restype = C.c_int
+    lib.vit_split_weight_pair.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_split_weight_pair.restype = C.c_int
     lib.vit_split_weights_many.argtypes = [vp, C.c_int, C.c_uint32, vp]
     lib.vit_split_weights_many.restype = C.c_int
     lib.vit_linear_x6c_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
@@ -716,6 +720,44 @@ def refresh_split_cache(params) -> int:
     return len(jobs)
 
 
+PAIR_SPLIT = os.environ.get("VIT_PAIR_SPLIT", "1") == "1"      # A/B switch: 0 = one launch per weight image (rounds 2-5)
+
+
+def _image_key(weight: Tensor, block: bool, transposed: bool) -> tuple:
+    if block:
+        return (id(weight), "block_t" if transposed else "block") + (("f16",) if _f16() else ())
+    return (id(weight), transposed, "f16") if _f16() else (id(weight), transposed)
+
+
+def _fresh(hit, weight: Tensor) -> bool:
+    return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
+
+
+def split_weight_pair(weight: Tensor, block_fwd: bool, block_t: bool) -> None:
+    """Both images of a Linear weight (N,K) -- the forward one and the transposed one its input-gradient GEMM will ask for -- in ONE launch
+    (vit_split_weight_pair), each in the layout its kernel wants (block: the LDS-DMA ring kernels; row: vit_linear_x6_fwd).  Called by the
+    forward of a layer whose input needs a gradient when the forward image is stale (i.e. once per optimizer step and weight): the
+    backward then finds its image in the cache.  Entries are the same as the single-image functions write."""
+    lib = load()
+    N, K = weight.shape
+    w = weight.detach().contiguous().float()
+    keys = (_image_key(weight, block_fwd, False), _image_key(weight, block_t, True))
+    sizes = (lib.vit_split_weight_block_bytes(N, K, 0) if block_fwd else lib.vit_split_weight_bytes(N, K),
+             lib.vit_split_weight_block_bytes(N, K, 1) if block_t else lib.vit_split_weight_bytes(N, K))
+    bufs = []
+    for key, nbytes in zip(keys, sizes):
+        hit = _SPLIT_CACHE.get(key)
+        reuse = hit is not None and hit[0]() is weight and hit[3].numel() == nbytes
+        bufs.append(hit[3] if reuse else torch.empty(nbytes, dtype=torch.uint8, device=weight.device))
+    if _f16():
+        _announce(_weight_amax_word(weight, w))
+    _check(lib.vit_split_weight_pair(w.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), N, K, 1 if block_fwd else 0, 1 if block_t else 0,
+                                     _stream(weight.device)), "vit_split_weight_pair")
+    CALLS["split_pair"] += 1
+    for key, buf in zip(keys, bufs):
+        _SPLIT_CACHE[key] = (_dead_entry_ref(weight, key), weight._version, weight.data_ptr(), buf)
+
+
 def split_weight_block(weight: Tensor, transposed: bool = False) -> Tensor:
     """bf16x3 split of a weight (N,K) in the BLOCK layout of csrc/vit_gemm_x6r.hip (vit_split_weight_block; rows padded to a
     multiple of 64 with zeros).  Cached like `split_weight` (weak reference + version counter)."""
@@ -837,7 +879,7 @@ CALLS = {"linear_x6r": 0, "conv_wgrad_via_linear": 0, "head_tail": 0, "input_mer
          # library / framework routes taken ON DEVICE TENSORS (layers the hand-written kernels do not cover): the end-to-end tests assert that every one of them stays at zero
          "library_conv_fwd": 0, "library_conv_bwd": 0, "framework_upsample": 0, "framework_dropout": 0, "framework_linear": 0,
          "input_merger_library": 0,
-         "amax_pass": 0, "amax_published": 0, "split_many_images": 0, "split_plan_reused": 0}     # f16x3: activation |max| words from a vit_amax pass / from the producing kernel's epilogue     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
+         "amax_pass": 0, "amax_published": 0, "split_many_images": 0, "split_plan_reused": 0, "split_pair": 0}     # f16x3: activation |max| words from a vit_amax pass / from the producing kernel's epilogue     # (the 7x7 input merger on the library: only when the IMAGE needs a gradient, i.e. in parity tests)
 LIBRARY_ROUTES = ("library_conv_fwd", "library_conv_bwd", "framework_upsample", "framework_dropout", "layernorm_framework")
 
 
@@ -1291,6 +1333,11 @@ class _FusedLinear(torch.autograd.Function):
             if publish:
                 link.ax = _AMAX.word(x2.device)
                 _check(load().vit_x6_set_output_amax(link.ax.data_ptr()), "vit_x6_set_output_amax")
+        if x6 and PAIR_SPLIT and x.requires_grad and N % 16 == 0 and K % 8 == 0 and not _fresh(_SPLIT_CACHE.get(_image_key(weight, bool(ring), False)), weight):
+            # the forward image is stale (the optimizer stepped): the backward's input-gradient GEMM will need the transposed image of the
+            # same values -- both in one launch, each in the layout its kernel takes (the dX dispatch rule of `backward` below)
+            ring_dx = _ring_cfg(M, K, N) if LINEAR_MODE in ("bf16x3", "f16x3") else 0
+            split_weight_pair(weight, bool(ring), bool(ring_dx))
         if ring:
             # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
             # tools/probes/gemm_lab.py measured them faster (per arithmetic mode: _RING_SHAPES)

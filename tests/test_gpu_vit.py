@@ -1116,3 +1116,59 @@ def test_batched_weight_resplit_equals_the_single_weight_images(mode, monkeypatc
     finally:
         vit_ops.LINEAR_MODE = "bf16x6"
         vit_ops._x6()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "bf16x3"])
+def test_pair_split_equals_the_single_image_kernels_and_feeds_the_backward(mode, monkeypatch):
+    """vit_split_weight_pair (round 6: the forward AND the transposed image of a Linear weight from one read of the weight, what a
+    trainable layer's forward launches when the optimizer has stepped) writes the bytes of the single-image kernels in all four layout
+    combinations, ragged row counts included; a fused Linear whose images came from it gives the outputs and gradients of the
+    one-launch-per-image path bit for bit, and its backward launches no split kernel of its own."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    vit_ops._x6()
+    g = torch.Generator(DEV).manual_seed(11)
+    try:
+        for (N, K) in [(3072, 1024), (200, 72), (64, 136), (768, 1024), (1000, 64)]:
+            for block_f in (False, True):
+                for block_t in (False, True):
+                    w = torch.nn.Parameter(torch.randn(N, K, device=DEV, generator=g) * 0.3)
+                    vit_ops.split_weight_pair(w, block_f, block_t)
+                    got = [(vit_ops.split_weight_block if block_f else vit_ops.split_weight)(w, False),
+                           (vit_ops.split_weight_block if block_t else vit_ops.split_weight)(w, True)]          # cache hits
+                    w2 = torch.nn.Parameter(w.detach().clone())
+                    monkeypatch.setattr(vit_ops, "PAIR_SPLIT", False)
+                    ref = [(vit_ops.split_weight_block if block_f else vit_ops.split_weight)(w2, False),
+                           (vit_ops.split_weight_block if block_t else vit_ops.split_weight)(w2, True)]
+                    monkeypatch.setattr(vit_ops, "PAIR_SPLIT", True)
+                    torch.cuda.synchronize()
+                    for li, (a, b, block) in enumerate(zip(got, ref, (block_f, block_t))):
+                        R, Kc = (K, N) if li else (N, K)
+                        body = ((R + 63) // 64 * 64 if block else R) * Kc * 6
+                        pa, pb = a[:body].view(-1, 16), b[:body].view(-1, 16)
+                        pa, pb = (pa.view(-1, 3, 64, 16), pb.view(-1, 3, 64, 16)) if block else (pa.view(-1, 3, 16), pb.view(-1, 3, 16))
+                        pieces = 2 if mode == "f16x3" else 3
+                        assert torch.equal(pa[:, :pieces], pb[:, :pieces]), (mode, (N, K), block_f, block_t, li)
+                        if mode == "f16x3":
+                            assert torch.equal(a[body:body + 8192].view(torch.int32)[::32], b[body:body + 8192].view(torch.int32)[::32]), "tail"
+        # through the layer: M = 5 140 rows takes the ring kernels (block images) where the shape is in the table
+        M, N, K = 5140, 3072, 1024
+        x0 = torch.randn(M, K, device=DEV, generator=g)
+        w0 = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+        outs = []
+        for pair in (True, False):
+            monkeypatch.setattr(vit_ops, "PAIR_SPLIT", pair)
+            x = x0.clone().requires_grad_(True); w = torch.nn.Parameter(w0.clone())
+            n0 = vit_ops.CALLS["split_pair"]
+            y = vit_ops.fused_linear(x, w)
+            assert (vit_ops.CALLS["split_pair"] - n0) == (1 if pair else 0)
+            keys = len(vit_ops._SPLIT_CACHE)
+            y.square().sum().backward()
+            if pair:
+                assert len(vit_ops._SPLIT_CACHE) == keys            # the backward found its image: no new entry, no split launch
+            outs.append((y.detach(), x.grad, w.grad))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # same images -> same bits
+        assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5 * float(outs[1][2].abs().max())  # (dW: split-M atomics arrive in any order)
+    finally:
+        vit_ops.LINEAR_MODE = "bf16x6"
+        vit_ops._x6()
