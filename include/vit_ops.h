@@ -152,6 +152,13 @@ int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int
  */
 int vit_split_weight_pair(const float *w, void *packed_fwd, void *packed_t, int rows, int cols, int block_fwd, int block_t, void *stream);
 /*
+ * The operand images of a convolution weight w (Co, Ci, k, k), k in {1, 3}, straight from the parameter in ONE launch: packed_fwd = the image
+ * vit_conv_x6_fwd takes for the forward (vit_split_weight_bytes(Co, k*k*Ci)); packed_dx (nullable) = the image of the spatially flipped,
+ * channel-transposed weight the same entry takes for the input gradient (vit_split_weight_bytes(Ci, k*k*Co)).  Ci % 8 == 0 (and Co % 8 == 0
+ * with packed_dx).  Bytes identical to vit_split_weight on the rearranged copies.  f16x3: announce the weight's |max| word first.
+ */
+int vit_split_conv_weight_pair(const float *w, void *packed_fwd, void *packed_dx, int Co, int Ci, int ksize, void *stream);
+/*
  * Every weight image of a model in ONE launch (what an optimizer step invalidates): jobs = device array sorted by first_block, one per image.
  *   kind bit 0: pack w^T (as transpose = 1 above); bit 1: the BLOCK layout of vit_split_weight_block, else the layout of vit_split_weight.
  *   first_block / nbx: the job owns workgroups [first_block, first_block + nbx * ceil(R / 64)), nbx = ceil(Kc / 64), with R x Kc the

@@ -14,6 +14,7 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
 int linear_fwd(const float *x, const float *w, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                int K, int act, hipStream_t stream);
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream);
+int split_conv_weight_pair(const float *w, void *packed_fwd, void *packed_dx, int Co, int Ci, int ksize, hipStream_t stream);
 int conv_x6_fwd(const float *in, const void *wp, const float *bias, const float *residual, float *out, int B, int Ci, int Co,
                 int H, int W, int ksize, int relu_in, hipStream_t stream);
 int conv_x6_wgrad(const float *dy, const float *in, float *dw, float *dbias, int B, int Ci, int Co, int H, int W, int ksize,
@@ -128,6 +129,11 @@ VIT_EXPORT size_t vit_split_weight_block_bytes(int rows, int cols, int transpose
 VIT_EXPORT int vit_split_weight_block(const float *w, void *packed, int rows, int cols, int transpose, void *stream)
 {
     return vit::split_weight_block(w, packed, rows, cols, transpose, static_cast<hipStream_t>(stream));
+}
+
+VIT_EXPORT int vit_split_conv_weight_pair(const float *w, void *packed_fwd, void *packed_dx, int Co, int Ci, int ksize, void *stream)
+{
+    return vit::split_conv_weight_pair(w, packed_fwd, packed_dx, Co, Ci, ksize, static_cast<hipStream_t>(stream));
 }
 
 VIT_EXPORT int vit_split_weight_pair(const float *w, void *packed_fwd, void *packed_t, int rows, int cols, int block_fwd, int block_t, void *stream)

@@ -1099,6 +1099,62 @@ __global__ void __launch_bounds__(256) k_split_transposed(const float *__restric
     uint4 *o = packed + ((int64_t)(c0 + c) * (rows >> 3) + (r0 >> 3) + kg) * 3;
     o[0] = q0; o[1] = q1; if (NPROD != 2) o[2] = q2;
 }
+
+// Both operand images of a convolution weight w (Co, Ci, k, k) straight from the parameter, in ONE launch (round 6; before: a permute + clone, a
+// flip, a second permute + clone and two k_split_rows launches per weight and optimizer step -- ~290 framework copy launches of a C3 step):
+//   forward image  rows = co, column = tap * Ci + ci               value w[co][ci][tap]                 (vit_conv_x6_fwd's weight)
+//   dX image       rows = ci, column = tap * Co + co               value w[co][ci][k*k - 1 - tap]       (spatially flipped, channel-transposed)
+// both in the row layout of vit_split_weight.  A workgroup owns 16 output channels x 16 input channels x all taps: each of the two images'
+// 8-wide k groups (8 consecutive ci at one (co, tap) / 8 consecutive co at one (ci, tap)) lies inside it.  pdx may be null (forward image only).
+constexpr int CW_T = 16, CW_TAPS_MAX = 9;
+template <int NPROD>
+__global__ void __launch_bounds__(256) k_split_conv_pair(const float *__restrict__ w, uint4 *__restrict__ pf, uint4 *__restrict__ pdx, int Co, int Ci, int kk,
+                                                         const uint32_t *__restrict__ amax, uint32_t *__restrict__ tail_f, uint32_t *__restrict__ tail_dx)
+{
+    if (NPROD == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const uint32_t a = amax[threadIdx.x * AMAX_STRIDE];
+        tail_f[threadIdx.x * AMAX_STRIDE] = a;
+        if (pdx) tail_dx[threadIdx.x * AMAX_STRIDE] = a;
+    }
+    const float sw = NPROD == 2 ? f16_scale(amax_line(amax)) : 1.f;
+    __shared__ float s[CW_T][CW_T * CW_TAPS_MAX + 1];            // [co][ci * kk + tap]
+    const int co0 = blockIdx.y * CW_T, ci0 = blockIdx.x * CW_T, run = CW_T * kk;
+    for (int i = threadIdx.x; i < CW_T * run; i += 256) {         // per co: CW_T * kk contiguous floats
+        const int co = i / run, e = i - co * run;
+        const int ci = e / kk;
+        s[co][e] = (co0 + co < Co && ci0 + ci < Ci) ? w[((int64_t)(co0 + co) * Ci + ci0) * kk + e] : 0.f;
+    }
+    __syncthreads();
+    const int items = CW_T * kk * (CW_T / 8);
+    {   // forward image
+        const int KG = (kk * Ci) >> 3;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int cg = i % (CW_T / 8), t = (i / (CW_T / 8)) % kk, co = i / ((CW_T / 8) * kk);
+            if (co0 + co >= Co || ci0 + cg * 8 >= Ci) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s[co][(cg * 8 + j) * kk + t];
+            uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
+            split8s<NPROD>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, q0, q1, q2);
+            uint4 *o = pf + ((int64_t)(co0 + co) * KG + ((t * Ci + ci0) >> 3) + cg) * 3;
+            o[0] = q0; o[1] = q1; if (NPROD != 2) o[2] = q2;
+        }
+    }
+    if (pdx) {   // input-gradient image
+        const int KG = (kk * Co) >> 3;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int cg = i % (CW_T / 8), t = (i / (CW_T / 8)) % kk, ci = i / ((CW_T / 8) * kk);
+            if (ci0 + ci >= Ci || co0 + cg * 8 >= Co) continue;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s[cg * 8 + j][ci * kk + (kk - 1 - t)];
+            uint4 q0, q1, q2 = make_uint4(0, 0, 0, 0);
+            split8s<NPROD>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), sw, q0, q1, q2);
+            uint4 *o = pdx + ((int64_t)(ci0 + ci) * KG + ((t * Co + co0) >> 3) + cg) * 3;
+            o[0] = q0; o[1] = q1; if (NPROD != 2) o[2] = q2;
+        }
+    }
+}
 }  // namespace x6
 
 // Partial products per bf16x6 kernel launch: 6 (default, fp32 round-off accuracy) or 3 ("bf16x3": a0 b0 + a0 b1 + a1 b0, operands
@@ -1165,6 +1221,28 @@ static int split_count(int tiles, int nslab, int min_slabs)
         if (score > best_score) { best_score = score; best = S; }
     }
     return best;
+}
+
+// the two images of a convolution weight (Co, Ci, k, k), k in {1, 3}: see k_split_conv_pair.  packed_dx may be null.  Ci % 8 == 0; with a dX image
+// also Co % 8 == 0.  f16x3: the weight's |max| word must be announced (vit_x6_set_operand_amax(word, NULL)).
+int split_conv_weight_pair(const float *w, void *packed_fwd, void *packed_dx, int Co, int Ci, int ksize, hipStream_t stream)
+{
+    if (!w || !packed_fwd || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3) || (Ci % 8) != 0 || (packed_dx && (Co % 8) != 0)) return VIT_EINVAL;
+    (void)hipGetLastError();
+    const int kk = ksize * ksize;
+    const uint32_t *am, *unused;
+    take_amax(am, unused);
+    uint32_t *tf = const_cast<uint32_t *>(weight_amax(packed_fwd, Co, kk * Ci));
+    uint32_t *td = packed_dx ? const_cast<uint32_t *>(weight_amax(packed_dx, Ci, kk * Co)) : nullptr;
+    const dim3 grid((Ci + x6::CW_T - 1) / x6::CW_T, (Co + x6::CW_T - 1) / x6::CW_T);
+    if (x6_products() == 2) {
+        if (!am) return VIT_EINVAL;
+        hipLaunchKernelGGL(x6::k_split_conv_pair<2>, grid, dim3(256), 0, stream, w, static_cast<uint4 *>(packed_fwd), static_cast<uint4 *>(packed_dx), Co, Ci, kk, am, tf, td);
+    } else
+        hipLaunchKernelGGL(x6::k_split_conv_pair<6>, grid, dim3(256), 0, stream, w, static_cast<uint4 *>(packed_fwd), static_cast<uint4 *>(packed_dx), Co, Ci, kk, am, tf, td);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
 }
 
 int split_weight(const float *w, void *packed, int rows, int cols, int transpose, hipStream_t stream)

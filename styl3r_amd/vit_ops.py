@@ -39,7 +39,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / os.environ.get("VIT_LIB_NAME", "libvit_hip.so")     # VIT_LIB_NAME: kernel-experiment builds (tools/ only); the product is libvit_hip.so
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_conv_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -151,6 +151,8 @@ def load() -> C.CDLL:
     lib.vit_split_weight_block.restype = C.c_int
     lib.vit_split_weight_pair.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_split_weight_pair.restype = C.c_int
+    lib.vit_split_conv_weight_pair.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_split_conv_weight_pair.restype = C.c_int
     lib.vit_split_weights_many.argtypes = [vp, C.c_int, C.c_uint32, vp]
     lib.vit_split_weights_many.restype = C.c_int
     lib.vit_linear_x6c_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
@@ -820,17 +822,37 @@ def split_weight(weight: Tensor, transposed: bool = False) -> Tensor:
     return packed
 
 
-def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
+def split_conv_weight(weight: Tensor, for_input_grad: bool = False, want_dx: bool = False) -> Tensor:
     """bf16x3 split of a conv weight (Co,Ci,k,k) rearranged for vit_conv_x6_fwd: (Co, k*k*Ci) with k index = tap*Ci + ci;
     `for_input_grad`: the spatially flipped, channel-transposed weight (Ci, k*k*Co) whose convolution with dY is dX.
-    Cached like `split_weight` (weak reference + version counter of the ORIGINAL parameter)."""
+    Cached like `split_weight` (weak reference + version counter of the ORIGINAL parameter).
+    Round 6: 1x1 / 3x3 weights are rearranged and split by ONE kernel straight from the parameter (vit_split_conv_weight_pair) -- and when
+    the forward finds its image stale and says its input needs a gradient (`want_dx`), the dX image comes out of the same launch."""
     key = (id(weight), "conv_dx" if for_input_grad else "conv") + (("f16",) if _f16() else ())
     hit = _SPLIT_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
     lib = load()
+    Co, Ci, kh, kw = weight.shape
+    if PAIR_SPLIT and kh == kw and kh in (1, 3) and Ci % 8 == 0 and weight.dtype == torch.float32 and weight.is_contiguous():
+        both = (want_dx or for_input_grad) and Co % 8 == 0
+        if for_input_grad and not both:
+            pass            # (a dX image of a weight whose Co is not a multiple of 8: the rearranged-copy path below)
+        else:
+            w = weight.detach()
+            kf, kd = (id(weight), "conv") + (("f16",) if _f16() else ()), (id(weight), "conv_dx") + (("f16",) if _f16() else ())
+            pf = torch.empty(lib.vit_split_weight_bytes(Co, kh * kw * Ci), dtype=torch.uint8, device=weight.device)
+            pd = torch.empty(lib.vit_split_weight_bytes(Ci, kh * kw * Co), dtype=torch.uint8, device=weight.device) if both else None
+            if _f16():
+                _announce(_weight_amax_word(weight, w))
+            _check(lib.vit_split_conv_weight_pair(w.data_ptr(), pf.data_ptr(), pd.data_ptr() if pd is not None else None, Co, Ci, kh,
+                                                  _stream(weight.device)), "vit_split_conv_weight_pair")
+            CALLS["split_pair"] += 1
+            _SPLIT_CACHE[kf] = (_dead_entry_ref(weight, kf), weight._version, weight.data_ptr(), pf)
+            if pd is not None:
+                _SPLIT_CACHE[kd] = (_dead_entry_ref(weight, kd), weight._version, weight.data_ptr(), pd)
+            return pd if for_input_grad else pf
     w = weight.detach().float()
-    Co, Ci, kh, kw = w.shape
     if for_input_grad:
         w2 = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Ci, kh * kw * Co).contiguous()
     else:
@@ -845,13 +867,14 @@ def split_conv_weight(weight: Tensor, for_input_grad: bool = False) -> Tensor:
 
 
 def conv_x6_forward(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-                    relu_in: bool = False, packed: Optional[Tensor] = None, amax: Optional[Tensor] = None, publish: bool = False) -> Tensor:
+                    relu_in: bool = False, packed: Optional[Tensor] = None, amax: Optional[Tensor] = None, publish: bool = False,
+                    want_dx: bool = False) -> Tensor:
     """out = [residual +] bias + conv2d(relu?(x), weight, padding=k//2) on vit_conv_x6_fwd (no autograd)."""
     B, Ci, H, W = x.shape
     Co, _, k, _ = weight.shape
     x = x.contiguous().float()
     out = torch.empty((B, Co, H, W), dtype=torch.float32, device=x.device)
-    wp = packed if packed is not None else split_conv_weight(weight)
+    wp = packed if packed is not None else split_conv_weight(weight, want_dx=want_dx)
     res = residual.contiguous().float() if residual is not None else None
     if _f16():
         _announce(amax if amax is not None else _amax_of(x))        # (relu_in: |max| of x bounds |max| of relu(x))
@@ -907,7 +930,9 @@ class _ConvX6(torch.autograd.Function):
         ctx.ax = _amax_of(x) if _f16() else None               # f16x3: the input's |max|, shared with the weight-gradient launch
         # (the 3x3 halo kernel publishes its output's |max| from the epilogue: the next convolution of a residual unit / head needs no pass)
         k_, W_ = weight.shape[2], x.shape[3]
-        return conv_x6_forward(x, weight, bias, residual, relu_in, amax=ctx.ax, publish=(k_ == 3 and W_ >= 32))
+        # (its input needs a gradient and the dX GEMM will take the own kernel: a stale forward image is rebuilt together with the dX image)
+        want_dx = bool(ctx.needs_input_grad[0]) and weight.shape[0] % 16 == 0 and weight.shape[1] >= _CONV_X6_MIN_ROWS
+        return conv_x6_forward(x, weight, bias, residual, relu_in, amax=ctx.ax, publish=(k_ == 3 and W_ >= 32), want_dx=want_dx)
 
     @staticmethod
     def backward(ctx, g):

@@ -1172,3 +1172,48 @@ def test_pair_split_equals_the_single_image_kernels_and_feeds_the_backward(mode,
     finally:
         vit_ops.LINEAR_MODE = "bf16x6"
         vit_ops._x6()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_conv_weight_pair_split_equals_the_rearranged_copy_path(mode, monkeypatch):
+    """vit_split_conv_weight_pair (round 6) builds the forward and the input-gradient image of a 1x1 / 3x3 convolution weight straight from the
+    (Co, Ci, k, k) parameter; the round-2..5 path made a permuted copy (and a flipped, channel-transposed one) and split those.  Same bytes,
+    channel counts that are not multiples of the kernel's 16 x 16 tile included; and a ReLU-fused convolution run on either path gives the same
+    outputs and input gradients."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", mode)
+    vit_ops._x6()
+    g = torch.Generator(DEV).manual_seed(23)
+    try:
+        for (Co, Ci, k) in [(256, 256, 3), (128, 96, 3), (24, 40, 3), (256, 256, 1), (32, 136, 1), (8, 8, 3)]:
+            w = torch.nn.Parameter(torch.randn(Co, Ci, k, k, device=DEV, generator=g) * 0.1)
+            monkeypatch.setattr(vit_ops, "PAIR_SPLIT", True)
+            n0 = vit_ops.CALLS["split_pair"]
+            a_f = vit_ops.split_conv_weight(w, False, want_dx=True)
+            a_d = vit_ops.split_conv_weight(w, True)
+            assert vit_ops.CALLS["split_pair"] - n0 == 1                   # one launch made both
+            w2 = torch.nn.Parameter(w.detach().clone())
+            monkeypatch.setattr(vit_ops, "PAIR_SPLIT", False)
+            b_f, b_d = vit_ops.split_conv_weight(w2, False), vit_ops.split_conv_weight(w2, True)
+            torch.cuda.synchronize()
+            pieces = 2 if mode == "f16x3" else 3
+            for a, b, (R, Kc) in ((a_f, b_f, (Co, k * k * Ci)), (a_d, b_d, (Ci, k * k * Co))):
+                body = R * Kc * 6
+                assert torch.equal(a[:body].view(-1, 3, 16)[:, :pieces], b[:body].view(-1, 3, 16)[:, :pieces]), (mode, Co, Ci, k)
+                if mode == "f16x3":     # (the |max| pass ran over differently ordered copies: the 64 slots differ, their maximum -- the scale -- does not)
+                    assert int(a[body:body + 8192].view(torch.int32)[::32].max()) == int(b[body:body + 8192].view(torch.int32)[::32].max())
+        x0 = torch.randn(2, 256, 32, 32, device=DEV, generator=g)
+        w0 = torch.randn(256, 256, 3, 3, device=DEV, generator=g) * 0.02
+        res = []
+        for pair in (True, False):
+            monkeypatch.setattr(vit_ops, "PAIR_SPLIT", pair)
+            x = x0.clone().requires_grad_(True); w = torch.nn.Parameter(w0.clone())
+            y = vit_ops._ConvX6.apply(x, w, None, None, True)
+            y.square().sum().backward()
+            res.append((y.detach(), x.grad))
+        # (2 x 32 x 32 pixels = 32 output tiles: the kernel splits K across workgroups and adds with atomics -- equal up to their arrival order)
+        for a, b in zip(res[0], res[1]):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    finally:
+        vit_ops.LINEAR_MODE = "bf16x6"
+        vit_ops._x6()
