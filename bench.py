@@ -576,7 +576,7 @@ def train_leg(args, rank, world, dev, dist):
            "data": "synthetic, random-init weights",
            "encoder": "tiny test trunk" if args.train_tiny else "full size (ViT-L encoder x2, 2x12 ViT-B decoder blocks, 5 DPT heads)"}
     if not cpu:
-        out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)
+        out["peak_mem_GB"] = round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)      # (of THIS leg: the counter is reset where the leg starts)
         if not args.train_tiny:
             for other in [m for m in ("f16x3", "bf16x6", "bf16x3") if m != head_mode]:
                 try:

@@ -252,6 +252,7 @@ int vit_layernorm_bwd(const float *dy, const float *x, const float *mean, const 
  * F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) of the DPT heads (dpt_block.py Interpolate /
  * FeatureFusionBlock): in (planes, H, W) -> out (planes, 2H, 2W), planes = B*C of a contiguous NCHW tensor; W even.
  */
+/* (out must be 16-byte aligned; a 16-byte aligned `in` / `dout` with power-of-two maps takes the LDS-staged fast kernels, anything else the generic ones) */
 int vit_upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, void *stream);
 /* its input gradient: dout (planes, 2H, 2W) -> din (planes, H, W), a gather (no atomics), overwritten */
 int vit_upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, void *stream);

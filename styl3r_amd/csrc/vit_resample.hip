@@ -221,10 +221,13 @@ __global__ void __launch_bounds__(256) k_upsample2x_bwd_lds(const float *__restr
 #pragma clang fp contract(fast)
 
 // the fast forward kernel's precondition: W a multiple of 4, 2W / 4 a power of two <= 256, fewer than 2^31 output rows
-static bool upsample_p2_ok(int64_t planes, int H, int W)
+//  ... and a 16-byte aligned INPUT: the fast kernels read `in` / `dout` with float4 loads (the generic ones only ever needed the
+// output and the addend aligned)
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool upsample_p2_ok(int64_t planes, int H, int W, const void *in)
 {
     const int ow4 = 2 * W / 4;
-    return (W & 3) == 0 && ow4 <= 256 && (ow4 & (ow4 - 1)) == 0 && planes * 2 * H < (int64_t)0x7fffffff;
+    return (W & 3) == 0 && ow4 <= 256 && (ow4 & (ow4 - 1)) == 0 && planes * 2 * H < (int64_t)0x7fffffff && aligned16(in);
 }
 
 int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, hipStream_t stream)
@@ -234,7 +237,7 @@ int upsample2x_bwd(const float *dout, float *din, int64_t planes, int H, int W, 
     const int64_t blocks = (planes * H * W + 255) / 256;
     (void)hipGetLastError();
     const int R = (W & (W - 1)) == 0 && W <= 256 && W >= 2 ? 256 / W : 0;
-    if (R && (H & (H - 1)) == 0 && H >= R && planes * (H / R) < (int64_t)0x7fffffff)
+    if (R && (H & (H - 1)) == 0 && H >= R && planes * (H / R) < (int64_t)0x7fffffff && aligned16(dout))
         hipLaunchKernelGGL(k_upsample2x_bwd_lds, dim3((unsigned)(planes * (H / R))), dim3(256), (size_t)(2 * R + 4) * 2 * W * sizeof(float), stream, dout,
                            din, H, W, rh, rw, __builtin_ctz((unsigned)W));
     else if ((W & (W - 1)) == 0 && planes * H * W < (int64_t)0x7fffffff)
@@ -255,7 +258,7 @@ int upsample2x_fwd(const float *in, float *out, int64_t planes, int H, int W, hi
     const int64_t total = planes * 2 * H * (2 * W / 4);
     const int64_t blocks = (total + 255) / 256;
     (void)hipGetLastError();
-    if (upsample_p2_ok(planes, H, W)) {
+    if (upsample_p2_ok(planes, H, W, in)) {
         const int l2 = __builtin_ctz((unsigned)(2 * W / 4));
         const int64_t rows = planes * 2 * H;
         hipLaunchKernelGGL(k_upsample2x_p2<false>, dim3((unsigned)((rows + (256 >> l2) - 1) >> (8 - l2))), dim3(256), 0, stream, in,
@@ -318,7 +321,7 @@ int upsample2x_add_relu_fwd(const float *in, const float *addend, float *out, in
     const int64_t total = planes * 2 * H * (2 * W / 4);
     const int64_t blocks = (total + 255) / 256;
     (void)hipGetLastError();
-    if (upsample_p2_ok(planes, H, W)) {
+    if (upsample_p2_ok(planes, H, W, in)) {
         const int l2 = __builtin_ctz((unsigned)(2 * W / 4));
         const int64_t rows = planes * 2 * H;
         hipLaunchKernelGGL(k_upsample2x_p2<true>, dim3((unsigned)((rows + (256 >> l2) - 1) >> (8 - l2))), dim3(256), 0, stream, in, addend,

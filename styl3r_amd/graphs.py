@@ -26,9 +26,13 @@ class GraphedEncoder:
                 self.encoder(self.ctx, self.style, 0)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = self.encoder(self.ctx, self.style, 0)
-        vit_ops._AMAX.end_capture()      # f16x3 |max| words: this graph's arena (zero fill captured with it) is not handed to anyone else
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = self.encoder(self.ctx, self.style, 0)
+        finally:
+            # f16x3 |max| words: this graph's arena (zero fill captured with it) is not handed to anyone else -- also when the capture raised
+            # (a failed capture left its arena registered, and the next capture on the stream drew words from a dead pool)
+            vit_ops._AMAX.end_capture()
 
     @torch.no_grad()
     def __call__(self, context: dict, style: dict) -> Gaussians:
@@ -74,9 +78,11 @@ class StreamGraphedEncoder:
         def capture(fn):
             g = torch.cuda.CUDAGraph()
             box = {}
-            with torch.no_grad(), torch.cuda.graph(g, stream=cap):
-                box["out"] = fn()
-            vit_ops._AMAX.end_capture()  # every graph zero-fills its own |max| arena on replay (words were never re-zeroed)
+            try:
+                with torch.no_grad(), torch.cuda.graph(g, stream=cap):
+                    box["out"] = fn()
+            finally:
+                vit_ops._AMAX.end_capture()  # every graph zero-fills its own |max| arena on replay; in a finally: a failed capture must not leave its arena registered
             self._keep.append(box)
             return g, box["out"]
 

@@ -678,12 +678,14 @@ def refresh_split_cache(params) -> int:
             return plan["njobs"]
         _SPLIT_PLAN.pop(pkey, None)
     jobs, entries = [], []
+    partial = False         # some image of some weight is not part of this refresh: the job table must not become the reusable plan
     for p in params:
         pid, ver, ptr = id(p), p._version, p.data_ptr()
         word = None
         if f16:
             hw = _WEIGHT_AMAX.get(pid)
             if hw is None or hw[0]() is not p or hw[1] != ver or hw[2] != ptr:
+                partial = True
                 continue
             word = hw[3]
         N, K = p.shape
@@ -691,7 +693,10 @@ def refresh_split_cache(params) -> int:
             for block in (False, True):
                 key = ((pid, "block_t" if transposed else "block") if block else (pid, transposed)) + (("f16",) if f16 else ())
                 hit = _SPLIT_CACHE.get(key)
-                if hit is None or hit[0]() is not p or hit[2] != ptr or hit[1] == ver:
+                if hit is None:
+                    continue            # (a layout this weight never uses)
+                if hit[0]() is not p or hit[2] != ptr or hit[1] == ver:
+                    partial = True      # an image that exists but is not refreshed here (already current, or of a replaced tensor)
                     continue
                 R, Kc = (K, N) if transposed else (N, K)
                 if Kc % 8:
@@ -716,8 +721,10 @@ def refresh_split_cache(params) -> int:
     for key, p, packed, word in entries:
         hit = _SPLIT_CACHE[key]
         _SPLIT_CACHE[key] = (hit[0], p._version, p.data_ptr(), packed)
-    # the plan is reusable only if it covers every image of every weight handed in (else the first steps, while the cache fills, would pin a partial one)
-    _SPLIT_PLAN[pkey] = {"params": list(params), "entries": entries, "table": table, "njobs": len(jobs), "blocks": first}
+    # the plan is reusable only if it covers every cached image of every weight handed in (a table built on an early step, while the
+    # cache was still filling or with some images already current, passed every fast-path check afterwards and pinned the rest to lazy launches)
+    if not partial:
+        _SPLIT_PLAN[pkey] = {"params": list(params), "entries": entries, "table": table, "njobs": len(jobs), "blocks": first}
     CALLS["split_many_images"] += len(jobs)
     return len(jobs)
 
