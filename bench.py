@@ -520,6 +520,8 @@ def train_leg(args, rank, world, dev, dist):
     from styl3r_amd.scenes import make_scene
     from styl3r_amd.train import TrainStep
     cpu = dev.type == "cpu"
+    if not cpu:
+        torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats(dev)      # peak_mem_GB below is this leg's, not the process's
     torch.manual_seed(0)   # identical replicas on every rank
     tiny = dict(enc_depth=1, dec_depth=2, enc_embed_dim=64, dec_embed_dim=32, enc_num_heads=2, dec_num_heads=2,
                 pos_embed="RoPE100", img_size=(512, 512)) if args.train_tiny else None
@@ -648,6 +650,8 @@ def stage_leg(args, rank, world, dev, dist, config):
     from styl3r_amd.scenes import make_scene
     from styl3r_amd.train import TrainStep
     c4 = config == "c4"
+    if dev.type != "cpu":
+        torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats(dev)      # per-leg peak memory
     torch.manual_seed(0)
     cfg = EncoderNoPoSplatTokenStyleCfg(stylized=c4)
     if not c4:

@@ -617,7 +617,7 @@ class PixelwiseTaskWithDPT(nn.Module):
         assert l2 > 9
         ed, dd = net.enc_embed_dim, net.dec_embed_dim
         self.kind = kind
-        self.dpt = DPTAdapter(num_channels, [ed, dd, dd, dd], [0, l2 * 2 // 4, l2 * 3 // 4, l2], kind)
+        self.dpt = DPTAdapter(num_channels, [ed, dd, dd, dd], [0, l2 * 2 // 4, l2 * 3 // 4, l2], "pts3d" if kind == "pts3d_raw" else kind)
 
     def forward(self, tokens, image_size, imgs=None, raw: bool = False):
         """raw=True: the DPT output (B, C, H, W) as it leaves the last convolution -- the fused adapter kernel
@@ -638,9 +638,52 @@ def landscape_mean_head(head, tokens, h: int, w: int) -> Tensor:
     return pts if w >= h else pts.swapaxes(1, 2)
 
 
+class LinearPts3d(nn.Module):
+    """`LinearPts3d` (heads/linear_head.py:12-43): every decoder token emits its 16 x 16 patch of 3-D points through ONE Linear layer
+    (on the fused kernels), a pixel shuffle puts them on the image grid, reg_dense_depth('exp') finishes.  has_conf = False as in every config."""
+
+    def __init__(self, net, has_conf: bool = False):
+        super().__init__()
+        assert not has_conf
+        self.patch_size = 16
+        self.proj = nn.Linear(net.dec_embed_dim, 3 * self.patch_size ** 2)
+
+    def forward(self, decout, img_shape, imgs=None, raw: bool = False):
+        H, W = img_shape
+        tokens = decout[-1]
+        B = tokens.shape[0]
+        feat = _linear(self.proj, tokens)                                             # (B, S, 3 p^2)
+        feat = feat.transpose(-1, -2).reshape(B, -1, H // self.patch_size, W // self.patch_size)
+        feat = torch.nn.functional.pixel_shuffle(feat, self.patch_size)                # (B, 3, H, W)
+        return feat if raw else {"pts3d": reg_dense_depth_exp(feat.permute(0, 2, 3, 1))}
+
+
+def rearrange_head(feat: Tensor, patch_size: int, H: int, W: int) -> Tensor:
+    """encoder_noposplat.py:54-59: per-token (B, S, C p^2) outputs of a linear Gaussian-parameter head -> (B, H W, C)"""
+    B = feat.shape[0]
+    feat = feat.transpose(-1, -2).reshape(B, -1, H // patch_size, W // patch_size)
+    return torch.nn.functional.pixel_shuffle(feat, patch_size).flatten(2).transpose(1, 2)
+
+
+class _LinearGsHead(nn.Sequential):
+    """the 'linear' Gaussian-parameter head of the encoders' set_gs_params_head (encoder_noposplat.py:98-106): nn.Sequential(ReLU, Linear) --
+    same state-dict keys (`1.weight`, `1.bias`); device tensors take the fused Linear kernels"""
+
+    def __init__(self, dim: int, out: int):
+        super().__init__(nn.ReLU(), nn.Linear(dim, out))
+
+    def forward(self, tokens: Tensor) -> Tensor:
+        return _linear(self[1], torch.relu(tokens))
+
+
 def head_factory(head_type, output_mode, net, has_conf=False, out_nchan=3):
-    """heads/__init__.py:13-27 (the variants the style encoders use)."""
+    """heads/__init__.py:13-27, all five branches."""
     assert not has_conf
+    if head_type == "linear" and output_mode == "pts3d":
+        return LinearPts3d(net, has_conf)
+    if head_type == "dpt" and output_mode == "gs_params":
+        # create_dpt_head(out_nchan=..., postprocess_func=None) (dpt_head.py:101-119): the 'regression' DPT head, raw channels out
+        return PixelwiseTaskWithDPT(out_nchan, net, "pts3d_raw")
     if head_type == "dpt" and output_mode == "pts3d":
         return PixelwiseTaskWithDPT(3, net, "pts3d")
     if head_type == "dpt_gs" and output_mode == "gs_params":
@@ -712,7 +755,8 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
     def __init__(self, cfg: EncoderNoPoSplatTokenStyleCfg, trunk_params: Optional[dict] = None):
         super().__init__()
         self.cfg = cfg
-        assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
+        assert cfg.pose_free and cfg.num_surfaces == 1
+        self.gs_params_head_type = cfg.gs_params_head_type
         self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
         assert self.backbone.intrinsics_embed_type == "token", "the Gaussian heads of this encoder take the 'token' intrinsics embedding (every shipped config)"
         self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
@@ -721,8 +765,19 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         d_sh3 = 3 * self.gaussian_adapter.d_sh
         self.downstream_head1 = head_factory("dpt", "pts3d", self.backbone)
         self.downstream_head2 = head_factory("dpt", "pts3d", self.backbone)
-        self.gaussian_param_head = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
-        self.gaussian_param_head2 = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
+        # set_gs_params_head (encoder_noposplat_multi_token_style.py:91-113): the constructor accepts 'linear' | 'dpt' | 'dpt_gs' (same
+        # modules / state-dict keys here); the reference's FORWARD runs 'dpt_gs' only and raises for the others (:161-170) -- so does this one
+        if cfg.gs_params_head_type == "linear":
+            self.gaussian_param_head = _LinearGsHead(self.backbone.dec_embed_dim, cfg.num_surfaces * self.patch_size ** 2 * self.raw_gs_dim)
+            self.gaussian_param_head2 = _LinearGsHead(self.backbone.dec_embed_dim, cfg.num_surfaces * self.patch_size ** 2 * self.raw_gs_dim)
+        elif cfg.gs_params_head_type == "dpt":
+            self.gaussian_param_head = head_factory("dpt", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+            self.gaussian_param_head2 = head_factory("dpt", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+        elif cfg.gs_params_head_type == "dpt_gs":
+            self.gaussian_param_head = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
+            self.gaussian_param_head2 = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim - d_sh3)
+        else:
+            raise NotImplementedError(f"unexpected head_type={cfg.gs_params_head_type!r}")
         self.stylized = cfg.stylized
         self.token_stylizer = TokenStylizer(cfg.token_stylizer, trunk_params)
         self.gaussian_appearance_head = head_factory("dpt_gs_sh", "gs_params", self.token_stylizer, out_nchan=d_sh3)
@@ -759,6 +814,8 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
 
     def forward(self, context: dict, style: dict, global_step: int = 0,
                 visualization_dump: Optional[dict] = None) -> Gaussians:
+        if self.gs_params_head_type != "dpt_gs":       # encoder_noposplat_multi_token_style.py:161-170
+            raise NotImplementedError(f"unexpected self.gs_params_head_type={self.gs_params_head_type!r}")
         b, v, _, h, w = context["image"].shape
         images = context["image"]
         self.backbone.branch_streams = bool(self.head_streams)
@@ -908,7 +965,8 @@ class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
     def __init__(self, cfg: EncoderNoPoSplatCfg, trunk_params: Optional[dict] = None):
         nn.Module.__init__(self)
         self.cfg = cfg
-        assert cfg.pose_free and cfg.gs_params_head_type == "dpt_gs" and cfg.num_surfaces == 1
+        assert cfg.pose_free and cfg.num_surfaces == 1
+        self.gs_params_head_type = cfg.gs_params_head_type
         self.backbone = AsymmetricCroCoMulti(cfg.backbone, 3, trunk_params)
         assert self.backbone.intrinsics_embed_type == "token", "the Gaussian heads of this encoder take the 'token' intrinsics embedding (every shipped config)"
         self.gaussian_adapter = UnifiedGaussianAdapter(cfg.gaussian_adapter)
@@ -916,8 +974,16 @@ class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
         self.raw_gs_dim = 1 + self.gaussian_adapter.d_in
         self.downstream_head1 = head_factory("dpt", "pts3d", self.backbone)
         self.downstream_head2 = head_factory("dpt", "pts3d", self.backbone)
-        self.gaussian_param_head = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
-        self.gaussian_param_head2 = head_factory("dpt_gs", "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+        # set_gs_params_head (encoder_noposplat.py:97-116): 'linear' | 'dpt' | 'dpt_gs'.  (The reference's multi-view forward only runs
+        # 'dpt_gs', its 2-view `noposplat` forward all three, :155-167; this class serves both registry names and runs all three at any v.)
+        if cfg.gs_params_head_type == "linear":
+            self.gaussian_param_head = _LinearGsHead(self.backbone.dec_embed_dim, cfg.num_surfaces * self.patch_size ** 2 * self.raw_gs_dim)
+            self.gaussian_param_head2 = _LinearGsHead(self.backbone.dec_embed_dim, cfg.num_surfaces * self.patch_size ** 2 * self.raw_gs_dim)
+        elif cfg.gs_params_head_type in ("dpt", "dpt_gs"):
+            self.gaussian_param_head = head_factory(cfg.gs_params_head_type, "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+            self.gaussian_param_head2 = head_factory(cfg.gs_params_head_type, "gs_params", self.backbone, out_nchan=self.raw_gs_dim)
+        else:
+            raise NotImplementedError(f"unexpected head_type={cfg.gs_params_head_type!r}")
 
     def forward(self, context: dict, global_step: int = 0, visualization_dump: Optional[dict] = None) -> Gaussians:
         b, v, _, h, w = context["image"].shape
@@ -929,7 +995,13 @@ class EncoderNoPoSplatMulti(EncoderNoPoSplatMultiTokenStyle):
                 pts.append(landscape_mean_head(head, [t[:, i].float() for t in dec_feat], h, w))
             for i in range(v):
                 head = self.gaussian_param_head if i == 0 else self.gaussian_param_head2
-                params.append(head([t[:, i].float() for t in dec_feat], (h, w), images[:, i, :3]).flatten(2).transpose(1, 2))
+                toks = [t[:, i].float() for t in dec_feat]
+                if self.gs_params_head_type == "linear":        # per-token Linear + pixel shuffle (encoder_noposplat.py:155-157)
+                    params.append(rearrange_head(head(toks[-1]), self.patch_size, h, w))
+                elif self.gs_params_head_type == "dpt":         # plain DPT regression head, no image / point input (:158-162)
+                    params.append(head(toks, (h, w)).flatten(2).transpose(1, 2))
+                else:
+                    params.append(head(toks, (h, w), images[:, i, :3]).flatten(2).transpose(1, 2))
         pts_all = torch.stack(pts, dim=1).reshape(b, v, h * w, 1, 3)
         depths = pts_all[..., -1].unsqueeze(-1)
         raw = torch.stack(params, dim=1).reshape(b, v, h * w, 1, -1)
