@@ -63,6 +63,11 @@ typedef struct VitAttnArgs {
      * (B,N,H,64) tensors.  3 * H * 64 with dq, dk, dv pointing at planes 0 / 1 / 2 of ONE (B,N,3,H,64) buffer writes the gradient
      * of a packed qkv projection in place (no select_backward fills / copies / adds behind the kernel). */
     int64_t dq_sn, dkv_sn;
+    /* optional |max| words (see vit_amax below: 8 KiB, zeroed by the caller) that the kernels fill with the largest |value| they STORE -- the
+     * f16x3 scale of the consumer (the proj / qkv / projq / projk / projv Linear layers behind and in front of the attention) then costs no
+     * vit_amax pass of its own.  Forward: amax_out (of `out`).  Backward: amax_dq, amax_dk, amax_dv (may all point at ONE word: the packed
+     * qkv gradient).  NULL = not wanted.  Launches that fall back to the exact-f32 kernels fill them with a pass over the contiguous result. */
+    uint32_t *amax_out, *amax_dq, *amax_dk, *amax_dv;
 } VitAttnArgs;
 
 int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,

@@ -233,6 +233,7 @@ int attention_set_arith(int mode)
 int attention_arith() { return g_attn_arith; }
 int attention_fwd_tail(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse, int rows,
                        hipStream_t stream);
+int amax(const float *x, int64_t n, void *out, hipStream_t stream);      // vit_gemm_x6.hip
 
 int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, float *out, float *lse,
                   hipStream_t stream)
@@ -253,9 +254,17 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     hipError_t e;
     if (attention_arith() >= 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, attention_arith() == 2 ? 3 : 6, stream);
     else {
-        if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
-        else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        // the exact-f32 kernel has no |max| epilogue: a requested word is filled by a pass over the (contiguous) result instead
+        VitAttnArgs b = a;
+        b.amax_out = nullptr;
+        const bool contiguous = a.o_sh == HD && a.o_sn == (int64_t)a.H * HD && a.o_sb == (int64_t)a.Nq * a.H * HD;
+        if (a.amax_out && !contiguous) return VIT_EINVAL;
+        if (rope) hipLaunchKernelGGL(k_attn_fwd<true>, grid, dim3(256), 0, stream, b, q, k, v, out, lse);
+        else hipLaunchKernelGGL(k_attn_fwd<false>, grid, dim3(256), 0, stream, b, q, k, v, out, lse);
         e = hipGetLastError();
+        if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+        if (tail_rows) { const int rc = attention_fwd_tail(b, q, k, v, out, lse, tail_rows, stream); if (rc != VIT_OK) return rc; }
+        return a.amax_out ? amax(out, (int64_t)a.B * a.Nq * a.H * HD, a.amax_out, stream) : VIT_OK;
     }
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     if (tail_rows) return attention_fwd_tail(a, q, k, v, out, lse, tail_rows, stream);

@@ -285,6 +285,8 @@ hipError_t launch_attention_bwd_x6(const VitAttnArgs &a, const float *q, const f
 int attention_bwd_tails(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *lse, const float *dout,
                         const float *delta, float *dq, float *dk, float *dv, int q_rows, int k_rows, hipStream_t stream);
 
+int amax(const float *x, int64_t n, void *out, hipStream_t stream);      // vit_gemm_x6.hip
+
 int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const float *v, const float *out, const float *lse,
                   const float *dout, float *dq, float *dk, float *dv, float *delta_ws, hipStream_t stream)
 {
@@ -306,14 +308,33 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     if (attention_arith() >= 1 && x6_ok) {
         e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, attention_arith() == 2 ? 3 : 6, stream);
     } else {
+        // the exact-f32 kernels have no |max| epilogue: requested words are filled by passes over the results -- ONE pass over the packed
+        // (B,N,3,H,64) gradient when the three words are one and dq / dk / dv are its planes, else one per contiguous tensor
+        VitAttnArgs b = a;
+        b.amax_dq = b.amax_dk = b.amax_dv = nullptr;
+        const bool want = a.amax_dq || a.amax_dk || a.amax_dv;
+        const int64_t hd = (int64_t)a.H * HD;
+        const bool packed = a.dq_sn == 3 * hd && a.dkv_sn == 3 * hd && a.Nq == a.Nk && dk == dq + hd && dv == dq + 2 * hd &&
+                            a.amax_dq && a.amax_dq == a.amax_dk && a.amax_dq == a.amax_dv;
+        const bool plain = (a.dq_sn == 0 || a.dq_sn == hd) && (a.dkv_sn == 0 || a.dkv_sn == hd);
+        if (want && !packed && !plain) return VIT_EINVAL;
         if (rope) {
-            hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
-            hipLaunchKernelGGL(k_attn_bwd_q<true>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+            hipLaunchKernelGGL(k_attn_bwd_kv<true>, gkv, dim3(256), 0, stream, b, q, k, v, dout, lse, delta_ws, dk, dv);
+            hipLaunchKernelGGL(k_attn_bwd_q<true>, gq, dim3(256), 0, stream, b, q, k, v, dout, lse, delta_ws, dq);
         } else {
-            hipLaunchKernelGGL(k_attn_bwd_kv<false>, gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dk, dv);
-            hipLaunchKernelGGL(k_attn_bwd_q<false>, gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta_ws, dq);
+            hipLaunchKernelGGL(k_attn_bwd_kv<false>, gkv, dim3(256), 0, stream, b, q, k, v, dout, lse, delta_ws, dk, dv);
+            hipLaunchKernelGGL(k_attn_bwd_q<false>, gq, dim3(256), 0, stream, b, q, k, v, dout, lse, delta_ws, dq);
         }
         e = hipGetLastError();
+        if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+        if (q_tail || k_tail) { const int rc = attention_bwd_tails(b, q, k, v, lse, dout, delta_ws, dq, dk, dv, q_tail, k_tail, stream); if (rc != VIT_OK) return rc; }
+        if (!want) return VIT_OK;
+        if (packed) return amax(dq, (int64_t)a.B * a.Nq * 3 * hd, a.amax_dq, stream);
+        int rc = VIT_OK;
+        if (a.amax_dq) rc = amax(dq, (int64_t)a.B * a.Nq * hd, a.amax_dq, stream);
+        if (rc == VIT_OK && a.amax_dk) rc = amax(dk, (int64_t)a.B * a.Nk * hd, a.amax_dk, stream);
+        if (rc == VIT_OK && a.amax_dv) rc = amax(dv, (int64_t)a.B * a.Nk * hd, a.amax_dv, stream);
+        return rc;
     }
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     if (q_tail || k_tail) return attention_bwd_tails(a, q, k, v, lse, dout, delta_ws, dq, dk, dv, q_tail, k_tail, stream);

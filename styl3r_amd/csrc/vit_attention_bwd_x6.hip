@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/vit_ops.h"
+#include "vit_amax.h"
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
@@ -247,6 +248,13 @@ __device__ inline void unrotate(f32x16 &lo, f32x16 &hi, int half, int64_t py, in
         hi[r] = hu * cx + hv * sx; hi[r + 8] = hv * cx - hu * sx;
     }
 }
+__device__ inline uint32_t max_abs_32(const f32x16 &lo, const f32x16 &hi)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = max(m, max(abs_bits(lo[r]), abs_bits(hi[r])));
+    return m;
+}
 __device__ inline void store_64(float *__restrict__ row, const f32x16 &lo, const f32x16 &hi, int half)
 {
 #pragma unroll
@@ -318,6 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
         }
         store_64(dq + ((int64_t)b * a.Nq + q0 + col) * (a.dq_sn ? a.dq_sn : (int64_t)a.H * HD) + h * HD, dq0, dq1, half);   // (B,Nq,H,64), token stride dq_sn
     }
+    if (a.amax_dq) amax_word_fold(a.amax_dq, (q0 + col < a.Nq) ? max_abs_32(dq0, dq1) : 0u);      // |max| of the stored gradient (after the inverse rotation)
 }
 
 // ------------------------------------------------------------------ dK, dV
@@ -398,6 +407,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
         store_64(dk + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD, dk0, dk1, half);
         store_64(dv + ((int64_t)b * a.Nk + key0 + col) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD, dv0, dv1, half);
     }
+    const bool stored = key0 + col < a.Nk;
+    if (a.amax_dk) amax_word_fold(a.amax_dk, stored ? max_abs_32(dk0, dk1) : 0u);
+    if (a.amax_dv) amax_word_fold(a.amax_dv, stored ? max_abs_32(dv0, dv1) : 0u);
 }
 }  // namespace abx6
 

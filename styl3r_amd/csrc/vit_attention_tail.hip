@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/vit_ops.h"
+#include "vit_amax.h"
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(64) k_attn_fwd_tail(VitAttnArgs a, const float
         o += p * vb[(int64_t)j * a.v_sn];
     }
     out[(int64_t)b * a.o_sb + (int64_t)qi * a.o_sn + (int64_t)h * a.o_sh + lane] = o / l;
+    if (a.amax_out) amax_word_fold(a.amax_out, abs_bits(o / l));
     if (lse && lane == 0) lse[((int64_t)b * a.H + h) * a.Nq + qi] = (mx + log2f(l)) * 0.6931471805599453f;
 }
 
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_q_tail(VitAttnArgs a, const flo
     float r = tot;
     if (ROPE) r = rope_feature(s_raw, lane, py, px, a.cos_tab, a.sin_tab, -1.f);   // inverse rotation
     dq[((int64_t)b * a.Nq + qi) * (a.dq_sn ? a.dq_sn : (int64_t)a.H * HD) + h * HD + lane] = r;
+    if (a.amax_dq) amax_word_fold(a.amax_dq, abs_bits(r));
 }
 
 // ---- backward, key side: dK[kj] = sum_i dS_i q_i , dV[kj] = sum_i P_i dO_i over ALL queries i ----
@@ -214,6 +217,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv_tail(VitAttnArgs a, const fl
 #pragma unroll 8
     for (int l2 = 0; l2 < 64; ++l2) tv += s_acc[l2 * 65 + lane];
     dv[((int64_t)b * a.Nk + kj) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD + lane] = tv;
+    if (a.amax_dv) amax_word_fold(a.amax_dv, abs_bits(tv));
     __syncthreads();
     // dK (w.r.t. the rotated key), then rotate back
 #pragma unroll
@@ -227,6 +231,7 @@ __global__ void __launch_bounds__(64) k_attn_bwd_kv_tail(VitAttnArgs a, const fl
     float r = tk;
     if (ROPE) r = rope_feature(s_raw, lane, py, px, a.cos_tab, a.sin_tab, -1.f);
     dk[((int64_t)b * a.Nk + kj) * (a.dkv_sn ? a.dkv_sn : (int64_t)a.H * HD) + h * HD + lane] = r;
+    if (a.amax_dk) amax_word_fold(a.amax_dk, abs_bits(r));
 }
 }  // namespace tail
 

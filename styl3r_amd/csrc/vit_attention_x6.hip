@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/vit_ops.h"
+#include "vit_amax.h"
 
 namespace vit {
 extern thread_local hipError_t g_last_hip_error;
@@ -272,8 +273,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
     }
 
     // ---- epilogue: O = O^T / l, out[q][d], d = 8g + 4 half + {0..3} (+32) ----
+    uint32_t omax = 0;              // |max| of the stored values (VitAttnArgs.amax_out)
     if (q0 + col < a.Nq) {
         const float inv = 1.f / l;
+        if (a.amax_out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) omax = max(omax, max(abs_bits(o0[r] * inv), abs_bits(o1[r] * inv)));
+        }
         float *orow = out + (int64_t)b * a.o_sb + (int64_t)(q0 + col) * a.o_sn + (int64_t)h * a.o_sh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -283,6 +289,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
         }
         if (lse && half == 0) lse[((int64_t)b * a.H + h) * a.Nq + q0 + col] = (m + log2f(l)) * 0.6931471805599453f;
     }
+    if (a.amax_out) amax_word_fold(a.amax_out, omax);      // (wave-uniform branch; waves past Nq fold 0)
 }
 }  // namespace ax6
 

@@ -106,7 +106,8 @@ class VitAttnArgs(C.Structure):
                 ("v_sb", C.c_int64), ("v_sn", C.c_int64), ("v_sh", C.c_int64),
                 ("o_sb", C.c_int64), ("o_sn", C.c_int64), ("o_sh", C.c_int64),
                 ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
-                ("P", C.c_int32), ("dq_sn", C.c_int64), ("dkv_sn", C.c_int64)]
+                ("P", C.c_int32), ("dq_sn", C.c_int64), ("dkv_sn", C.c_int64),
+                ("amax_out", C.c_void_p), ("amax_dq", C.c_void_p), ("amax_dk", C.c_void_p), ("amax_dv", C.c_void_p)]
 
 
 def load() -> C.CDLL:
@@ -333,6 +334,16 @@ def _sync_attention_arith(mode: Optional[str] = None) -> None:
         _check(lib.vit_attention_set_arith(want), "vit_attention_set_arith")
 
 
+def _attn_word(a: "VitAttnArgs", field: str, dev) -> Optional[Tensor]:
+    """f16x3: hand the attention launch a zeroed |max| word for one of its outputs (VitAttnArgs.amax_*): the Linear layer that consumes the
+    output (proj after the forward; qkv / projq / projk / projv after the backward) then needs no vit_amax pass for its operand scale"""
+    if not (LINEAR_MODE == "f16x3" and PUBLISH_AMAX):
+        return None
+    w = _AMAX.word(dev)
+    setattr(a, field, w.data_ptr())
+    return w
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, qpos, kpos, base, max_pos):
@@ -343,8 +354,11 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
         rope = (qpos, kpos, base, max_pos) if qpos is not None else None
         a, keep = _attn_args(q, k, v, out, scale, rope)
+        word = _attn_word(a, "amax_out", q.device)
         _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), _stream(q.device)), "vit_attention_fwd")
+        if word is not None:
+            _publish(out, word)
         ctx.save_for_backward(q, k, v, out, lse, qpos, kpos)
         ctx.cfg = (scale, base, max_pos)
         ctx.arith = ATTENTION_ARITH
@@ -365,9 +379,13 @@ class _Attention(torch.autograd.Function):
         rope = (qpos, kpos, base, max_pos) if qpos is not None else None
         a, keep = _attn_args(q, k, v, out, scale, rope)
         delta = torch.empty_like(lse)
+        wq, wk, wv = (_attn_word(a, n, q.device) for n in ("amax_dq", "amax_dk", "amax_dv"))       # the projq / projk / projv weight-gradient and dX launches read them
         _check(lib.vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                      lse.data_ptr(), g.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                      delta.data_ptr(), _stream(q.device)), "vit_attention_bwd")
+        for t, w in ((dq, wq), (dk, wk), (dv, wv)):
+            if w is not None:
+                _publish(t, w)
         return dq, dk, dv, None, None, None, None, None
 
 
@@ -389,8 +407,11 @@ class _AttentionQKV(torch.autograd.Function):
         lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         rope = (pos, pos, base, max_pos) if pos is not None else None
         a, keep = _attn_args(q, k, v, out, scale, rope)
+        word = _attn_word(a, "amax_out", qkv.device)
         _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), _stream(qkv.device)), "vit_attention_fwd")
+        if word is not None:
+            _publish(out, word)
         ctx.save_for_backward(qkv, out, lse, pos)
         ctx.cfg = (scale, base, max_pos)
         ctx.arith = ATTENTION_ARITH
@@ -410,9 +431,14 @@ class _AttentionQKV(torch.autograd.Function):
         a.dq_sn = a.dkv_sn = 3 * H * D
         delta = torch.empty_like(lse)
         base_ptr, plane = dqkv.data_ptr(), H * D * 4
+        word = _attn_word(a, "amax_dq", qkv.device)          # ONE word for the packed gradient: both kernels fold into it
+        if word is not None:
+            a.amax_dk = a.amax_dv = a.amax_dq
         _check(load().vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), g.data_ptr(), base_ptr, base_ptr + plane, base_ptr + 2 * plane,
                                         delta.data_ptr(), _stream(qkv.device)), "vit_attention_bwd")
+        if word is not None:
+            _publish(dqkv, word)
         return dqkv, None, None, None, None
 
 

@@ -1217,3 +1217,55 @@ def test_conv_weight_pair_split_equals_the_rearranged_copy_path(mode, monkeypatc
     finally:
         vit_ops.LINEAR_MODE = "bf16x6"
         vit_ops._x6()
+
+
+def test_attention_kernels_publish_the_absolute_maximum_of_what_they_store(monkeypatch):
+    """f16x3 (round 6): the attention forward fills a |max| word with the largest |out| it stores and the backward one for the packed qkv
+    gradient (or one each for dq / dk / dv of a cross-attention), tail rows (the 257th token) included, so the proj / qkv / projq / projk /
+    projv layers around it need no vit_amax pass.  The words must equal the maxima of the tensors exactly (a max is order-independent) and the
+    consumers must find them (vit_ops.CALLS: no amax pass for these tensors)."""
+    from styl3r_amd import vit_ops
+    monkeypatch.setattr(vit_ops, "LINEAR_MODE", "f16x3")
+    monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", "f16x3")
+    vit_ops._x6()
+    g = torch.Generator(DEV).manual_seed(3)
+    word_max = lambda w: w.view(torch.int32)[::32].max().item()
+    bits_max = lambda t: t.detach().abs().max().view(torch.int32).item()
+    try:
+        B, N, H = 2, 257, 4
+        qkv = torch.randn(B, N, 3, H, 64, device=DEV, generator=g).requires_grad_(True)
+        pos = torch.stack(torch.meshgrid(torch.arange(17, device=DEV), torch.arange(16, device=DEV), indexing="ij"), -1).reshape(-1, 2)[:N][None].expand(B, -1, -1).contiguous()
+        o = vit_ops.attention_qkv(qkv, 0.125, pos)
+        w = vit_ops._known_amax(o)
+        assert w is not None and word_max(w) == bits_max(o)
+        w2 = vit_ops._known_amax(o.reshape(B, N, H * 64))            # the view the proj layer sees
+        assert w2 is not None and w2.data_ptr() == w.data_ptr()
+        go = torch.randn(o.shape, device=DEV, generator=g)
+        (dqkv,) = torch.autograd.grad(o, qkv, go)
+        wg = vit_ops._known_amax(dqkv)
+        assert wg is not None and word_max(wg) == bits_max(dqkv)
+        # cross-attention: three tensors, three words (Nk = 514: two tail-free blocks + rows in the vector kernels)
+        q = torch.randn(B, 257, H, 64, device=DEV, generator=g).requires_grad_(True)
+        k = torch.randn(B, 514, H, 64, device=DEV, generator=g).requires_grad_(True)
+        v = torch.randn(B, 514, H, 64, device=DEV, generator=g).requires_grad_(True)
+        o2 = vit_ops.memory_efficient_attention(q, k, v, scale=0.125)
+        assert word_max(vit_ops._known_amax(o2)) == bits_max(o2)
+        dq, dk, dv = torch.autograd.grad(o2, (q, k, v), torch.randn(o2.shape, device=DEV, generator=g))
+        for t in (dq, dk, dv):
+            wt = vit_ops._known_amax(t)
+            assert wt is not None and word_max(wt) == bits_max(t)
+        # the exact-f32 kernels (mode f32) fill the words by a pass over the result
+        monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", "f32")
+        o3 = vit_ops.attention_qkv(qkv.detach(), 0.125, pos)
+        assert word_max(vit_ops._known_amax(o3)) == bits_max(o3)
+        # a block's proj consumes the published word: no amax pass
+        monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", "f16x3")
+        wt_ = torch.nn.Parameter(torch.randn(256, 256, device=DEV, generator=g) * 0.05)
+        o4 = vit_ops.attention_qkv(qkv.detach(), 0.125, pos)
+        n0 = vit_ops.CALLS["amax_pass"]
+        with torch.no_grad():
+            vit_ops.fused_linear(o4.reshape(B, N, H * 64), wt_)
+        assert vit_ops.CALLS["amax_pass"] == n0
+    finally:
+        vit_ops.LINEAR_MODE = "bf16x6"; vit_ops.ATTENTION_ARITH = "bf16x6"
+        vit_ops._x6()
