@@ -68,6 +68,10 @@ typedef struct VitAttnArgs {
      * vit_amax pass of its own.  Forward: amax_out (of `out`).  Backward: amax_dq, amax_dk, amax_dv (may all point at ONE word: the packed
      * qkv gradient).  NULL = not wanted.  Launches that fall back to the exact-f32 kernels fill them with a pass over the contiguous result. */
     uint32_t *amax_out, *amax_dq, *amax_dk, *amax_dv;
+    /* arithmetic mode 3 ("f16x3": two fp16 pieces per operand, three products per contraction step) only: the |max| words of the INPUT tensors q, k,
+     * v (may be one word: a packed qkv projection) and, for the backward, of dout -- the power-of-two operand scales come from them.  Required in
+     * that mode (VIT_EINVAL otherwise: no guessed scale); ignored in every other mode. */
+    const uint32_t *amax_q, *amax_k, *amax_v, *amax_g;
 } VitAttnArgs;
 
 int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, const float *v, float *out, float *lse,
@@ -76,7 +80,10 @@ int vit_attention_fwd(const VitAttnArgs *a, const float *q, const float *k, cons
  * Arithmetic of the contractions of vit_attention_fwd and vit_attention_bwd: 1 (default) = bf16x6 split arithmetic on the bf16
  * MFMA (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; fp32 round-off accuracy -- measured at or below the f32 kernels'
  * error against float64 -- forward 1.3 - 1.6x, backward 1.3 - 1.55x faster), 0 = exact-f32 MFMA, 2 = the split-arithmetic kernels with three
- * instead of six partial products per contraction step ("bf16x3": operands good to 2^-18, the attention counterpart of vit_x6_set_products(3)).  Strides that are not multiples
+ * instead of six partial products per contraction step ("bf16x3": operands good to 2^-18, the attention counterpart of vit_x6_set_products(3)),
+ * 3 = "f16x3" (round 6): two fp16 pieces per operand x power-of-two scale, three products on v_mfma_f32_32x32x16_f16 -- 2^-22 per product, the accuracy
+ * class of mode 1 at the MFMA count of mode 2; needs VitAttnArgs.amax_q / _k / _v (/ _g); the dS operand of the backward carries a per-lane running
+ * scale (csrc/vit_attention_bwd_x6.hip).  Strides that are not multiples
  * of 4 floats (or bases that are not 16-byte aligned) always take the f32 kernels.  Per calling thread (thread_local), read at launch time on that thread.
  */
 int vit_attention_set_arith(int mode);

@@ -226,7 +226,7 @@ hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const f
 static thread_local int g_attn_arith = 1;
 int attention_set_arith(int mode)
 {
-    if (mode < 0 || mode > 2) return VIT_EINVAL;
+    if (mode < 0 || mode > 3) return VIT_EINVAL;
     g_attn_arith = mode;
     return VIT_OK;
 }
@@ -252,7 +252,8 @@ int attention_fwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     // the split-arithmetic kernel loads q / k rows as float4: strides in multiples of 4 floats, 16-byte aligned bases
     const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb) & 3) && !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15);
     hipError_t e;
-    if (attention_arith() >= 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, attention_arith() == 2 ? 3 : 6, stream);
+    if (attention_arith() == 3 && x6_ok && !(a.amax_q && a.amax_k && a.amax_v)) return VIT_EINVAL;     // f16x3 without the operands' |max| words: refuse, never guess a scale
+    if (attention_arith() >= 1 && x6_ok) e = launch_attention_fwd_x6(a, q, k, v, out, lse, grid, attention_arith() == 2 ? 3 : (attention_arith() == 3 ? 2 : 6), stream);
     else {
         // the exact-f32 kernel has no |max| epilogue: a requested word is filled by a pass over the (contiguous) result instead
         VitAttnArgs b = a;

@@ -305,8 +305,9 @@ int attention_bwd(const VitAttnArgs &a, const float *q, const float *k, const fl
     const bool x6_ok = !((a.q_sn | a.q_sh | a.q_sb | a.k_sn | a.k_sh | a.k_sb | a.v_sn | a.v_sh | a.v_sb) & 3) &&
                        !((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15);
     hipError_t e;
+    if (attention_arith() == 3 && x6_ok && !(a.amax_q && a.amax_k && a.amax_v && a.amax_g)) return VIT_EINVAL;     // f16x3: the operands' |max| words are required
     if (attention_arith() >= 1 && x6_ok) {
-        e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, attention_arith() == 2 ? 3 : 6, stream);
+        e = launch_attention_bwd_x6(a, q, k, v, dout, lse, delta_ws, dq, dk, dv, gkv, gq, attention_arith() == 2 ? 3 : (attention_arith() == 3 ? 2 : 6), stream);
     } else {
         // the exact-f32 kernels have no |max| epilogue: requested words are filled by passes over the results -- ONE pass over the packed
         // (B,N,3,H,64) gradient when the three words are one and dq / dk / dv are its planes, else one per contiguous tensor

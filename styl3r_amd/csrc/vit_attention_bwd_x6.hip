@@ -59,11 +59,37 @@ __device__ inline void split8(const float *v, bf16x8 (&f)[3])
     split2(v[6], v[7], q0.w, q1.w, q2.w);
     f[0] = __builtin_bit_cast(bf16x8, q0); f[1] = __builtin_bit_cast(bf16x8, q1); f[2] = __builtin_bit_cast(bf16x8, q2);
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NP == 2 ("f16x3", vit_attention_set_arith(3), round 6): eight ALREADY SCALED values -> two fp16x8 pieces (held in bf16x8 registers)
+__device__ inline void split8h(const float *v, bf16x8 (&f)[3])
+{
+    uint4 q0, q1;
+    f16_split2(v[0], v[1], q0.x, q1.x);
+    f16_split2(v[2], v[3], q0.y, q1.y);
+    f16_split2(v[4], v[5], q0.z, q1.z);
+    f16_split2(v[6], v[7], q0.w, q1.w);
+    f[0] = __builtin_bit_cast(bf16x8, q0); f[1] = __builtin_bit_cast(bf16x8, q1);
+}
+template <int NP> __device__ inline void split8p(const float *v, bf16x8 (&f)[3]) { if (NP == 2) split8h(v, f); else split8(v, f); }
+template <int NP> __device__ inline void split2p(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2)
+{
+    if (NP == 2) f16_split2(a, b, p0, p1); else split2(a, b, p0, p1, p2);
+}
 // NP = 6: six partial products, smallest first; NP = 3 ("bf16x3", vit_attention_set_arith(2)): the three 2^-16-level products are left
-// out -- the third bf16 piece of every operand is then never used: the compiler drops its computation, the image stores skip it
+// out -- the third bf16 piece of every operand is then never used: the compiler drops its computation, the image stores skip it;
+// NP = 2 ("f16x3"): two fp16 pieces of value x power-of-two scale, h l' + l h' + h h' on the f16 MFMA (2^-22 per product).  Scales: Q, K, V, dO
+// from their tensors' |max| words (folded into `mul` of the loaders / stagers below), P the constant 2^14, dS a PER-LANE RUNNING scale (the
+// lane is the MFMA column = the query / key that owns the accumulators, so a lane's scale multiplies its whole accumulator column: when a
+// tile's dS outgrows the lane's current scale the column is rescaled by an exact power of two, as the online softmax rescales O).
 template <int NP>
 __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c)
 {
+    if (NP == 2) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        return c;
+    }
     if (NP == 6) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
@@ -76,7 +102,7 @@ __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x1
 }
 
 // ---- register fragments of one row (the MFMA B operand): step t covers d = 16 t + 8 half + j; rotated if ROPE, times `mul` ----
-template <bool ROPE>
+template <bool ROPE, int NP>
 __device__ inline void load_row_pieces(bf16x8 (&f)[4][3], const float *__restrict__ rp, int half, const int64_t *__restrict__ pos2,
                                        const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, float mul)
 {
@@ -102,7 +128,7 @@ __device__ inline void load_row_pieces(bf16x8 (&f)[4][3], const float *__restric
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[t][j] *= mul;
-        split8(x[t], f[t]);
+        split8p<NP>(x[t], f[t]);
     }
 }
 
@@ -122,7 +148,7 @@ __device__ inline void fetch_row_item(RowItem &it, const float *__restrict__ bas
 }
 template <bool ROPE, int NP>
 __device__ inline void store_row_item(unsigned char *__restrict__ img, const RowItem &it, int row0, int n_valid, int i,
-                                      const float *__restrict__ cos_tab, const float *__restrict__ sin_tab)
+                                      const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, float mul = 1.f)
 {
     const int row = i >> 2, sub = i & 3, sg = 4 * (sub >> 1) + (sub & 1);
     float u[8] = {it.a0.x, it.a0.y, it.a0.z, it.a0.w, it.a1.x, it.a1.y, it.a1.z, it.a1.w};
@@ -141,12 +167,16 @@ __device__ inline void store_row_item(unsigned char *__restrict__ img, const Row
 #pragma unroll
         for (int j = 0; j < 8; ++j) { u[j] = 0.f; w[j] = 0.f; }
     }
+    if (NP == 2) {                     // f16x3: the tensor's power-of-two scale
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u[j] *= mul; w[j] *= mul; }
+    }
     bf16x8 f[3];
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(img + row * ROWB);
-    split8(u, f);
+    split8p<NP>(u, f);
     dst[sg * 3 + 0] = f[0]; dst[sg * 3 + 1] = f[1];
     if (NP == 6) dst[sg * 3 + 2] = f[2];
-    split8(w, f);
+    split8p<NP>(w, f);
     dst[(sg + 2) * 3 + 0] = f[0]; dst[(sg + 2) * 3 + 1] = f[1];
     if (NP == 6) dst[(sg + 2) * 3 + 2] = f[2];
 }
@@ -169,7 +199,7 @@ __device__ inline void fetch_t_item(TItem &it, const float *__restrict__ base, i
 }
 template <bool ROPE, int NP>
 __device__ inline void store_t_item(unsigned char *__restrict__ img, const TItem &it, int row0, int n_valid, int i,
-                                    const float *__restrict__ cos_tab, const float *__restrict__ sin_tab)
+                                    const float *__restrict__ cos_tab, const float *__restrict__ sin_tab, float mul = 1.f)
 {
     const int m = i >> 5, pd = i & 31, d = pd + 16 * (pd >> 4);
     const int p0 = 16 * ((m >> 2) & 1) + 8 * (m & 1) + 4 * ((m >> 1) & 1);
@@ -183,15 +213,16 @@ __device__ inline void store_t_item(unsigned char *__restrict__ img, const TItem
             u[e] = t0; w[e] = t1;
         }
         if (row0 + 4 * m + e >= n_valid) { u[e] = 0.f; w[e] = 0.f; }
+        if (NP == 2) { u[e] *= mul; w[e] *= mul; }
     }
     uint2 a0, a1, a2;
-    split2(u[0], u[1], a0.x, a1.x, a2.x);
-    split2(u[2], u[3], a0.y, a1.y, a2.y);
+    split2p<NP>(u[0], u[1], a0.x, a1.x, a2.x);
+    split2p<NP>(u[2], u[3], a0.y, a1.y, a2.y);
     unsigned char *dst = img + d * TROWB + p0 * 2;
     *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1;
     if (NP == 6) *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
-    split2(w[0], w[1], a0.x, a1.x, a2.x);
-    split2(w[2], w[3], a0.y, a1.y, a2.y);
+    split2p<NP>(w[0], w[1], a0.x, a1.x, a2.x);
+    split2p<NP>(w[2], w[3], a0.y, a1.y, a2.y);
     dst += 16 * TROWB;
     *reinterpret_cast<uint2 *>(dst) = a0; *reinterpret_cast<uint2 *>(dst + HD * TROWB) = a1;
     if (NP == 6) *reinterpret_cast<uint2 *>(dst + 2 * HD * TROWB) = a2;
@@ -213,17 +244,18 @@ __device__ inline f32x16 rows_times_regs(const unsigned char *__restrict__ img, 
     return acc;
 }
 // second products: (lo, hi) (64 d x 32 lanes) += transposed image . x, x = 16 values per lane in D-layout register order
+// (xmul: f16x3 only -- the scale of the register operand, 2^14 for P, the lane's running scale for dS)
 template <int NP>
-__device__ inline void t_times_regs(const unsigned char *__restrict__ img, int col, int half, const f32x16 &x, f32x16 &lo, f32x16 &hi)
+__device__ inline void t_times_regs(const unsigned char *__restrict__ img, int col, int half, const f32x16 &x, f32x16 &lo, f32x16 &hi, float xmul = 1.f)
 {
     const unsigned char *ta = img + col * TROWB + half * 16;           // d = col (+ 32), positions 16 u + 8 half ..
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         float xv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xv[j] = x[8 * u + j];
+        for (int j = 0; j < 8; ++j) xv[j] = NP == 2 ? x[8 * u + j] * xmul : x[8 * u + j];
         bf16x8 xf[3], tf[3];
-        split8(xv, xf);
+        split8p<NP>(xv, xf);
 #pragma unroll
         for (int p = 0; p < 3; ++p) tf[p] = *reinterpret_cast<const bf16x8 *>(ta + u * 32 + p * HD * TROWB);
         lo = mfma6<NP>(tf, xf, lo);
@@ -231,6 +263,26 @@ __device__ inline void t_times_regs(const unsigned char *__restrict__ img, int c
         for (int p = 0; p < 3; ++p) tf[p] = *reinterpret_cast<const bf16x8 *>(ta + u * 32 + 32 * TROWB + p * HD * TROWB);
         hi = mfma6<NP>(tf, xf, hi);
     }
+}
+
+// f16x3: the per-lane running scale of the dS operand.  `ds`: this lane's 16 dS values of the tile (its MFMA column: lanes l and l + 32 hold the
+// two halves of the same column).  Returns the scale to split them with; when the column's |max| has outgrown the scale so far, the lane's
+// accumulators (lo, hi: everything accumulated under the old scale) are multiplied by new / old first -- exact, powers of two.  The scale only
+// ever shrinks (a larger |max| wins), so a lane rescales a handful of times at the start of its walk and then never again.
+__device__ inline float ds_running_scale(const f32x16 &ds, float &s_run, f32x16 &lo, f32x16 &hi)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = max(m, abs_bits(ds[r]));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 32, 64));                 // the column's other half
+    const float s_new = fminf(s_run, f16_scale_of(m));                // f16_scale_of(0) = 1: an all-zero tile changes nothing below 1 ...
+    if (m != 0u && s_new != s_run) {                                  // (per lane; rare)
+        const float f = s_new / s_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { lo[r] *= f; hi[r] *= f; }
+        s_run = s_new;
+    }
+    return s_run;
 }
 
 // inverse rotation of a transposed 64 x (lane) gradient held as two f32x16 (rows rowmap(r) and 32 + rowmap(r))
@@ -280,10 +332,17 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
     const int qi = min(q0 + col, a.Nq - 1);
     const bool wave_active = q0 < a.Nq;
 
+    // f16x3: power-of-two operand scales from the tensors' |max| words; the products are un-scaled right behind their MFMAs
+    float sk = 1.f, sv = 1.f, sg = 1.f, sq = 1.f, inv_qk = 1.f, inv_gv = 1.f, s_run = 1.2676506e30f /* 2^100: no dS seen yet */;
+    if (NP == 2) {
+        sq = f16_scale_of(amax_word_read(a.amax_q)); sk = f16_scale_of(amax_word_read(a.amax_k));
+        sv = f16_scale_of(amax_word_read(a.amax_v)); sg = f16_scale_of(amax_word_read(a.amax_g));
+        inv_qk = 1.f / (sq * sk); inv_gv = 1.f / (sg * sv);
+    }
     bf16x8 qf[4][3], gf[4][3];      // Q pre-scaled by scale * log2(e): only S consumes it
-    load_row_pieces<ROPE>(qf, q + (int64_t)b * a.q_sb + (int64_t)qi * a.q_sn + (int64_t)h * a.q_sh, half,
-                          ROPE ? a.qpos + ((int64_t)b * a.Nq + qi) * 2 : nullptr, a.cos_tab, a.sin_tab, a.scale * LOG2E);
-    load_row_pieces<false>(gf, g + (((int64_t)b * a.Nq + qi) * a.H + h) * HD, half, nullptr, nullptr, nullptr, 1.f);
+    load_row_pieces<ROPE, NP>(qf, q + (int64_t)b * a.q_sb + (int64_t)qi * a.q_sn + (int64_t)h * a.q_sh, half,
+                              ROPE ? a.qpos + ((int64_t)b * a.Nq + qi) * 2 : nullptr, a.cos_tab, a.sin_tab, a.scale * LOG2E * sq);
+    load_row_pieces<false, NP>(gf, g + (((int64_t)b * a.Nq + qi) * a.H + h) * HD, half, nullptr, nullptr, nullptr, sg);
     const float lse2 = lse[((int64_t)b * a.H + h) * a.Nq + qi] * LOG2E;
     const float del = delta[((int64_t)b * a.H + h) * a.Nq + qi];
 
@@ -302,22 +361,31 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_q_x6(VitAttnArgs a, const f
     fetch(0);
     for (int k0 = 0; k0 < a.Nk; k0 += TR) {
         __syncthreads();
-        if (tid < 128) store_row_item<ROPE, NP>(s_k, ri, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
-        else store_row_item<false, NP>(s_v, ri, k0, a.Nk, tid - 128, nullptr, nullptr);
-        store_t_item<ROPE, NP>(s_kt, ti, k0, a.Nk, tid, a.cos_tab, a.sin_tab);
+        if (tid < 128) store_row_item<ROPE, NP>(s_k, ri, k0, a.Nk, tid, a.cos_tab, a.sin_tab, sk);
+        else store_row_item<false, NP>(s_v, ri, k0, a.Nk, tid - 128, nullptr, nullptr, sv);
+        store_t_item<ROPE, NP>(s_kt, ti, k0, a.Nk, tid, a.cos_tab, a.sin_tab, sk);
         __syncthreads();
         if (k0 + TR < a.Nk) fetch(k0 + TR);
         if (!wave_active) continue;
         f32x16 st = rows_times_regs<NP>(s_k, col, half, qf);
         f32x16 dp = rows_times_regs<NP>(s_v, col, half, gf);
+        if (NP == 2) mfma_result_fence();
         // element r: key k0 + rowmap(r), query = this lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + rowmap(r, half);
-            const float p = key < a.Nk ? exp2f(st[r] - lse2) : 0.f;
-            dp[r] = p * (dp[r] - del) * a.scale;
+            const float sr = NP == 2 ? st[r] * inv_qk : st[r], dr = NP == 2 ? dp[r] * inv_gv : dp[r];
+            const float p = key < a.Nk ? exp2f(sr - lse2) : 0.f;
+            dp[r] = p * (dr - del) * a.scale;
         }
-        t_times_regs<NP>(s_kt, col, half, dp, dq0, dq1);
+        const float sds = NP == 2 ? ds_running_scale(dp, s_run, dq0, dq1) : 1.f;
+        t_times_regs<NP>(s_kt, col, half, dp, dq0, dq1, sds);
+    }
+    mfma_result_fence();    // (loop exit right behind the last MFMAs: vit_amax.h)
+    if (NP == 2) {          // accumulated under (the lane's final dS scale) x (K's scale)
+        const float f = 1.f / (s_run * sk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq0[r] *= f; dq1[r] *= f; }
     }
     if (q0 + col < a.Nq) {
         if (ROPE) {
@@ -345,10 +413,17 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
     const int ki = min(key0 + col, a.Nk - 1);
     const bool wave_active = key0 < a.Nk;
 
+    float sk = 1.f, sv = 1.f, sg = 1.f, sq = 1.f, inv_qk = 1.f, inv_gv = 1.f, s_run = 1.2676506e30f /* 2^100: no dS seen yet */;
+    constexpr float PSCALE = 16384.f;       // f16x3: the probabilities' scale (p <= 1)
+    if (NP == 2) {
+        sq = f16_scale_of(amax_word_read(a.amax_q)); sk = f16_scale_of(amax_word_read(a.amax_k));
+        sv = f16_scale_of(amax_word_read(a.amax_v)); sg = f16_scale_of(amax_word_read(a.amax_g));
+        inv_qk = 1.f / (sq * sk); inv_gv = 1.f / (sg * sv);
+    }
     bf16x8 kf[4][3], vf[4][3];      // K pre-scaled by scale * log2(e): only S consumes it
-    load_row_pieces<ROPE>(kf, k + (int64_t)b * a.k_sb + (int64_t)ki * a.k_sn + (int64_t)h * a.k_sh, half,
-                          ROPE ? a.kpos + ((int64_t)b * a.Nk + ki) * 2 : nullptr, a.cos_tab, a.sin_tab, a.scale * LOG2E);
-    load_row_pieces<false>(vf, v + (int64_t)b * a.v_sb + (int64_t)ki * a.v_sn + (int64_t)h * a.v_sh, half, nullptr, nullptr, nullptr, 1.f);
+    load_row_pieces<ROPE, NP>(kf, k + (int64_t)b * a.k_sb + (int64_t)ki * a.k_sn + (int64_t)h * a.k_sh, half,
+                              ROPE ? a.kpos + ((int64_t)b * a.Nk + ki) * 2 : nullptr, a.cos_tab, a.sin_tab, a.scale * LOG2E * sk);
+    load_row_pieces<false, NP>(vf, v + (int64_t)b * a.v_sb + (int64_t)ki * a.v_sn + (int64_t)h * a.v_sh, half, nullptr, nullptr, nullptr, sv);
 
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
     const float *qb = q + (int64_t)b * a.q_sb + (int64_t)h * a.q_sh;
@@ -373,10 +448,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
         fetch_t_item<ROPE>(tq, qb, a.q_sn, q0, a.Nq, tid, qpos);
         fetch_t_item<false>(tg, gb, g_sn, q0, a.Nq, tid, nullptr);
         __syncthreads();
-        if (tid < 128) store_row_item<ROPE, NP>(s_q, ri, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
-        else store_row_item<false, NP>(s_g, ri, q0, a.Nq, tid - 128, nullptr, nullptr);
-        store_t_item<ROPE, NP>(s_qt, tq, q0, a.Nq, tid, a.cos_tab, a.sin_tab);
-        store_t_item<false, NP>(s_gt, tg, q0, a.Nq, tid, nullptr, nullptr);
+        if (tid < 128) store_row_item<ROPE, NP>(s_q, ri, q0, a.Nq, tid, a.cos_tab, a.sin_tab, sq);
+        else store_row_item<false, NP>(s_g, ri, q0, a.Nq, tid - 128, nullptr, nullptr, sg);
+        store_t_item<ROPE, NP>(s_qt, tq, q0, a.Nq, tid, a.cos_tab, a.sin_tab, sq);
+        store_t_item<false, NP>(s_gt, tg, q0, a.Nq, tid, nullptr, nullptr, sg);
         if (tid < TR) {
             const int qi = q0 + tid;
             s_lse[tid] = qi < a.Nq ? lse_b[qi] * LOG2E : INFINITY;   // padded queries: P = exp2(-inf) = 0
@@ -387,16 +462,25 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_kv_x6(VitAttnArgs a, const 
         if (!wave_active) continue;
         f32x16 sc = rows_times_regs<NP>(s_q, col, half, kf);
         f32x16 dp = rows_times_regs<NP>(s_g, col, half, vf);
+        if (NP == 2) mfma_result_fence();
         // element r: query q0 + rowmap(r), key = this lane
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = rowmap(r, half);
-            const float p = exp2f(sc[r] - s_lse[qr]);
+            const float sr = NP == 2 ? sc[r] * inv_qk : sc[r], dr = NP == 2 ? dp[r] * inv_gv : dp[r];
+            const float p = exp2f(sr - s_lse[qr]);
             sc[r] = p;                                        // P
-            dp[r] = p * (dp[r] - s_delta[qr]) * a.scale;      // dS (w.r.t. the unscaled dot product)
+            dp[r] = p * (dr - s_delta[qr]) * a.scale;         // dS (w.r.t. the unscaled dot product)
         }
-        t_times_regs<NP>(s_gt, col, half, sc, dv0, dv1);
-        t_times_regs<NP>(s_qt, col, half, dp, dk0, dk1);
+        t_times_regs<NP>(s_gt, col, half, sc, dv0, dv1, PSCALE);
+        const float sds = NP == 2 ? ds_running_scale(dp, s_run, dk0, dk1) : 1.f;
+        t_times_regs<NP>(s_qt, col, half, dp, dk0, dk1, sds);
+    }
+    mfma_result_fence();
+    if (NP == 2) {
+        const float fk = 1.f / (s_run * sq), fv = 1.f / (PSCALE * sg);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk0[r] *= fk; dk1[r] *= fk; dv0[r] *= fv; dv1[r] *= fv; }
     }
     if (key0 + col < a.Nk) {
         if (ROPE) {
@@ -422,8 +506,8 @@ hipError_t launch_attention_bwd_x6(const VitAttnArgs &a, const float *q, const f
         hipLaunchKernelGGL((abx6::k_attn_bwd_kv_x6<RP, NP_>), gkv, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dk, dv);          \
         hipLaunchKernelGGL((abx6::k_attn_bwd_q_x6<RP, NP_>), gq, dim3(256), 0, stream, a, q, k, v, dout, lse, delta, dq);                \
     } while (0)
-    if (a.cos_tab) { if (products == 3) ABX_LAUNCH(true, 3); else ABX_LAUNCH(true, 6); }
-    else { if (products == 3) ABX_LAUNCH(false, 3); else ABX_LAUNCH(false, 6); }
+    if (a.cos_tab) { if (products == 2) ABX_LAUNCH(true, 2); else if (products == 3) ABX_LAUNCH(true, 3); else ABX_LAUNCH(true, 6); }
+    else { if (products == 2) ABX_LAUNCH(false, 2); else if (products == 3) ABX_LAUNCH(false, 3); else ABX_LAUNCH(false, 6); }
 #undef ABX_LAUNCH
     return hipGetLastError();
 }

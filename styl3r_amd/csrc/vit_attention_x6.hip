@@ -57,6 +57,21 @@ __device__ inline void split8(const float *v, bf16x8 &f0, bf16x8 &f1, bf16x8 &f2
     split2(v[6], v[7], q0.w, q1.w, q2.w);
     f0 = __builtin_bit_cast(bf16x8, q0); f1 = __builtin_bit_cast(bf16x8, q1); f2 = __builtin_bit_cast(bf16x8, q2);
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NP == 2 ("f16x3"): eight ALREADY SCALED fp32 values -> two fp16x8 pieces (in bf16x8 registers: only the MFMA reinterprets them)
+__device__ inline void split8h(const float *v, bf16x8 &f0, bf16x8 &f1)
+{
+    uint4 q0, q1;
+    f16_split2(v[0], v[1], q0.x, q1.x);
+    f16_split2(v[2], v[3], q0.y, q1.y);
+    f16_split2(v[4], v[5], q0.z, q1.z);
+    f16_split2(v[6], v[7], q0.w, q1.w);
+    f0 = __builtin_bit_cast(bf16x8, q0); f1 = __builtin_bit_cast(bf16x8, q1);
+}
+template <int NP> __device__ inline void split8p(const float *v, bf16x8 &f0, bf16x8 &f1, bf16x8 &f2)
+{
+    if (NP == 2) split8h(v, f0, f1); else split8(v, f0, f1, f2);
+}
 __device__ inline float wave_xor32(float x)
 {
     float y = x;
@@ -64,10 +79,19 @@ __device__ inline float wave_xor32(float x)
     return (threadIdx.x & 32) ? x : y;
 }
 
-// NP = 6: six partial products, smallest first; NP = 3 ("bf16x3"): without the three 2^-16-level products (see vit_attention_bwd_x6.hip)
+// NP = 6: six partial products, smallest first; NP = 3 ("bf16x3"): without the three 2^-16-level products (see vit_attention_bwd_x6.hip);
+// NP = 2 ("f16x3", round 6): two fp16 pieces per operand, h l' + l h' + h h' on v_mfma_f32_32x32x16_f16 -- 2^-22 per product at the MFMA
+// count of bf16x3.  Operands carry power-of-two scales: Q, K, V from their tensors' |max| words (VitAttnArgs.amax_q / _k / _v), the
+// probabilities the constant 2^14 (p <= 1); the scores are un-scaled before the softmax, the output in the epilogue.
 template <int NP>
 __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c)
 {
+    if (NP == 2) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[1]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, b[0]), c, 0, 0, 0);
+        return c;
+    }
     if (NP == 6) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
@@ -92,7 +116,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
     const int q0 = blockIdx.x * QB + wave * QW;
     const int qi = min(q0 + col, a.Nq - 1);   // clamped: rows beyond Nq compute garbage that is never stored
     const bool wave_active = q0 < a.Nq;
-    const float qscale = a.scale * 1.4426950408889634f;   // scores in the base-2 domain
+    float qscale = a.scale * 1.4426950408889634f;   // scores in the base-2 domain
+    // f16x3: tensor scales (a rotation grows a component by at most sqrt 2: |max| s < 2^15.5, inside fp16's 65 504) and the two inverse factors
+    float sk = 1.f, sv = 1.f, inv_qk = 1.f, inv_pv = 1.f;
+    constexpr float PSCALE = 16384.f;
+    if (NP == 2) {
+        const float sq = f16_scale_of(amax_word_read(a.amax_q));
+        sk = f16_scale_of(amax_word_read(a.amax_k)); sv = f16_scale_of(amax_word_read(a.amax_v));
+        qscale *= sq;
+        inv_qk = 1.f / (sq * sk); inv_pv = 1.f / (PSCALE * sv);
+    }
 
     // ---- Q fragments: step t covers d = 16 t + 8 half + j, j = 0..7; rotated, pre-scaled, split once ----
     bf16x8 qf[4][3];
@@ -120,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[t][j] *= qscale;
-            split8(x[t], qf[t][0], qf[t][1], qf[t][2]);
+            split8p<NP>(x[t], qf[t][0], qf[t][1], qf[t][2]);
         }
     }
 
@@ -170,12 +203,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { u[j] = 0.f; w[j] = 0.f; }
             }
+            if (NP == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { u[j] *= sk; w[j] *= sk; }
+            }
             bf16x8 f0, f1, f2;
             bf16x8 *row = reinterpret_cast<bf16x8 *>(s_k + skey * KROW);
-            split8(u, f0, f1, f2);
+            split8p<NP>(u, f0, f1, f2);
             row[sg * 3 + 0] = f0; row[sg * 3 + 1] = f1;
             if (NP == 6) row[sg * 3 + 2] = f2;
-            split8(w, f0, f1, f2);
+            split8p<NP>(w, f0, f1, f2);
             row[(sg + 2) * 3 + 0] = f0; row[(sg + 2) * 3 + 1] = f1;
             if (NP == 6) row[(sg + 2) * 3 + 2] = f2;
         }
@@ -188,8 +225,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = (k0 + 4 * m_ + e < a.Nk) ? vreg[it][e] : 0.f;
             uint2 w0, w1, w2;                            // packed pairs: low half = first value
-            split2(x[0], x[1], w0.x, w1.x, w2.x);
-            split2(x[2], x[3], w0.y, w1.y, w2.y);
+            if (NP == 2) {
+                f16_split2(x[0] * sv, x[1] * sv, w0.x, w1.x);
+                f16_split2(x[2] * sv, x[3] * sv, w0.y, w1.y);
+            } else {
+                split2(x[0], x[1], w0.x, w1.x, w2.x);
+                split2(x[2], x[3], w0.y, w1.y, w2.y);
+            }
             unsigned char *dst = s_v + lane * VROW + pos * 2;
             *reinterpret_cast<uint2 *>(dst) = w0;
             *reinterpret_cast<uint2 *>(dst + HD * VROW) = w1;
@@ -217,6 +259,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
                     st1 = mfma6<NP>(kf, qf[t], st1);
                 }
             }
+        }
+        mfma_result_fence();            // (the branch around the second block's MFMAs joins here: see vit_amax.h)
+        if (NP == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st0[r] *= inv_qk; st1[r] *= inv_qk; }
         }
         // mask keys beyond Nk: element r of block kb is key k0 + 32 kb + (r&3) + 8 (r>>2) + 4 half
         if (k0 + KT > a.Nk) {
@@ -257,9 +304,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
                 for (int u = 0; u < 2; ++u) {
                     float pv[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pv[j] = blk ? st1[8 * u + j] : st0[8 * u + j];
+                    for (int j = 0; j < 8; ++j) pv[j] = (blk ? st1[8 * u + j] : st0[8 * u + j]) * (NP == 2 ? PSCALE : 1.f);
                     bf16x8 pf[3], vf[3];
-                    split8(pv, pf[0], pf[1], pf[2]);
+                    split8p<NP>(pv, pf[0], pf[1], pf[2]);
                     const unsigned char *vp = va + blk * 64 + u * 32;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8 *>(vp + p * HD * VROW);
@@ -273,9 +320,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_x6(VitAttnArgs a, const flo
     }
 
     // ---- epilogue: O = O^T / l, out[q][d], d = 8g + 4 half + {0..3} (+32) ----
+    mfma_result_fence();                // (loop exit right behind the last P V MFMAs)
     uint32_t omax = 0;              // |max| of the stored values (VitAttnArgs.amax_out)
     if (q0 + col < a.Nq) {
-        const float inv = 1.f / l;
+        const float inv = (NP == 2 ? inv_pv : 1.f) / l;
         if (a.amax_out) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) omax = max(omax, max(abs_bits(o0[r] * inv), abs_bits(o1[r] * inv)));
@@ -298,10 +346,12 @@ hipError_t launch_attention_fwd_x6(const VitAttnArgs &a, const float *q, const f
                                    int products, hipStream_t stream)
 {
     if (a.cos_tab) {
-        if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        if (products == 2) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 2>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        else if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
         else hipLaunchKernelGGL((ax6::k_attn_fwd_x6<true, 6>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
     } else {
-        if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        if (products == 2) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 2>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
+        else if (products == 3) hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 3>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
         else hipLaunchKernelGGL((ax6::k_attn_fwd_x6<false, 6>), grid, dim3(256), 0, stream, a, q, k, v, out, lse);
     }
     return hipGetLastError();

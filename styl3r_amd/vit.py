@@ -20,14 +20,15 @@ from torch import Tensor, nn
 
 from .vit_ops import CALLS, GeluLink, LayerNorm, attention_qkv, fused_linear, memory_efficient_attention
 
-def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False, link=None, link_in=None) -> Tensor:
+def _linear(layer: nn.Linear, x: Tensor, residual: Optional[Tensor] = None, gelu: bool = False, link=None, link_in=None,
+            amax_out: bool = False, amax_dx: bool = False) -> Tensor:
     """Linear layers of the blocks on the fused kernels (bias / exact GELU / residual in the epilogue).  Device tensors ALWAYS take them:
     a contraction length the kernels cannot take (not a multiple of 16: no layer of the model) is an error, not a silent library GEMM.
     CPU tensors (host-side tests of the module logic) take the framework's ops and are counted in vit_ops.CALLS["framework_linear"]."""
     if x.is_cuda:
         if layer.in_features % 16 != 0:
             raise RuntimeError(f"fused Linear: in_features = {layer.in_features} is not a multiple of 16 (zero-pad the contraction as encoder._intrinsics_token does)")
-        return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu, link=link, link_in=link_in)
+        return fused_linear(x, layer.weight, layer.bias, residual=residual, gelu=gelu, link=link, link_in=link_in, amax_out=amax_out, amax_dx=amax_dx)
     CALLS["framework_linear"] += 1
     y = torch.nn.functional.linear(x, layer.weight, layer.bias)
     if gelu:
@@ -72,12 +73,12 @@ class Attention(nn.Module):
 
     def forward(self, x: Tensor, xpos: Tensor, residual: Optional[Tensor] = None) -> Tensor:
         B, N, C = x.shape
-        qkv = _linear(self.qkv, x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv = _linear(self.qkv, x, amax_out=True).view(B, N, 3, self.num_heads, C // self.num_heads)     # (f16x3: the attention's operand scales)
         if qkv.is_cuda and qkv.dtype == torch.float32:
             # packed path: the kernels read the three planes in place and the backward writes ONE (B,N,3,H,64) gradient
             o = attention_qkv(qkv, self.scale, xpos if self.rope is not None else None,
                               self.rope.freq if self.rope is not None else 100.0, self.rope.max_pos if self.rope is not None else 64)
-            return _linear(self.proj, o.reshape(B, N, C), residual=residual)
+            return _linear(self.proj, o.reshape(B, N, C), residual=residual, amax_dx=True)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B,N,H,64) views, no copies
         if self.rope is not None:
             o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=xpos, kpos=xpos, rope_base=self.rope.freq,
@@ -129,15 +130,15 @@ class CrossAttention(nn.Module):
                 residual: Optional[Tensor] = None) -> Tensor:
         B, Nq, C = query.shape
         H = self.num_heads
-        q = _linear(self.projq, query).view(B, Nq, H, C // H)
-        k = _linear(self.projk, key).view(B, key.shape[1], H, C // H)
-        v = _linear(self.projv, value).view(B, value.shape[1], H, C // H)
+        q = _linear(self.projq, query, amax_out=True).view(B, Nq, H, C // H)
+        k = _linear(self.projk, key, amax_out=True).view(B, key.shape[1], H, C // H)
+        v = _linear(self.projv, value, amax_out=True).view(B, value.shape[1], H, C // H)
         if self.rope is not None:
             o = memory_efficient_attention(q, k, v, scale=self.scale, qpos=qpos, kpos=kpos, rope_base=self.rope.freq,
                                            max_pos=self.rope.max_pos)
         else:
             o = memory_efficient_attention(q, k, v, scale=self.scale)
-        return _linear(self.proj, o.reshape(B, Nq, C), residual=residual)
+        return _linear(self.proj, o.reshape(B, Nq, C), residual=residual, amax_dx=True)
 
 
 class DecoderBlock(nn.Module):

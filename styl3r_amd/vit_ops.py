@@ -107,7 +107,8 @@ class VitAttnArgs(C.Structure):
                 ("o_sb", C.c_int64), ("o_sn", C.c_int64), ("o_sh", C.c_int64),
                 ("qpos", C.c_void_p), ("kpos", C.c_void_p), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
                 ("P", C.c_int32), ("dq_sn", C.c_int64), ("dkv_sn", C.c_int64),
-                ("amax_out", C.c_void_p), ("amax_dq", C.c_void_p), ("amax_dk", C.c_void_p), ("amax_dv", C.c_void_p)]
+                ("amax_out", C.c_void_p), ("amax_dq", C.c_void_p), ("amax_dk", C.c_void_p), ("amax_dv", C.c_void_p),
+                ("amax_q", C.c_void_p), ("amax_k", C.c_void_p), ("amax_v", C.c_void_p), ("amax_g", C.c_void_p)]
 
 
 def load() -> C.CDLL:
@@ -319,7 +320,8 @@ def _attn_args(q, k, v, out, scale, rope):
 
 
 ATTENTION_ARITH = os.environ.get("VIT_ATTENTION", "bf16x6")   # attention contractions, forward and backward: "bf16x6" (split arithmetic on the bf16 MFMA, default) | "bf16x3" (three of the six partial products) | "f32" (exact-f32 MFMA)
-_ATTN_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "f16x3": 1}     # (the attention kernels have no fp16-split variant: "f16x3" runs their six-product form)
+_ATTN_MODES = {"f32": 0, "bf16x6": 1, "bf16x3": 2, "f16x3": 3}     # "f16x3" (round 6): two fp16 pieces per operand, three products (rounds 4-5 ran the six-product bf16 form under this name)
+ATTENTION_F16 = os.environ.get("VIT_ATTENTION_F16", "1") == "1"     # A/B switch: 0 = "f16x3" runs the six-product bf16 kernels as in rounds 4-5
 
 
 def _sync_attention_arith(mode: Optional[str] = None) -> None:
@@ -329,9 +331,31 @@ def _sync_attention_arith(mode: Optional[str] = None) -> None:
     if mode not in _ATTN_MODES:
         raise ValueError(f"VIT_ATTENTION = {mode!r}: expected f32, bf16x6, bf16x3 or f16x3")
     want = _ATTN_MODES[mode]
+    if want == 3 and not ATTENTION_F16:
+        want = 1
     lib = load()
     if lib.vit_attention_arith() != want:
         _check(lib.vit_attention_set_arith(want), "vit_attention_set_arith")
+
+
+def _attn_operand_words(a: "VitAttnArgs", mode: str, q, k, v, g=None, packed=None):
+    """attention in "f16x3": the |max| words of the operand tensors (VitAttnArgs.amax_q / _k / _v / _g) -- published by the Linear layers that
+    produced them (fused_linear(amax_out=True) / (amax_dx=True)), else one vit_amax pass each.  `packed`: the (B,N,3,H,64) projection q, k, v are
+    planes of (one word serves all three).  Returns the words (kept alive by the caller until the launch is enqueued)."""
+    if not (mode == "f16x3" and ATTENTION_F16):
+        return None
+    def word(t):
+        return _amax_of(t if t.is_contiguous() else t.contiguous())
+    if packed is not None:
+        wq = wk = wv = word(packed)
+    else:
+        wq, wk, wv = word(q), word(k), word(v)
+    a.amax_q, a.amax_k, a.amax_v = wq.data_ptr(), wk.data_ptr(), wv.data_ptr()
+    wg = None
+    if g is not None:
+        wg = word(g)
+        a.amax_g = wg.data_ptr()
+    return (wq, wk, wv, wg)
 
 
 def _attn_word(a: "VitAttnArgs", field: str, dev) -> Optional[Tensor]:
@@ -355,6 +379,7 @@ class _Attention(torch.autograd.Function):
         rope = (qpos, kpos, base, max_pos) if qpos is not None else None
         a, keep = _attn_args(q, k, v, out, scale, rope)
         word = _attn_word(a, "amax_out", q.device)
+        ctx.words = _attn_operand_words(a, ATTENTION_ARITH, q, k, v)
         _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), _stream(q.device)), "vit_attention_fwd")
         if word is not None:
@@ -380,6 +405,11 @@ class _Attention(torch.autograd.Function):
         a, keep = _attn_args(q, k, v, out, scale, rope)
         delta = torch.empty_like(lse)
         wq, wk, wv = (_attn_word(a, n, q.device) for n in ("amax_dq", "amax_dk", "amax_dv"))       # the projq / projk / projv weight-gradient and dX launches read them
+        if ctx.arith == "f16x3" and ATTENTION_F16:      # the forward's words for q, k, v (same tensors), one more for dO
+            fw = ctx.words
+            a.amax_q, a.amax_k, a.amax_v = fw[0].data_ptr(), fw[1].data_ptr(), fw[2].data_ptr()
+            gw = _amax_of(g)
+            a.amax_g = gw.data_ptr()
         _check(lib.vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                      lse.data_ptr(), g.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                      delta.data_ptr(), _stream(q.device)), "vit_attention_bwd")
@@ -408,6 +438,7 @@ class _AttentionQKV(torch.autograd.Function):
         rope = (pos, pos, base, max_pos) if pos is not None else None
         a, keep = _attn_args(q, k, v, out, scale, rope)
         word = _attn_word(a, "amax_out", qkv.device)
+        ctx.words = _attn_operand_words(a, ATTENTION_ARITH, q, k, v, packed=qkv)
         _check(load().vit_attention_fwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), _stream(qkv.device)), "vit_attention_fwd")
         if word is not None:
@@ -434,6 +465,11 @@ class _AttentionQKV(torch.autograd.Function):
         word = _attn_word(a, "amax_dq", qkv.device)          # ONE word for the packed gradient: both kernels fold into it
         if word is not None:
             a.amax_dk = a.amax_dv = a.amax_dq
+        if ctx.arith == "f16x3" and ATTENTION_F16:
+            fw = ctx.words
+            a.amax_q = a.amax_k = a.amax_v = fw[0].data_ptr()
+            gw = _amax_of(g)
+            a.amax_g = gw.data_ptr()
         _check(load().vit_attention_bwd(C.byref(a), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                         lse.data_ptr(), g.data_ptr(), base_ptr, base_ptr + plane, base_ptr + 2 * plane,
                                         delta.data_ptr(), _stream(qkv.device)), "vit_attention_bwd")
@@ -1361,7 +1397,7 @@ class _FusedLinear(torch.autograd.Function):
     GEMMs through torch / hipBLASLt."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, link=None, link_in=None):
+    def forward(ctx, x, weight, bias, residual, act, link=None, link_in=None, amax_out=False, amax_dx=False):
         _need_gpu(x, "linear")
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous().float()
@@ -1382,8 +1418,12 @@ class _FusedLinear(torch.autograd.Function):
         # f16x3: |max| of the input (shared with the weight-gradient launch).  An fc2 takes the word its fc1's epilogue filled (GeluLink.ax)
         # instead of a pass over the (M, 4 C) hidden activation; an fc1 asks its own epilogue for that word
         publish = f16 and link is not None and need_pre and ring in (0, 1, 3)
+        # amax_out: the consumer of this layer's output wants its |max| (the attention kernels in f16x3: q, k, v scales) -- the epilogue publishes it
+        out_word = None
+        ctx.amax_dx = bool(amax_dx)
 
         def operands():
+            nonlocal out_word
             if not f16:
                 return
             ctx.ax = link_in.ax if (link_in is not None and link_in.ax is not None) else _amax_of(x2)
@@ -1391,6 +1431,9 @@ class _FusedLinear(torch.autograd.Function):
             if publish:
                 link.ax = _AMAX.word(x2.device)
                 _check(load().vit_x6_set_output_amax(link.ax.data_ptr()), "vit_x6_set_output_amax")
+            elif amax_out and PUBLISH_AMAX and ring in (0, 1, 3) and act == 0:
+                out_word = _AMAX.word(x2.device)
+                _check(load().vit_x6_set_output_amax(out_word.data_ptr()), "vit_x6_set_output_amax")
         if x6 and PAIR_SPLIT and x.requires_grad and N % 16 == 0 and K % 8 == 0 and not _fresh(_SPLIT_CACHE.get(_image_key(weight, bool(ring), False)), weight):
             # the forward image is stale (the optimizer stepped): the backward's input-gradient GEMM will need the transposed image of the
             # same values -- both in one launch, each in the layout its kernel takes (the dX dispatch rule of `backward` below)
@@ -1409,6 +1452,8 @@ class _FusedLinear(torch.autograd.Function):
             _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), *args), "vit_linear_x6_fwd")
         else:
             _check(load().vit_linear_fwd(x2.data_ptr(), w.data_ptr(), *args), "vit_linear_fwd")
+        if out_word is not None:
+            _publish(out, out_word)
         ctx.save_for_backward(x2, w, pre)
         # GeluLink: `link` (this layer applies the GELU) publishes its pre-activation; `link_in` (this layer consumes that GELU's
         # output) lets the backward run GELU' inside its input-gradient GEMM -- see GeluLink
@@ -1447,11 +1492,18 @@ class _FusedLinear(torch.autograd.Function):
                 ag = _amax_of(t)
             return ag
 
+        dx_word = None
+
         def publish_dx(lk, ring):
+            nonlocal dx_word
             # (fc2, GELU' in the epilogue: the stored values ARE fc1's dY)
             if f16 and lk is not None and gelu_pre is not None and ring in (0, 1, 3):
                 lk.adx = _AMAX.word(g.device)
                 _check(load().vit_x6_set_output_amax(lk.adx.data_ptr()), "vit_x6_set_output_amax")
+            elif f16 and ctx.amax_dx and PUBLISH_AMAX and gelu_pre is None and ring in (0, 1, 3):
+                # (proj: its input gradient is the attention backward's dO, whose f16x3 scale comes from this word)
+                dx_word = _AMAX.word(g.device)
+                _check(load().vit_x6_set_output_amax(dx_word.data_ptr()), "vit_x6_set_output_amax")
         dx = None
         if need_x:
             N, K = w.shape
@@ -1482,6 +1534,8 @@ class _FusedLinear(torch.autograd.Function):
                            "vit_linear_x6_fwd (dX)")
                 if gelu_pre is not None:
                     lk.fused = True
+                if dx_word is not None:
+                    _publish(dx, dx_word)
                 dx = dx.reshape(shp)
             else:
                 dx = (g2 @ w).reshape(shp)
@@ -1508,7 +1562,7 @@ class _FusedLinear(torch.autograd.Function):
                 db = bslot["view"].detach()
             if has_bias and need_b and bslot is None:
                 db = g2.sum(0)
-            return dx, dw, db, g_res, None, None, None
+            return dx, dw, db, g_res, None, None, None, None, None
         if need_w and ctx.weight_ref is not None:         # dW (+ db in the same pass) on the bf16x6 kernel
             g2c = g2.contiguous().float()
             N, K = w.shape
@@ -1524,7 +1578,7 @@ class _FusedLinear(torch.autograd.Function):
             dw = g2.t() @ x2 if need_w else None          # frozen layers (style stage) skip the weight GEMM
         if db is None and has_bias and need_b:
             db = g2.sum(0)
-        return dx, dw, db, g_res, None, None, None
+        return dx, dw, db, g_res, None, None, None, None, None
 
 
 class GeluLink:
@@ -1542,8 +1596,11 @@ class GeluLink:
 
 
 def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, residual: Optional[Tensor] = None,
-                 gelu: bool = False, link: Optional[GeluLink] = None, link_in: Optional[GeluLink] = None) -> Tensor:
-    """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd).  link / link_in: see GeluLink."""
+                 gelu: bool = False, link: Optional[GeluLink] = None, link_in: Optional[GeluLink] = None,
+                 amax_out: bool = False, amax_dx: bool = False) -> Tensor:
+    """[residual +] [gelu](x @ weight.T + bias) in one kernel (vit_linear_fwd).  link / link_in: see GeluLink.
+    amax_out / amax_dx (f16x3): publish the |max| of the output / of the input gradient from the producing GEMM's epilogue -- the attention
+    kernels take their operand scales from those words (qkv, projq / projk / projv outputs; proj's input gradient = the attention's dO)."""
     if not torch.is_grad_enabled() and _x6() and x.is_cuda and x.dtype == torch.float32:
         # serving path: no autograd node, no saved tensors, straight to the kernel
         shp = x.shape
@@ -1559,13 +1616,19 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
             if not res2.is_contiguous() or res2.dtype != torch.float32:
                 res2 = res2.contiguous().float()
         wp = split_weight(weight)
+        ow = None
         if _f16():
             _announce(_amax_of(x2))
+            if amax_out and PUBLISH_AMAX and not gelu:
+                ow = _AMAX.word(x2.device)
+                _check(load().vit_x6_set_output_amax(ow.data_ptr()), "vit_x6_set_output_amax")
         _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
                                         res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
                                         1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
+        if ow is not None:
+            _publish(out, ow)
         return out.reshape(*shp[:-1], N)
-    return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0, link, link_in)
+    return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0, link, link_in, amax_out, amax_dx)
 
 
 # --------------------------------------------------------------------------- LayerNorm (E2, E5, E6: norm1..3, norm_y, enc/dec_norm)

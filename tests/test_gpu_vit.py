@@ -49,14 +49,15 @@ def test_rope_kernel_matches_reference_golden_and_is_inplace_on_views():
     assert torch.equal(qkv[:, :, 1:], before[:, :, 1:])   # k, v untouched
 
 
-@pytest.fixture(params=["bf16x6", "f32"])
+@pytest.fixture(params=["bf16x6", "f32", "f16x3"])
 def attention_arith(request, monkeypatch):
-    """both kernel families, forward and backward: bf16x6 split arithmetic (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; the
-    default) and exact-f32 MFMA (csrc/vit_attention.hip, vit_attention_bwd.hip)"""
+    """every kernel family, forward and backward: bf16x6 split arithmetic (csrc/vit_attention_x6.hip, vit_attention_bwd_x6.hip; the
+    default), exact-f32 MFMA (csrc/vit_attention.hip, vit_attention_bwd.hip), and f16x3 (round 6: the split kernels on two fp16 pieces per
+    operand and three products, operand scales from |max| words, per-lane running scale for dS) -- all against the same oracle bars"""
     from styl3r_amd import vit_ops
     monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", request.param)
     yield request.param
-    assert vit_ops.load().vit_attention_arith() == (1 if request.param == "bf16x6" else 0)     # the launch really took that kernel
+    assert vit_ops.load().vit_attention_arith() == {"bf16x6": 1, "f32": 0, "f16x3": 3}[request.param]     # the launch really took that kernel
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,rope", [(2, 3, 257, 257, True), (1, 2, 130, 771, False), (3, 12, 514, 256, True)])
@@ -71,11 +72,11 @@ def test_attention_three_product_mode_forward_and_backward(B, H, Nq, Nk, rope, m
     qpos = (torch.arange(Nq, device=DEV)[None, :, None].expand(B, -1, 2) % 17).contiguous() if rope else None
     kpos = (torch.arange(Nk, device=DEV)[None, :, None].expand(B, -1, 2) % 17).contiguous() if rope else None
     res = {}
-    for mode in ("bf16x3", "bf16x6"):
+    for mode in ("bf16x3", "bf16x6", "f16x3"):
         monkeypatch.setattr(vit_ops, "ATTENTION_ARITH", mode)
         q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
         o = vit_ops.memory_efficient_attention(q, k, v, scale=0.125, qpos=qpos, kpos=kpos, rope_base=100.0, max_pos=16)
-        assert vit_ops.load().vit_attention_arith() == (2 if mode == "bf16x3" else 1)
+        assert vit_ops.load().vit_attention_arith() == {"bf16x3": 2, "bf16x6": 1, "f16x3": 3}[mode]
         (o * go).sum().backward()
         res[mode] = [t.detach().double().cpu() for t in (o, q.grad, k.grad, v.grad)]
     # float64 reference
@@ -98,11 +99,16 @@ def test_attention_three_product_mode_forward_and_backward(B, H, Nq, Nk, rope, m
     od = ref_attn(qd, kd, vd)
     (od * go.double().cpu()).sum().backward()
     want = [od.detach(), qd.grad, kd.grad, vd.grad]
-    for name, a3, a6, w in zip(("out", "dq", "dk", "dv"), res["bf16x3"], res["bf16x6"], want):
+    errs = {}
+    for name, a3, a6, ah, w in zip(("out", "dq", "dk", "dv"), res["bf16x3"], res["bf16x6"], res["f16x3"], want):
         e3 = float((a3 - w).abs().max() / w.abs().max()); e6 = float((a6 - w).abs().max() / w.abs().max())
+        eh = float((ah - w).abs().max() / w.abs().max())
+        errs[name] = (e3, e6, eh)
         assert e6 <= 5e-6, (name, e6)
         assert e3 <= 5e-5, (name, e3)
-    assert not torch.equal(res["bf16x3"][0], res["bf16x6"][0])
+        assert eh <= 5e-6, (name, eh)          # f16x3 (three products on fp16 pieces): the six-product bar
+    print("attention error vs float64 (bf16x3, bf16x6, f16x3):", errs)
+    assert not torch.equal(res["bf16x3"][0], res["bf16x6"][0]) and not torch.equal(res["f16x3"][0], res["bf16x6"][0])
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk", [(2, 3, 257, 257), (1, 2, 130, 771), (2, 12, 64, 64), (1, 1, 5, 1), (11, 16, 257, 257), (11, 16, 260, 129), (1, 1, 1025, 1025)])
