@@ -79,11 +79,13 @@ def _build_noposplat():
 
 
 @pytest.mark.gpu
-def test_encoder_forward_in_bf16x3_mode_stays_within_the_1e_4_bar(monkeypatch):
-    """VIT_LINEAR_MODE=bf16x3 (three partial products per GEMM launch): the Gaussians still match the reference fixture to the
-    north_star bar of 1e-4; what the mode gives up is gradient noise deep in the network (observed 5e-3 on the stylizer's projk
-    weight against 1e-4 .. 6e-4 in bf16x6 mode -- the same order as the reference's own fp32 run on the mid-size fixture), which is
-    why it is opt-in."""
+def test_encoder_forward_in_bf16x3_mode_is_an_order_looser_than_the_default_modes(monkeypatch):
+    """VIT_LINEAR_MODE=bf16x3 (three partial products per GEMM launch) is opt-in and is NOT offered as meeting north_star's 1e-4:
+    on this fixture its covariances land between 4.8e-5 and 1.07e-4 from one process to the next (nine runs on two trees,
+    profiles/r06_run_to_run_spread.txt: the split-K summation order moves an activation across a bf16 rounding boundary and the
+    dropped middle x middle product moves with it), against 6e-6 .. 7e-6 in the bf16x6 and f16x3 modes that the parity tests and the
+    bench run in.  The bars here say what the mode delivers: 1e-4 for means / harmonics / opacities (observed <= 7e-5), 2e-4 for the
+    covariances.  Deep in the network it also gives up gradient accuracy (5e-3 on the stylizer's projk weight against 1e-4 .. 6e-4)."""
     from styl3r_amd import vit_ops
     from tests.gpu_utils import assert_close_rel
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x3")
@@ -94,7 +96,7 @@ def test_encoder_forward_in_bf16x3_mode_stays_within_the_1e_4_bar(monkeypatch):
         gs = m(dict(image=T("image"), intrinsics=T("intrinsics")), dict(image=T("style")), global_step=0)
     assert vit_ops.load().vit_x6_products() == 3
     assert_close_rel(gs.means.cpu().numpy(), G[f"{tag}_means"], 1e-4, "means")
-    assert_close_rel(gs.covariances.cpu().numpy(), G[f"{tag}_cov"], 1e-4, "covariances")
+    assert_close_rel(gs.covariances.cpu().numpy(), G[f"{tag}_cov"], 2e-4, "covariances")
     assert_close_rel(gs.harmonics.cpu().numpy(), G[f"{tag}_sh"], 1e-4, "harmonics")
     assert_close_rel(gs.opacities.cpu().numpy(), G[f"{tag}_opac"], 1e-4, "opacities")
     monkeypatch.setattr(vit_ops, "LINEAR_MODE", "bf16x6")
