@@ -192,6 +192,18 @@ typedef struct VitSplitJob {
 int vit_split_weights_many(const VitSplitJob *jobs_device, int n_jobs, uint32_t total_blocks, void *stream);
 int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                        int M, int N, int K, int act, int cfg, void *stream);
+
+/* Small row counts (round 6; batch-1 serving: 257 / 514 token rows -- infer_model_re10k.py:262-560): vit_linear_x6r_fwd with cfg = 5 runs
+ * csrc/vit_gemm_sm.hip on the BLOCK image: 32- / 64-row x 64-column tiles, the contraction split over the 4 / 8 waves of a workgroup, every wave
+ * streaming its own operands without a workgroup barrier (weight pieces straight from the block image into MFMA registers, activations
+ * row-contiguous -> split -> a wave-private LDS double buffer), the partial tiles reduced once through LDS in wave order (deterministic) and the
+ * FULL epilogue (bias, GELU / GELU', residual, `pre`, the |max| word) in the same launch: no zero-fill launch, no atomics, no vit_amax pass
+ * behind it.  Same operands, same split functions as the other kernels.  vit_linear_sm_ok(M, N, K): 1 when the shape is served (M <= max_rows,
+ * N % 64 == 0, K a multiple of 64 x waves), else the caller keeps vit_linear_x6_fwd; cfg 5 on an unserved shape is VIT_EINVAL.
+ * vit_linear_sm_set: max_rows (default 1024; 0 = never, the A/B switch), tile_row_blocks (0 | 1 | 2) and waves (0 | 4 | 8) force the tile rows
+ * (x 32) and the waves per workgroup, 0 = the built-in rule.  Per host thread. */
+int vit_linear_sm_set(int max_rows, int tile_row_blocks, int waves);
+int vit_linear_sm_ok(int M, int N, int K);
 /*
  * The ping-pong kernel (cfg 3 above: 256 x 256 tiles, one workgroup per CU) with an S-way split of K whose partial tiles meet in a
  * caller-owned workspace (vit_linear_x6c_workspace_bytes; plain stores, one ticket per tile, the last arriver reduces and runs the
@@ -210,6 +222,7 @@ int vit_linear_x6c_fwd(const float *x, const void *w_packed, const float *bias, 
  * GELU, no bias, `pre` must be NULL) -- the separate GeluBackward pass over the (M, 4 dim) hidden gradient disappears. */
 int vit_linear_x6_fwd(const float *x, const void *w_packed, const float *bias, const float *residual, float *out, float *pre,
                       int M, int N, int K, int act, void *stream);
+
 
 /*
  * Weight and bias gradient of the same Linear in bf16x6 arithmetic:

@@ -58,6 +58,8 @@ int split_weight_pair(const float *w, void *packed_f, void *packed_t, int rows, 
 int split_weights_many(const VitSplitJob *jobs_dev, int njobs, uint32_t total_blocks, hipStream_t stream);
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                    int K, int act, int cfg, hipStream_t stream);
+int linear_sm_set(int max_rows, int tm, int nw);
+int linear_sm_ok(int M, int N, int K);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
 }  // namespace vit
@@ -145,6 +147,9 @@ VIT_EXPORT int vit_split_weights_many(const VitSplitJob *jobs_device, int n_jobs
 {
     return vit::split_weights_many(jobs_device, n_jobs, total_blocks, static_cast<hipStream_t>(stream));
 }
+
+VIT_EXPORT int vit_linear_sm_set(int max_rows, int tile_row_blocks, int waves) { return vit::linear_sm_set(max_rows, tile_row_blocks, waves); }
+VIT_EXPORT int vit_linear_sm_ok(int M, int N, int K) { return vit::linear_sm_ok(M, N, K); }
 
 VIT_EXPORT size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits) { return vit::x6c_workspace_bytes(M, N, splits); }
 VIT_EXPORT int vit_linear_x6c_choose_splits(int M, int N, int K) { return vit::x6c_choose_splits(M, N, K); }

@@ -889,10 +889,21 @@ int split_weight_block(const float *w, void *packed, int rows, int cols, int tra
 
 // cfg: 1 = ring kernel, 128 x 128 tiles, 3 stages, two workgroups per CU; 2 = ring kernel, 256 x 256 tiles (8 waves);
 // 3 = convert-once ping-pong kernel, 256 x 256 tiles.  (tools/probes/gemm_lab.py sweeps them against vit_linear_x6_fwd.)
+// vit_gemm_sm.hip: the small-M kernel on the block image (cfg 5: no split-K, no zero fill, fused epilogue, |max| word)
+int linear_sm_fwd(const float *x, const void *wpb, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K, int act,
+                  const uint32_t *am_x, const uint32_t *am_w, uint32_t *am_out, hipStream_t stream);
+
 int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                    int K, int act, int cfg, hipStream_t stream)
 {
     if (!x || !wp || !out) return VIT_EINVAL;
+    if (cfg == 5) {
+        if (M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre))) return VIT_EINVAL;
+        const uint32_t *ax, *unused;
+        x6_take_amax(ax, unused);
+        const uint32_t *aw = reinterpret_cast<const uint32_t *>(static_cast<const char *>(wp) + (size_t)((N + 63) / 64) * 64 * (size_t)K * 6);
+        return linear_sm_fwd(x, wp, bias, residual, out, pre, M, N, K, act, ax, aw, x6_take_output_amax(), stream);
+    }
     if (M <= 0 || N <= 0 || K <= 0 || (K % x6r::BK) != 0 || act < 0 || act > 2 || (act == 2 && (!residual || pre || (cfg != 1 && cfg != 3))) ||
         !((cfg >= 1 && cfg <= 4) || (cfg >= 34 && cfg <= 40))) return VIT_EINVAL;   // 32 + S: cfg 3 with an S-way K split; act 2: see vit_linear_x6_fwd
     const uint4 *w4 = static_cast<const uint4 *>(wp);

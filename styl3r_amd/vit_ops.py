@@ -27,6 +27,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import threading
 import weakref
 from pathlib import Path
 from typing import Optional
@@ -37,9 +38,9 @@ from torch import Tensor, nn
 _PKG = Path(__file__).resolve().parent
 _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / os.environ.get("VIT_LIB_NAME", "libvit_hip.so")     # VIT_LIB_NAME: kernel-experiment builds (tools/ only); the product is libvit_hip.so
-_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
+_SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_sm.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_conv_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_conv_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_sm_set", "vit_linear_sm_ok", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -167,6 +168,10 @@ def load() -> C.CDLL:
     lib.vit_linear_x6r_fwd.restype = C.c_int
     lib.vit_linear_x6_fwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_fwd.restype = C.c_int
+    lib.vit_linear_sm_set.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vit_linear_sm_set.restype = C.c_int
+    lib.vit_linear_sm_ok.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vit_linear_sm_ok.restype = C.c_int
     lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_wgrad.restype = C.c_int
     lib.vit_linear_x6_wgrad_acc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -523,6 +528,7 @@ def _x6() -> bool:
     lib = load()
     if lib.vit_x6_products() != want:
         _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
+    _sync_small_m()
     return True
 
 def _pin_products(mode: str) -> None:
@@ -534,6 +540,7 @@ def _pin_products(mode: str) -> None:
         lib = load()
         if lib.vit_x6_products() != want:
             _check(lib.vit_x6_set_products(want), "vit_x6_set_products")
+        _sync_small_m()
 
 
 _SPLIT_CACHE: dict = {}   # (id(weight), layout[, "f16"]) -> (weakref(weight), weight._version, data_ptr, packed uint8 tensor)
@@ -1386,6 +1393,8 @@ RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
 
 def _ring_cfg(M: int, N: int, K: int) -> int:
+    if M <= SMALL_M_ROWS and small_m_kernel(M, N, K):
+        return 5                    # csrc/vit_gemm_sm.hip (batch-1 serving row counts; the tiny trunks of the tests)
     if not RING_DISPATCH or M < 2048:
         return 0
     return (_RING_SHAPES if M >= 4096 else _RING_SHAPES_MID).get(LINEAR_MODE, {}).get((N, K), 0)
@@ -1417,7 +1426,7 @@ class _FusedLinear(torch.autograd.Function):
         f16 = x6 and _f16()
         # f16x3: |max| of the input (shared with the weight-gradient launch).  An fc2 takes the word its fc1's epilogue filled (GeluLink.ax)
         # instead of a pass over the (M, 4 C) hidden activation; an fc1 asks its own epilogue for that word
-        publish = f16 and link is not None and need_pre and ring in (0, 1, 3)
+        publish = f16 and link is not None and need_pre and ring in (0, 1, 3, 5)
         # amax_out: the consumer of this layer's output wants its |max| (the attention kernels in f16x3: q, k, v scales) -- the epilogue publishes it
         out_word = None
         ctx.amax_dx = bool(amax_dx)
@@ -1431,13 +1440,15 @@ class _FusedLinear(torch.autograd.Function):
             if publish:
                 link.ax = _AMAX.word(x2.device)
                 _check(load().vit_x6_set_output_amax(link.ax.data_ptr()), "vit_x6_set_output_amax")
-            elif amax_out and PUBLISH_AMAX and ring in (0, 1, 3) and act == 0:
+            elif amax_out and PUBLISH_AMAX and ring in (0, 1, 3, 5) and act == 0:
                 out_word = _AMAX.word(x2.device)
                 _check(load().vit_x6_set_output_amax(out_word.data_ptr()), "vit_x6_set_output_amax")
         if x6 and PAIR_SPLIT and x.requires_grad and N % 16 == 0 and K % 8 == 0 and not _fresh(_SPLIT_CACHE.get(_image_key(weight, bool(ring), False)), weight):
             # the forward image is stale (the optimizer stepped): the backward's input-gradient GEMM will need the transposed image of the
             # same values -- both in one launch, each in the layout its kernel takes (the dX dispatch rule of `backward` below)
-            ring_dx = _ring_cfg(M, K, N) if LINEAR_MODE in ("bf16x3", "f16x3") else 0
+            ring_dx = _ring_cfg(M, K, N)
+            if ring_dx != 5 and LINEAR_MODE not in ("bf16x3", "f16x3"):
+                ring_dx = 0
             split_weight_pair(weight, bool(ring), bool(ring_dx))
         if ring:
             # LDS-DMA ring kernels (csrc/vit_gemm_x6r.hip), bit-identical to vit_linear_x6_fwd: taken on the shapes where
@@ -1497,10 +1508,10 @@ class _FusedLinear(torch.autograd.Function):
         def publish_dx(lk, ring):
             nonlocal dx_word
             # (fc2, GELU' in the epilogue: the stored values ARE fc1's dY)
-            if f16 and lk is not None and gelu_pre is not None and ring in (0, 1, 3):
+            if f16 and lk is not None and gelu_pre is not None and ring in (0, 1, 3, 5):
                 lk.adx = _AMAX.word(g.device)
                 _check(load().vit_x6_set_output_amax(lk.adx.data_ptr()), "vit_x6_set_output_amax")
-            elif f16 and ctx.amax_dx and PUBLISH_AMAX and gelu_pre is None and ring in (0, 1, 3):
+            elif f16 and ctx.amax_dx and PUBLISH_AMAX and gelu_pre is None and ring in (0, 1, 3, 5):
                 # (proj: its input gradient is the attention backward's dO, whose f16x3 scale comes from this word)
                 dx_word = _AMAX.word(g.device)
                 _check(load().vit_x6_set_output_amax(dx_word.data_ptr()), "vit_x6_set_output_amax")
@@ -1513,7 +1524,9 @@ class _FusedLinear(torch.autograd.Function):
                 lk = ctx.link_in
                 gelu_pre = lk.pre if (lk is not None and lk.pre is not None and tuple(lk.pre.shape) == (g2c.shape[0], K)) else None
                 # (input-gradient GEMMs take the ring kernels in three-product mode only: in six-product mode the A/B on the whole step lost 3 ms)
-                ring = _ring_cfg(g2c.shape[0], K, N) if (ctx.mode == LINEAR_MODE and ctx.mode in ("bf16x3", "f16x3")) else 0
+                ring = _ring_cfg(g2c.shape[0], K, N) if ctx.mode == LINEAR_MODE else 0
+                if ring != 5 and ctx.mode not in ("bf16x3", "f16x3"):
+                    ring = 0
                 if ring:
                     CALLS["linear_x6r"] += 1
                     wpb = split_weight_block(ctx.weight_ref, True)
@@ -1581,6 +1594,24 @@ class _FusedLinear(torch.autograd.Function):
         return dx, dw, db, g_res, None, None, None, None, None
 
 
+SMALL_M_ROWS = int(os.environ.get("VIT_SMALL_M_ROWS", "1024"))      # vit_linear_sm_set(max_rows): 0 = the 128-row-tile kernel at every M (A/B switch)
+_SMALL_M_SET: dict = {}                                              # host thread -> the max_rows this thread last told the library
+
+
+def small_m_kernel(M: int, N: int, K: int) -> bool:
+    """does vit_linear_x6_fwd take the small-M kernel for this shape?  (the rule of csrc/vit_gemm_sm.hip linear_sm_ok; also keeps the library's
+    per-thread max_rows in step with SMALL_M_ROWS, which tests and benchmarks flip at run time)"""
+    _sync_small_m()
+    return SMALL_M_ROWS > 0 and M <= SMALL_M_ROWS and bool(load().vit_linear_sm_ok(M, N, K))
+
+
+def _sync_small_m() -> None:
+    tid = threading.get_ident()
+    if _SMALL_M_SET.get(tid) != SMALL_M_ROWS:
+        _check(load().vit_linear_sm_set(SMALL_M_ROWS, 0, 0), "vit_linear_sm_set")
+        _SMALL_M_SET[tid] = SMALL_M_ROWS
+
+
 class GeluLink:
     """Ties the two Linear layers of an Mlp (fc1 -> GELU -> fc2, blocks.py:76-82) together for the backward: fc1's node publishes
     the GELU's pre-activation here, fc2's node -- whose input-gradient GEMM produces exactly the gradient of the GELU's output -- runs
@@ -1615,16 +1646,25 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
             res2 = residual.reshape(-1, N)
             if not res2.is_contiguous() or res2.dtype != torch.float32:
                 res2 = res2.contiguous().float()
-        wp = split_weight(weight)
+        small = small_m_kernel(M, N, K)
+        wp = split_weight_block(weight) if small else split_weight(weight)
         ow = None
         if _f16():
             _announce(_amax_of(x2))
-            if amax_out and PUBLISH_AMAX and not gelu:
+            # the small-M kernel (csrc/vit_gemm_sm.hip) runs the whole epilogue in one launch, GELU included: every output gets its |max| word
+            # for free (the next Linear / the attention finds it published); the 128-row kernel publishes un-activated outputs on request
+            if PUBLISH_AMAX and ((amax_out and not gelu) or small):
                 ow = _AMAX.word(x2.device)
                 _check(load().vit_x6_set_output_amax(ow.data_ptr()), "vit_x6_set_output_amax")
-        _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
-                                        1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
+        if small:
+            CALLS["linear_sm"] = CALLS.get("linear_sm", 0) + 1
+            _check(load().vit_linear_x6r_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                             res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
+                                             1 if gelu else 0, 5, _stream(x.device)), "vit_linear_x6r_fwd (small M)")
+        else:
+            _check(load().vit_linear_x6_fwd(x2.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            res2.data_ptr() if res2 is not None else None, out.data_ptr(), None, M, N, K,
+                                            1 if gelu else 0, _stream(x.device)), "vit_linear_x6_fwd")
         if ow is not None:
             _publish(out, ow)
         return out.reshape(*shp[:-1], N)
