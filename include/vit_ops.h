@@ -204,6 +204,18 @@ int vit_linear_x6r_fwd(const float *x, const void *w_packed, const float *bias, 
  * (x 32) and the waves per workgroup, 0 = the built-in rule.  Per host thread. */
 int vit_linear_sm_set(int max_rows, int tile_row_blocks, int waves);
 int vit_linear_sm_ok(int M, int N, int K);
+
+/* Serving path of the dual decoders (backbone_croco_multiview.py:147-188 at two context views: decoder 1 on view 0, decoder 2 on view 1, the
+ * same layer shapes with two weight sets): TWO problems of one shape per launch.  The arrays hold `groups` (1 or 2) HOST-side arrays of device
+ * pointers -- they are read at the call and travel as kernel arguments.  vit_linear_sm_grouped: out_g = [residual_g +] act(x_g . w_g^T + bias_g)
+ * on the block images w_block[g] (the shape must satisfy vit_linear_sm_ok); bias / residual may be NULL (or hold NULL entries).  The activation
+ * |max| word announced with vit_x6_set_operand_amax covers BOTH inputs, the word of vit_x6_set_output_amax both outputs (the stacked tensors are
+ * one tensor with one scale).  vit_layernorm_fwd_grouped: y_g = LayerNorm(x_g; gamma_g, beta_g) over M rows of C each, the operations of
+ * vit_layernorm_fwd (results within 1 ulp of it; no mean / rstd: forward only). */
+int vit_linear_sm_grouped(const float *const *x, const void *const *w_block, const float *const *bias, const float *const *residual,
+                          float *const *out, int groups, int M, int N, int K, int act, void *stream);
+int vit_layernorm_fwd_grouped(const float *const *x, const float *const *gamma, const float *const *beta, float *const *y, int groups,
+                              int M, int C, float eps, void *stream);
 /*
  * The ping-pong kernel (cfg 3 above: 256 x 256 tiles, one workgroup per CU) with an S-way split of K whose partial tiles meet in a
  * caller-owned workspace (vit_linear_x6c_workspace_bytes; plain stores, one ticket per tile, the last arriver reduces and runs the

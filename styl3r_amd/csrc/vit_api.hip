@@ -60,6 +60,10 @@ int linear_x6r_fwd(const float *x, const void *wp, const float *bias, const floa
                    int K, int act, int cfg, hipStream_t stream);
 int linear_sm_set(int max_rows, int tm, int nw);
 int linear_sm_ok(int M, int N, int K);
+int linear_sm_grouped(const float *const *x, const void *const *wpb, const float *const *bias, const float *const *residual, float *const *out,
+                      int groups, int M, int N, int K, int act, hipStream_t stream);
+int layernorm_fwd_grouped(const float *const *x, const float *const *gamma, const float *const *beta, float *const *y, int groups, int M, int C,
+                          float eps, hipStream_t stream);
 int linear_x6_fwd(const float *x, const void *wp, const float *bias, const float *residual, float *out, float *pre, int M, int N,
                   int K, int act, hipStream_t stream);
 }  // namespace vit
@@ -150,6 +154,16 @@ VIT_EXPORT int vit_split_weights_many(const VitSplitJob *jobs_device, int n_jobs
 
 VIT_EXPORT int vit_linear_sm_set(int max_rows, int tile_row_blocks, int waves) { return vit::linear_sm_set(max_rows, tile_row_blocks, waves); }
 VIT_EXPORT int vit_linear_sm_ok(int M, int N, int K) { return vit::linear_sm_ok(M, N, K); }
+VIT_EXPORT int vit_linear_sm_grouped(const float *const *x, const void *const *w_block, const float *const *bias, const float *const *residual,
+                                    float *const *out, int groups, int M, int N, int K, int act, void *stream)
+{
+    return vit::linear_sm_grouped(x, w_block, bias, residual, out, groups, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+VIT_EXPORT int vit_layernorm_fwd_grouped(const float *const *x, const float *const *gamma, const float *const *beta, float *const *y, int groups,
+                                         int M, int C, float eps, void *stream)
+{
+    return vit::layernorm_fwd_grouped(x, gamma, beta, y, groups, M, C, eps, static_cast<hipStream_t>(stream));
+}
 
 VIT_EXPORT size_t vit_linear_x6c_workspace_bytes(int M, int N, int splits) { return vit::x6c_workspace_bytes(M, N, splits); }
 VIT_EXPORT int vit_linear_x6c_choose_splits(int M, int N, int K) { return vit::x6c_choose_splits(M, N, K); }

@@ -74,19 +74,28 @@ __device__ inline int a_slot(int row, int g) { return row * 4 + (g ^ ((row >> 2)
 // TM: 32-row MFMA blocks per tile (tile = 32 TM rows x 64 columns = one block row of the weight image); NW: waves per workgroup = contraction
 // ranges; NPROD: 6 / 3 (bf16 pieces) or 2 (fp16 pieces).  act: 0 none, 1 exact GELU, 2 "times GELU'(residual)" (the input-gradient GEMM behind
 // a GELU: `residual` carries the pre-activation).  Requires N % 64 == 0 and K % (64 NW) == 0 (an even number of 32-deep stages per wave).
+// Up to two problems of one shape per launch (blockIdx.y): the dual decoders of the serving path run the same layer with two weight sets
+// (vit_linear_sm_grouped; backbone_croco_multiview.py:147-188 at two context views).  The operands of a group are its own; the |max| words of
+// the activations are shared (the stacked input / output tensor is one tensor with one scale).
+struct SmGroup { const float *x; const uint4 *wpb; const float *bias; const float *residual; float *out; float *pre; const uint32_t *amax_w; };
+struct SmArgs { SmGroup g[2]; int M, N, K, act; const uint32_t *amax_x; uint32_t *amax_out; };
+
 template <int TM, int NW, int NPROD>
-__global__ void __launch_bounds__(NW * 64) k_linear_sm(const float *x, const uint4 *wpb, const float *__restrict__ bias,
-                                                       const float *__restrict__ residual, float *__restrict__ out, float *__restrict__ pre,
-                                                       int M, int N, int K, int act, const uint32_t *__restrict__ amax_x,
-                                                       const uint32_t *__restrict__ amax_w, uint32_t *__restrict__ amax_out)
+__global__ void __launch_bounds__(NW * 64) k_linear_sm(const SmArgs args)
 {
+    const SmGroup &grp = args.g[blockIdx.y];
+    const float *x = grp.x;
+    const uint4 *wpb = grp.wpb;
+    const float *__restrict__ bias = grp.bias, *__restrict__ residual = grp.residual;
+    float *__restrict__ out = grp.out, *__restrict__ pre = grp.pre;
+    const int M = args.M, N = args.N, K = args.K, act = args.act;
+    const uint32_t *__restrict__ amax_x = args.amax_x, *__restrict__ amax_w = grp.amax_w;
+    uint32_t *__restrict__ amax_out = args.amax_out;
     constexpr int BMT = 32 * TM, BNT = 64, NPC = NPROD == 6 ? 3 : 2;
     constexpr int NLA = BMT / 8;                       // activation loads per stage and lane (8 rows x 128 B per wave instruction)
     constexpr int ABUF = NPC * BMT * 4;                // uint4 slots of one LDS stage image
     constexpr int CS = BMT + LPAD;                     // column stride of a partial tile in LDS (floats)
     extern __shared__ uint4 lds[];                     // main loop: [wave][2][ABUF]; afterwards the partial tiles [wave][64][CS] floats
-    float sx = 1.f, ix = 1.f, iw = 1.f;
-    if (NPROD == 2) { sx = f16_scale_of(amax_word_read(amax_x)); ix = 1.f / sx; iw = 1.f / f16_scale_of(amax_word_read(amax_w)); }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     // workgroup id -> tile: consecutive ids are dealt round-robin to the 8 XCDs; XCD x takes one contiguous range of the tile sequence, which
@@ -124,6 +133,7 @@ __global__ void __launch_bounds__(NW * 64) k_linear_sm(const float *x, const uin
 #pragma unroll
                 for (int c = 0; c < NPC; ++c) rb_.v[s][j][c] = p[(2 * s * 3 + c) * 64 + 32 * j];
     };
+    float sx = 1.f, ix = 1.f, iw = 1.f;
     uint4 *ring = lds + (size_t)wave * 2 * ABUF;
     // split one stage of raw activations and store its pieces: lane (row, seg) holds k = 4 seg .. 4 seg + 3 -> half a k group of every piece
     auto write_a = [&](int buf, const RA &ra) {
@@ -183,6 +193,9 @@ __global__ void __launch_bounds__(NW * 64) k_linear_sm(const float *x, const uin
     RB rb_p, rb_q;
     load_a(ra_p, 0); load_b(rb_p, 0); load_a(ra_q, 1); load_b(rb_q, 1);
     fence();
+    // f16x3: the operand scales, read BEHIND the first operand loads (two more round trips to memory that would otherwise sit in front of them)
+    if (NPROD == 2) { sx = f16_scale_of(amax_word_read(amax_x)); ix = 1.f / sx; iw = 1.f / f16_scale_of(amax_word_read(amax_w)); }
+    fence();
     write_a(0, ra_p);
     fence();
     load_a(ra_p, 2);
@@ -205,6 +218,18 @@ __global__ void __launch_bounds__(NW * 64) k_linear_sm(const float *x, const uin
         load_a(ra_p, st + 4);
         fence();
     }
+    // the epilogue's global operands, requested before the two barriers of the reduction: thread = (column c = lane, row group = wave)
+    constexpr int RPT = BMT / NW;                        // rows per thread (a multiple of 4 for every instantiated shape)
+    static_assert(RPT % 4 == 0 && RPT * NW == BMT, "tile / workgroup shape");
+    const int c = lane, rg = wave, n = n0 + c;
+    const float bv = bias ? bias[n] : 0.f;
+    float resv[RPT];
+#pragma unroll
+    for (int e = 0; e < RPT; ++e) {
+        const int m = m0 + rg * RPT + e;
+        resv[e] = (residual && m < M) ? residual[(int64_t)m * N + n] : 0.f;
+    }
+    fence();
     mfma_result_fence();
     __syncthreads();                                   // every wave is done with its ring: the partial tiles take the memory
     float *part = reinterpret_cast<float *>(lds);
@@ -221,43 +246,36 @@ __global__ void __launch_bounds__(NW * 64) k_linear_sm(const float *x, const uin
                 *reinterpret_cast<float4 *>(mine + (32 * j + col) * CS + 32 * i + 8 * g + 4 * half) = v;
             }
     __syncthreads();
-    // epilogue: thread = (column c, row group rg): rows rg * RPT .. + RPT of column c, four rows per ds_read_b128; the 64 lanes of a wave store 64
-    // consecutive floats of one output row
-    constexpr int RPT = BMT / NW;                        // rows per thread (a multiple of 4 for every instantiated shape)
-    static_assert(RPT % 4 == 0 && RPT * NW == BMT, "tile / workgroup shape");
-    const int c = lane, rg = wave;
+    // epilogue: rows rg * RPT .. + RPT of column c per thread, four rows per ds_read_b128; the 64 lanes of a wave store 64 consecutive floats of
+    // one output row
     uint32_t omax = 0;
-    {
-        const int n = n0 + c;
-        const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-        for (int t = 0; t < RPT / 4; ++t) {
-            const int row = rg * RPT + 4 * t;
-            float4 sum = *reinterpret_cast<const float4 *>(part + c * CS + row);
+    for (int t = 0; t < RPT / 4; ++t) {
+        const int row = rg * RPT + 4 * t;
+        float4 sum = *reinterpret_cast<const float4 *>(part + c * CS + row);
 #pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const float4 v = *reinterpret_cast<const float4 *>(part + ((size_t)w * BNT + c) * CS + row);
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        for (int w = 1; w < NW; ++w) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + ((size_t)w * BNT + c) * CS + row);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + row + e;
+            if (m >= M) continue;
+            const int64_t o = (int64_t)m * N + n;
+            float v = vals[e];
+            if (NPROD == 2) v = v * ix * iw;
+            v += bv;
+            if (act == 2) {
+                v *= gelu_grad_exact(resv[4 * t + e]);
+            } else {
+                if (pre) pre[o] = v;
+                if (act == 1) v = gelu_exact(v);
+                if (residual) v += resv[4 * t + e];
             }
-            const float vals[4] = {sum.x, sum.y, sum.z, sum.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + row + e;
-                if (m >= M) continue;
-                const int64_t o = (int64_t)m * N + n;
-                float v = vals[e];
-                if (NPROD == 2) v = v * ix * iw;
-                v += bv;
-                if (act == 2) {
-                    v *= gelu_grad_exact(residual[o]);
-                } else {
-                    if (pre) pre[o] = v;
-                    if (act == 1) v = gelu_exact(v);
-                    if (residual) v += residual[o];
-                }
-                out[o] = v;
-                omax = max(omax, abs_bits(v));
-            }
+            out[o] = v;
+            omax = max(omax, abs_bits(v));
         }
     }
     if (amax_out) amax_word_fold(amax_out, omax);
@@ -313,18 +331,15 @@ int linear_sm_ok(int M, int N, int K)
     return nw != 0 && sm::fits(K, nw) && sm::built(tm, nw, x6_products());
 }
 
-// wpb: the BLOCK image of the weight (vit_split_weight_block)
-int linear_sm_fwd(const float *x, const void *wpb, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K, int act,
-                  const uint32_t *am_x, const uint32_t *am_w, uint32_t *am_out, hipStream_t stream)
+static int launch_sm(const sm::SmArgs &a, int groups, hipStream_t stream)
 {
-    const int np = x6_products();
-    if (np == 2 && !am_x) return VIT_EINVAL;
+    const int np = x6_products(), M = a.M, N = a.N, K = a.K;
+    if (np == 2 && !a.amax_x) return VIT_EINVAL;
     if (!linear_sm_ok(M, N, K)) return VIT_EINVAL;
     sm::Cfg c = sm::choose(M, N, K);
     if (sm::g_force_tm) c.tm = sm::g_force_tm;
     if (sm::g_force_nw) c.nw = sm::g_force_nw;
     const int tiles = ((M + 32 * c.tm - 1) / (32 * c.tm)) * (N / 64);
-    const uint4 *w4 = static_cast<const uint4 *>(wpb);
     (void)hipGetLastError();
 #define VIT_SM_LAUNCH(TM, NW, NP)                                                                                                                 \
     do {                                                                                                                                         \
@@ -337,7 +352,7 @@ int linear_sm_fwd(const float *x, const void *wpb, const float *bias, const floa
             }                                                                                                                                    \
             attr_set = true;                                                                                                                     \
         }                                                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(tiles), dim3(NW * 64), lds, stream, x, w4, bias, residual, out, pre, M, N, K, act, am_x, am_w, am_out);   \
+        hipLaunchKernelGGL(kern, dim3(tiles, groups), dim3(NW * 64), lds, stream, a);                                                           \
     } while (0)
 #define VIT_SM_NP(TM, NW)                                                                                                                         \
     do {                                                                                                                                         \
@@ -351,5 +366,40 @@ int linear_sm_fwd(const float *x, const void *wpb, const float *bias, const floa
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;
+}
+
+static const uint32_t *block_image_amax(const void *wpb, int N, int K)
+{
+    return reinterpret_cast<const uint32_t *>(static_cast<const char *>(wpb) + (size_t)((N + 63) / 64) * 64 * (size_t)K * 6);
+}
+
+// wpb: the BLOCK image of the weight (vit_split_weight_block)
+int linear_sm_fwd(const float *x, const void *wpb, const float *bias, const float *residual, float *out, float *pre, int M, int N, int K, int act,
+                  const uint32_t *am_x, const uint32_t *am_w, uint32_t *am_out, hipStream_t stream)
+{
+    sm::SmArgs a{};
+    a.g[0] = sm::SmGroup{x, static_cast<const uint4 *>(wpb), bias, residual, out, pre, am_w};
+    a.g[1] = a.g[0];
+    a.M = M; a.N = N; a.K = K; a.act = act; a.amax_x = am_x; a.amax_out = am_out;
+    return launch_sm(a, 1, stream);
+}
+
+// Two Linear layers of one shape in one launch (see sm::SmGroup): out_g = [residual_g +] act(x_g . w_g^T + bias_g), g = 0, 1.  The announced
+// activation |max| word (vit_x6_set_operand_amax) covers BOTH inputs, the output word (vit_x6_set_output_amax) both outputs.
+int linear_sm_grouped(const float *const *x, const void *const *wpb, const float *const *bias, const float *const *residual, float *const *out,
+                      int groups, int M, int N, int K, int act, hipStream_t stream)
+{
+    if (!x || !wpb || !out || groups < 1 || groups > 2 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return VIT_EINVAL;
+    const uint32_t *ax, *unused;
+    x6_take_amax(ax, unused);
+    sm::SmArgs a{};
+    for (int g = 0; g < groups; ++g) {
+        if (!x[g] || !wpb[g] || !out[g] || (act == 2 && !(residual && residual[g]))) return VIT_EINVAL;
+        a.g[g] = sm::SmGroup{x[g], static_cast<const uint4 *>(wpb[g]), bias ? bias[g] : nullptr, residual ? residual[g] : nullptr, out[g], nullptr,
+                             block_image_amax(wpb[g], N, K)};
+    }
+    if (groups == 1) a.g[1] = a.g[0];
+    a.M = M; a.N = N; a.K = K; a.act = act; a.amax_x = ax; a.amax_out = x6_take_output_amax();
+    return launch_sm(a, groups, stream);
 }
 }  // namespace vit

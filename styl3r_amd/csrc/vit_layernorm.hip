@@ -89,6 +89,49 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const float *__restrict__ x, con
     publish_amax(amax_out, omax, lane);
 }
 
+// Two LayerNorms of one shape in one launch (blockIdx.y = group): the dual decoders of the serving path (vit_layernorm_fwd_grouped).  Rows of
+// group g: x_g / y_g with (gamma_g, beta_g); the |max| word covers both outputs.  No mean / rstd (forward only).
+struct LnGroups { const float *x[2]; const float *gamma[2]; const float *beta[2]; float *y[2]; };
+template <int N4>
+__global__ void __launch_bounds__(256) k_ln_fwd_grouped(const LnGroups a, int M, float eps, uint32_t *__restrict__ amax_out)
+{
+    constexpr int C = N4 * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = blockIdx.y;
+    const float *__restrict__ x = a.x[g], *__restrict__ gamma = a.gamma[g], *__restrict__ beta = a.beta[g];
+    float *__restrict__ y = a.y[g];
+    uint32_t omax = 0;
+    float4 gm[N4], bt[N4];
+#pragma unroll
+    for (int j = 0; j < N4; ++j) {
+        gm[j] = reinterpret_cast<const float4 *>(gamma)[j * 64 + lane];
+        bt[j] = beta ? reinterpret_cast<const float4 *>(beta)[j * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {       // (the operations of k_ln_fwd)
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (int64_t)row * C);
+        float4 v[N4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < N4; ++j) { v[j] = xr[j * 64 + lane]; s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
+        const float mu = wave_sum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < N4; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
+        float4 *yr = reinterpret_cast<float4 *>(y + (int64_t)row * C);
+#pragma unroll
+        for (int j = 0; j < N4; ++j) {
+            const float4 o = make_float4(v[j].x * rs * gm[j].x + bt[j].x, v[j].y * rs * gm[j].y + bt[j].y,
+                                         v[j].z * rs * gm[j].z + bt[j].z, v[j].w * rs * gm[j].w + bt[j].w);
+            yr[j * 64 + lane] = o;
+            omax = max(omax, abs_bits4(o));
+        }
+    }
+    publish_amax(amax_out, omax, lane);
+}
+
 template <int N4>
 __global__ void __launch_bounds__(256) k_ln_bwd(const float *__restrict__ dy, const float *__restrict__ x,
                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -201,6 +244,27 @@ int layernorm_fwd(const float *x, const float *gamma, const float *beta, float *
 #define VIT_LN_F(N4) case N4: hipLaunchKernelGGL(k_ln_fwd<N4>, dim3(blocks), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, M, eps, am_out); break
     switch (C / 256) { VIT_LN_F(1); VIT_LN_F(2); VIT_LN_F(3); VIT_LN_F(4); VIT_LN_F(5); VIT_LN_F(6); VIT_LN_F(7); VIT_LN_F(8); }
 #undef VIT_LN_F
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
+    return VIT_OK;
+}
+
+int layernorm_fwd_grouped(const float *const *x, const float *const *gamma, const float *const *beta, float *const *y, int groups, int M, int C,
+                          float eps, hipStream_t stream)
+{
+    if (!x || !gamma || !y || groups < 1 || groups > 2 || M <= 0 || C <= 0 || (C % 256) != 0 || C / 256 > LN_MAX_N4) return VIT_EINVAL;
+    LnGroups a{};
+    for (int g = 0; g < 2; ++g) {
+        const int s = g < groups ? g : 0;
+        if (!x[s] || !gamma[s] || !y[s]) return VIT_EINVAL;
+        a.x[g] = x[s]; a.gamma[g] = gamma[s]; a.beta[g] = beta ? beta[s] : nullptr; a.y[g] = y[s];
+    }
+    const int blocks = (M + 3) / 4 < 2048 ? (M + 3) / 4 : 2048;
+    uint32_t *am_out = x6_take_output_amax();
+    (void)hipGetLastError();
+#define VIT_LN_G(N4) case N4: hipLaunchKernelGGL(k_ln_fwd_grouped<N4>, dim3(blocks, groups), dim3(256), 0, stream, a, M, eps, am_out); break
+    switch (C / 256) { VIT_LN_G(1); VIT_LN_G(2); VIT_LN_G(3); VIT_LN_G(4); VIT_LN_G(5); VIT_LN_G(6); VIT_LN_G(7); VIT_LN_G(8); }
+#undef VIT_LN_G
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_hip_error = e; return VIT_ELAUNCH; }
     return VIT_OK;

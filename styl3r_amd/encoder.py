@@ -240,6 +240,12 @@ class AsymmetricCroCoMulti(CrocoTrunk):
         # Serving (`branch_streams`, no-grad, device tensors): within a layer the two decoders only read each other's PREVIOUS outputs, and
         # at batch 1 neither fills the chip -- decoder 2 runs on its own stream, forked and joined once per layer (the critical path of a
         # C2 forward drops from 24 encoder + 24 decoder block-times to 24 + 12).
+        if self._decoder_pair_ok(st):
+            # Serving at two context views: the two decoders run the same shapes with two weight sets -- each layer is ONE sequence of 14
+            # two-problem launches (vit.decoder_blocks_pair) instead of 2 x 14 launches on two streams with a fork and a join per layer
+            for i in range(len(self.dec_blocks)):
+                self._decoder_layer_pair(st, i)
+            return self._decoder_end(st)
         side = None
         if self.branch_streams and st.f1.is_cuda and not torch.is_grad_enabled():
             main = torch.cuda.current_stream(st.f1.device)
@@ -297,13 +303,40 @@ class AsymmetricCroCoMulti(CrocoTrunk):
             return self.dec_blocks[i](st.f1, st.f2.view(st.b, (st.v - 1) * st.l, -1), st.p1, st.pm1)[0]
         return self.dec_blocks2[i](st.f2, self._mem_of_rest(st, st.f1, st.f2, st.f1.shape[-1]), st.p2, st.pm2)[0]
 
+    pair_launches = True     # serving option: layer i of both decoders as two-problem launches where the shapes allow it (A/B switch)
+
+    def _decoder_pair_ok(self, st) -> bool:
+        """two context views, batch rows equal, serving (no grad), every layer shape served by the small-M kernel"""
+        from .vit import decoder_blocks_pair_ok
+        if not self.pair_launches or torch.is_grad_enabled() or st.v != 2 or not st.f1.is_cuda or st.f1.shape != st.f2.shape:
+            return False
+        hit = getattr(st, "pair_ok", None)
+        if hit is None:
+            x = torch.stack((st.f1, st.f2))
+            hit = st.pair_ok = all(decoder_blocks_pair_ok(b1, b2, x) for b1, b2 in zip(self.dec_blocks, self.dec_blocks2))
+        return hit
+
+    def _decoder_layer_pair(self, st, i: int):
+        """layer i of BOTH decoders (serving, v == 2): st.x (2, b, l, c) holds the stacked features; st.f1 / st.f2 are views of it"""
+        from .vit import decoder_blocks_pair
+        if getattr(st, "x", None) is None:
+            st.x = torch.stack((st.f1, st.f2))
+            st.pos2 = torch.cat((st.p1, st.p2), dim=0).contiguous()
+            st.mpos2 = torch.cat((st.pm1, st.pm2), dim=0).contiguous()
+        st.x = decoder_blocks_pair(self.dec_blocks[i], self.dec_blocks2[i], st.x, st.pos2, st.mpos2)
+        self._decoder_advance(st, st.x[0], st.x[1])
+
     @staticmethod
     def _decoder_advance(st, n1: Tensor, n2: Tensor):
         st.f1, st.f2 = n1, n2
         st.outs.append((n1, n2))
 
     def _decoder_end(self, st):
-        st.outs[-1] = (self.dec_norm(st.f1), self.dec_norm(st.f2))
+        if getattr(st, "x", None) is not None:               # (pair path: the stacked features, one launch)
+            y = self.dec_norm(st.x)
+            st.outs[-1] = (y[0], y[1])
+        else:
+            st.outs[-1] = (self.dec_norm(st.f1), self.dec_norm(st.f2))
         return st.outs
 
     def _decoder(self, feat: Tensor, pos: Tensor):

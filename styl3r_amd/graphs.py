@@ -92,12 +92,19 @@ class StreamGraphedEncoder:
         self.g_se, encoded = capture(lambda: ts.encode_style(self.style))
         self.g_sd, sty_feat = capture(lambda: ts(self.style, enc_feat, enc_pos, encoded=encoded))
         self.g_dpre, st = capture(lambda: bb._decoder_begin(enc_feat, enc_pos))
-        self.g_d1, self.g_d2 = [], []
-        for i in range(len(bb.dec_blocks)):
-            g1, n1 = capture(lambda: bb._decoder_layer(st, i, 1))
-            g2, n2 = capture(lambda: bb._decoder_layer(st, i, 2))
-            bb._decoder_advance(st, n1, n2)
-            self.g_d1.append(g1); self.g_d2.append(g2)
+        self.g_d1, self.g_d2, self.g_dpair = [], [], None
+        with torch.no_grad():
+            pair = bb._decoder_pair_ok(st)
+        if pair:
+            # two context views: every layer of the two decoders is one sequence of two-problem launches -- ONE graph on the main stream, no
+            # fork / join per layer
+            self.g_dpair, _ = capture(lambda: [bb._decoder_layer_pair(st, i) for i in range(len(bb.dec_blocks))] and None)
+        else:
+            for i in range(len(bb.dec_blocks)):
+                g1, n1 = capture(lambda: bb._decoder_layer(st, i, 1))
+                g2, n2 = capture(lambda: bb._decoder_layer(st, i, 2))
+                bb._decoder_advance(st, n1, n2)
+                self.g_d1.append(g1); self.g_d2.append(g2)
         self.g_dpost, dec_feat = capture(lambda: [(a[:, :-1], r[:, :-1]) for a, r in bb._decoder_end(st)])
         jobs = enc._head_jobs(images, dec_feat, sty_feat)
         assert len(jobs) <= len(self.s_heads)
@@ -125,6 +132,8 @@ class StreamGraphedEncoder:
         with torch.cuda.stream(self.s_style):
             self.g_sd.replay()
         self.g_dpre.replay()
+        if self.g_dpair is not None:
+            self.g_dpair.replay()
         for g1, g2 in zip(self.g_d1, self.g_d2):
             self.s_dec2.wait_stream(main)                     # decoder 2, layer i reads decoder 1's layer i-1 (and its own)
             with torch.cuda.stream(self.s_dec2):

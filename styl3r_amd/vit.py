@@ -166,4 +166,48 @@ class DecoderBlock(nn.Module):
         return x, y
 
 
+def decoder_blocks_pair_ok(blk1: "DecoderBlock", blk2: "DecoderBlock", x: Tensor) -> bool:
+    """serving path: can layer i of BOTH decoders run as one sequence of two-problem launches (vit_ops.grouped_linear / grouped_layernorm)?"""
+    from .vit_ops import grouped_ok, grouped_shape_ok
+    if not (x.dim() == 4 and x.shape[0] == 2 and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32):
+        return False
+    C, M, hid = x.shape[-1], x.shape[1] * x.shape[2], blk1.mlp.fc1.out_features
+    norms = [blk1.norm1, blk1.norm2, blk1.norm3, blk2.norm1, blk2.norm2, blk2.norm3] + [n for n in (blk1.norm_y, blk2.norm_y) if not isinstance(n, nn.Identity)]
+    mlp_ok = all(isinstance(b.mlp.act, nn.GELU) and b.mlp.act.approximate == "none" for b in (blk1, blk2)) and blk2.mlp.fc1.out_features == hid
+    return (mlp_ok and isinstance(blk1.norm_y, nn.Identity) == isinstance(blk2.norm_y, nn.Identity)
+            and all(isinstance(n, LayerNorm) and n._hip_ok(x) for n in norms) and (blk1.attn.rope is None) == (blk2.attn.rope is None)
+            and blk1.attn.num_heads == blk2.attn.num_heads
+            and all(grouped_ok(x, n) for n in (C, 3 * C, hid)) and grouped_shape_ok(M, C, hid))
+
+
+@torch.no_grad()
+def decoder_blocks_pair(blk1: "DecoderBlock", blk2: "DecoderBlock", x: Tensor, pos: Tensor, mpos: Tensor) -> Tensor:
+    """Layer i of decoder 1 (group 0) and decoder 2 (group 1) in ONE sequence of 14 two-problem launches (serving, two context views: the two
+    decoders run the same shapes with two weight sets -- backbone_croco_multiview.py:147-188, blocks.py:203-242).  x: (2, b, l, c) = the two
+    decoders' features stacked; the memory of a decoder's cross-attention is the OTHER decoder's input features (x flipped).  pos: (2 b, l, 2),
+    mpos: (2 b, l, 2) positions of the queries / of the memory.  The arithmetic of DecoderBlock.forward, operation for operation."""
+    from .vit_ops import grouped_layernorm as gln, grouped_linear as glin
+    G, b, l, C = x.shape
+    a1, a2, c1, c2 = blk1.attn, blk2.attn, blk1.cross_attn, blk2.cross_attn
+    H = a1.num_heads
+    rope = a1.rope
+    h = gln(x, (blk1.norm1, blk2.norm1))
+    qkv = glin(h, (a1.qkv, a2.qkv)).view(2 * b, l, 3, H, C // H)
+    o = attention_qkv(qkv, a1.scale, pos if rope is not None else None, rope.freq if rope is not None else 100.0, rope.max_pos if rope is not None else 64)
+    x1 = glin(o.reshape(2, b, l, C), (a1.proj, a2.proj), residual=x)
+    y_ = gln(x, (blk1.norm_y, blk2.norm_y), flip=True)
+    h = gln(x1, (blk1.norm2, blk2.norm2))
+    q = glin(h, (c1.projq, c2.projq)).view(2 * b, l, H, C // H)
+    k = glin(y_, (c1.projk, c2.projk)).view(2 * b, l, H, C // H)
+    v = glin(y_, (c1.projv, c2.projv)).view(2 * b, l, H, C // H)
+    if c1.rope is not None:
+        o = memory_efficient_attention(q, k, v, scale=c1.scale, qpos=pos, kpos=mpos, rope_base=c1.rope.freq, max_pos=c1.rope.max_pos)
+    else:
+        o = memory_efficient_attention(q, k, v, scale=c1.scale)
+    x2 = glin(o.reshape(2, b, l, C), (c1.proj, c2.proj), residual=x1)
+    h = gln(x2, (blk1.norm3, blk2.norm3))
+    hid = glin(h, (blk1.mlp.fc1, blk2.mlp.fc1), gelu=True)
+    return glin(hid, (blk1.mlp.fc2, blk2.mlp.fc2), residual=x2)
+
+
 LayerNorm6 = partial(LayerNorm, eps=1e-6)   # croco.py:34 norm_layer=partial(nn.LayerNorm, eps=1e-6); vit_ops.LayerNorm: same parameters, HIP kernels

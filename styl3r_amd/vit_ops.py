@@ -40,7 +40,7 @@ _CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "lib" / os.environ.get("VIT_LIB_NAME", "libvit_hip.so")     # VIT_LIB_NAME: kernel-experiment builds (tools/ only); the product is libvit_hip.so
 _SOURCES = ["vit_rope.hip", "vit_attention.hip", "vit_attention_tail.hip", "vit_attention_bwd.hip", "vit_gemm.hip", "vit_attention_x6.hip", "vit_attention_bwd_x6.hip", "vit_gemm_x6.hip", "vit_gemm_sm.hip", "vit_gemm_x6r.hip", "vit_resample.hip", "vit_head_tail.hip", "vit_layernorm.hip", "vit_adapter.hip", "vit_optim.hip", "vit_api.hip"]
 EXPORTS = ("vit_rope2d", "vit_attention_fwd", "vit_attention_set_arith", "vit_attention_arith", "vit_attention_bwd", "vit_linear_fwd", "vit_split_weight_bytes",
-           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_conv_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_sm_set", "vit_linear_sm_ok", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
+           "vit_split_weight", "vit_x6_set_products", "vit_x6_products", "vit_x6_set_operand_amax", "vit_x6_set_output_amax", "vit_amax", "vit_split_weight_block_bytes", "vit_split_weight_block", "vit_split_weight_pair", "vit_split_conv_weight_pair", "vit_split_weights_many", "vit_linear_x6_fwd", "vit_linear_sm_set", "vit_linear_sm_ok", "vit_linear_sm_grouped", "vit_layernorm_fwd_grouped", "vit_linear_x6r_fwd", "vit_linear_x6c_fwd", "vit_linear_x6c_workspace_bytes", "vit_linear_x6c_choose_splits", "vit_linear_x6_wgrad", "vit_linear_x6_wgrad_acc", "vit_conv_x6_fwd", "vit_conv_x6_wgrad", "vit_upsample2x_fwd", "vit_upsample2x_bwd", "vit_relu_dropout_fwd", "vit_relu_dropout_bwd", "vit_layernorm_scratch_bytes", "vit_layernorm_fwd", "vit_layernorm_bwd",
            "vit_adapter_fwd", "vit_adapter_bwd", "vit_head_tail_fwd", "vit_head_tail_bwd", "vit_im2col7", "vit_im2col3_rows", "vit_upsample2x_add_relu_fwd", "vit_adamw_step", "vit_version", "vit_last_error")
 ERRORS = {-1: "VIT_EINVAL", -3: "VIT_ELAUNCH"}
 _lib = None
@@ -172,6 +172,11 @@ def load() -> C.CDLL:
     lib.vit_linear_sm_set.restype = C.c_int
     lib.vit_linear_sm_ok.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.vit_linear_sm_ok.restype = C.c_int
+    pp = C.POINTER(C.c_void_p)
+    lib.vit_linear_sm_grouped.argtypes = [pp, pp, pp, pp, pp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.vit_linear_sm_grouped.restype = C.c_int
+    lib.vit_layernorm_fwd_grouped.argtypes = [pp, pp, pp, pp, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+    lib.vit_layernorm_fwd_grouped.restype = C.c_int
     lib.vit_linear_x6_wgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.vit_linear_x6_wgrad.restype = C.c_int
     lib.vit_linear_x6_wgrad_acc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -1669,6 +1674,80 @@ def fused_linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, resid
             _publish(out, ow)
         return out.reshape(*shp[:-1], N)
     return _FusedLinear.apply(x, weight, bias, residual, 1 if gelu else 0, link, link_in, amax_out, amax_dx)
+
+
+# --------------------------------------------------------------------------- two problems per launch (serving path of the dual decoders)
+def _ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(p) if p else None for p in ptrs])
+
+
+def grouped_shape_ok(M: int, N: int, K: int) -> bool:
+    """serving path: can two (M, K) x (N, K)^T problems run in one vit_linear_sm_grouped launch?"""
+    return not torch.is_grad_enabled() and LINEAR_MODE != "f32" and _x6() and small_m_kernel(M, N, K)
+
+
+def grouped_ok(x: Tensor, N: int) -> bool:
+    """... for a (2, ..., K) stacked device input and N output features"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and x.shape[0] == 2 and x.is_contiguous()
+            and grouped_shape_ok(x.numel() // (2 * x.shape[-1]), N, x.shape[-1]))
+
+
+def grouped_linear(x: Tensor, layers, residual: Optional[Tensor] = None, gelu: bool = False, flip: bool = False) -> Tensor:
+    """Serving path, no autograd.  x: (2, ..., K) contiguous, the inputs of two layers of ONE shape stacked; group g runs layers[g] on x[g]
+    (flip: on x[1 - g] -- the memory of a decoder is the other decoder's features) and writes out[g]: (2, ..., N) = [residual +]
+    [gelu](x_g . W_g^T + b_g) in one launch of the small-M kernel (vit_linear_sm_grouped).  f16x3: one |max| word for the stacked input, one
+    published for the stacked output."""
+    assert grouped_ok(x, layers[0].out_features), "grouped_linear: check grouped_ok first"
+    K = x.shape[-1]
+    M = x.numel() // (2 * K)
+    N = layers[0].out_features
+    assert layers[1].out_features == N and layers[0].in_features == K == layers[1].in_features and x.is_contiguous()
+    out = torch.empty((2, *x.shape[1:-1], N), dtype=torch.float32, device=x.device)
+    res = None
+    if residual is not None:
+        res = residual if (residual.is_contiguous() and residual.dtype == torch.float32) else residual.contiguous().float()
+        assert res.numel() == out.numel()
+    wps = [split_weight_block(l.weight) for l in layers]
+    ow = None
+    if _f16():
+        _announce(_amax_of(x))
+        if PUBLISH_AMAX:
+            ow = _AMAX.word(x.device)
+            _check(load().vit_x6_set_output_amax(ow.data_ptr()), "vit_x6_set_output_amax")
+    xb, ob, eb = x.data_ptr(), out.data_ptr(), 4
+    xs = [xb + (1 if flip else 0) * M * K * eb, xb + (0 if flip else 1) * M * K * eb]
+    os_ = [ob, ob + M * N * eb]
+    rs = [res.data_ptr(), res.data_ptr() + M * N * eb] if res is not None else [None, None]
+    bs = [l.bias.data_ptr() if l.bias is not None else None for l in layers]
+    CALLS["linear_sm_grouped"] = CALLS.get("linear_sm_grouped", 0) + 1
+    _check(load().vit_linear_sm_grouped(_ptr_array(xs), _ptr_array([w.data_ptr() for w in wps]), _ptr_array(bs), _ptr_array(rs), _ptr_array(os_),
+                                        2, M, N, K, 1 if gelu else 0, _stream(x.device)), "vit_linear_sm_grouped")
+    if ow is not None:
+        _publish(out, ow)
+    return out
+
+
+def grouped_layernorm(x: Tensor, norms, flip: bool = False) -> Tensor:
+    """Serving path.  x: (2, ..., C) contiguous; out[g] = norms[g](x[g]) (flip: of x[1 - g]) in one launch (vit_layernorm_fwd_grouped: the
+    arithmetic of vit_layernorm_fwd).  norms[g] may be nn.Identity (both or none)."""
+    if isinstance(norms[0], nn.Identity):
+        assert isinstance(norms[1], nn.Identity)
+        return torch.stack((x[1], x[0])) if flip else x
+    Cn = x.shape[-1]
+    M = x.numel() // (2 * Cn)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda and all(n._hip_ok(x) for n in norms)
+    y = torch.empty_like(x)
+    pub = _want_output_amax(x.device)
+    xb, yb = x.data_ptr(), y.data_ptr()
+    xs = [xb + (1 if flip else 0) * M * Cn * 4, xb + (0 if flip else 1) * M * Cn * 4]
+    CALLS["layernorm_hip_fwd"] += 1
+    _check(load().vit_layernorm_fwd_grouped(_ptr_array(xs), _ptr_array([n.weight.data_ptr() for n in norms]),
+                                            _ptr_array([n.bias.data_ptr() if n.bias is not None else None for n in norms]),
+                                            _ptr_array([yb, yb + M * Cn * 4]), 2, M, Cn, float(norms[0].eps), _stream(x.device)),
+           "vit_layernorm_fwd_grouped")
+    if pub is not None:
+        _publish(y, pub)
+    return y
 
 
 # --------------------------------------------------------------------------- LayerNorm (E2, E5, E6: norm1..3, norm_y, enc/dec_norm)

@@ -148,3 +148,70 @@ def test_small_m_switch_off_restores_the_split_contraction_path(vo, monkeypatch)
     monkeypatch.setattr(vo, "SMALL_M_ROWS", 1024)
     assert vo.small_m_kernel(257, 768, 768) and not vo.small_m_kernel(257, 768, 80) and not vo.small_m_kernel(2000, 768, 768)
     assert _rel(a, b.double()) <= 4e-6
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_two_problem_launches_equal_the_single_launches_bit_for_bit(mode, vo, monkeypatch):
+    """vit_linear_sm_grouped / vit_layernorm_fwd_grouped: group g of a two-problem launch = the one-problem launch on the same operands (same
+    kernel, same tile walk; in f16x3 the shared |max| word of the stacked input is what the single launches are given too)"""
+    from torch import nn
+    monkeypatch.setattr(vo, "LINEAR_MODE", mode)
+    g = torch.Generator(DEV).manual_seed(11)
+    M, K, N = 257, 768, 2304
+    x = torch.randn(2, M, K, device=DEV, generator=g)
+    res = torch.randn(2, M, N, device=DEV, generator=g)
+    layers = [nn.Linear(K, N).to(DEV), nn.Linear(K, N).to(DEV)]
+    norms = [vo.LayerNorm(K, eps=1e-6).to(DEV), vo.LayerNorm(K, eps=1e-6).to(DEV)]
+    for n in norms:
+        n.weight.data.uniform_(0.5, 1.5, generator=g); n.bias.data.normal_(generator=g)
+    lib = vo.load()
+    with torch.no_grad():
+        assert vo.grouped_ok(x, N)
+        for flip in (False, True):
+            for gelu, use_res in ((False, True), (True, False)):
+                got = vo.grouped_linear(x, layers, residual=res if use_res else None, gelu=gelu, flip=flip)
+                for gi in range(2):
+                    xin = x[gi ^ int(flip)]
+                    # the single launch with the STACKED tensor's |max| word (f16x3: the scale is part of the arithmetic)
+                    out = torch.empty(M, N, device=DEV)
+                    wp = vo.split_weight_block(layers[gi].weight)
+                    if vo._f16():
+                        vo._announce(vo._amax_of(x))
+                    r = res[gi] if use_res else None
+                    vo._check(lib.vit_linear_x6r_fwd(xin.data_ptr(), wp.data_ptr(), layers[gi].bias.data_ptr(), r.data_ptr() if r is not None else None,
+                                                     out.data_ptr(), None, M, N, K, 1 if gelu else 0, 5, vo._stream(x.device)), "single")
+                    assert torch.equal(got[gi], out), (flip, gelu, gi)
+                if vo._f16():
+                    assert int(vo._known_amax(got).max()) == int(got.abs().max().view(torch.int32))
+            y = vo.grouped_layernorm(x, norms, flip=flip)
+            for gi in range(2):
+                ref = norms[gi](x[gi ^ int(flip)].contiguous())
+                assert float((y[gi] - ref).abs().max()) <= 4e-7 * float(ref.abs().max()), (flip, gi)       # (same operations; the compiler contracts the affine step of the two kernels differently: <= 1 ulp)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+def test_paired_decoder_layers_equal_the_two_decoder_path(mode, vo, monkeypatch):
+    """encoder backbone, serving, two context views: layer i of both decoders as 14 two-problem launches (vit.decoder_blocks_pair) against the
+    two DecoderBlock.forward calls -- same operations in the same order; in f16x3 the operand scales differ (one |max| word for the stacked
+    tensor instead of one per decoder), so the comparison is to fp32 round-off, not to the bit"""
+    from styl3r_amd import vit
+    monkeypatch.setattr(vo, "LINEAR_MODE", mode)
+    monkeypatch.setattr(vo, "ATTENTION_ARITH", "bf16x6" if mode == "bf16x6" else mode)
+    torch.manual_seed(3)
+    C, H, b, l = 256, 4, 1, 257
+    rope = vit.RopeCfg(100.0, 64)
+    blks = [vit.DecoderBlock(C, H, 4.0, qkv_bias=True, norm_layer=vit.LayerNorm6, rope=rope).to(DEV).eval() for _ in range(2)]
+    for blk in blks:
+        for n in (blk.norm1, blk.norm2, blk.norm3, blk.norm_y):
+            n.weight.data.uniform_(0.5, 1.5); n.bias.data.normal_(0, 0.3)
+    g = torch.Generator(DEV).manual_seed(4)
+    x = torch.randn(2, b, l, C, device=DEV, generator=g)
+    pos = torch.randint(0, 16, (2 * b, l, 2), device=DEV, generator=g)
+    with torch.no_grad():
+        assert vit.decoder_blocks_pair_ok(blks[0], blks[1], x)
+        got = vit.decoder_blocks_pair(blks[0], blks[1], x, pos, torch.cat((pos[b:], pos[:b])))
+        r0 = blks[0](x[0], x[1], pos[:b], pos[b:])[0]
+        r1 = blks[1](x[1], x[0], pos[b:], pos[:b])[0]
+    for gi, r in enumerate((r0, r1)):
+        e = _rel(got[gi], r.double())
+        assert e <= (1e-6 if mode == "bf16x6" else 3e-6), (gi, e)         # (bf16x6: the 1-ulp LayerNorm difference carried through the block)

@@ -11,7 +11,6 @@ from styl3r_amd import vit_ops as vo
 
 dev = torch.device("cuda:0")
 lib = vo.load()
-st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f16x3", "bf16x6"]
 ACT = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 shapes = dict(enc_qkv=(514, 3072, 1024), enc_proj=(514, 1024, 1024), enc_fc1=(514, 4096, 1024), enc_fc2=(514, 1024, 4096),
@@ -24,14 +23,19 @@ torch.cuda.synchronize()
 
 
 def timeit(fns, iters=240, warm=24):
+    """GPU time per launch: the launches are captured into one hipGraph and replayed (no host time between them)"""
     n = len(fns)
     for i in range(warm): fns[i % n]()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(iters): fns[i % n]()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     e0.record()
-    for i in range(iters): fns[i % n]()
+    for _ in range(3): g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    return e0.elapsed_time(e1) / (3 * iters) * 1e3
 
 
 for mode in modes:
@@ -52,8 +56,8 @@ for mode in modes:
         def mk(wp, small):
             def f():
                 if ax is not None: vo._announce(ax)
-                if small: rc = lib.vit_linear_x6r_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, M, N, K, ACT, 5, st)
-                else: rc = lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, M, N, K, ACT, st)
+                if small: rc = lib.vit_linear_x6r_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, M, N, K, ACT, 5, vo._stream(dev))
+                else: rc = lib.vit_linear_x6_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, M, N, K, ACT, vo._stream(dev))
                 assert rc == 0, rc
             return f
         fns = [mk(wp, False) for wp in wps]; fsm = [mk(wp, True) for wp in wbs]
