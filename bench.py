@@ -744,8 +744,8 @@ def infer_leg(args, dev):
                         t_enc += ev[0].elapsed_time(ev[1]); t_ras += ev[1].elapsed_time(ev[2])
         finally:
             vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
-        rec = {"encoder_ms": round(t_enc / steps, 3), "rasterizer_ms": round(t_ras / steps, 3), "total_ms": round((t_enc + t_ras) / steps, 3),
-               "views_per_s": round(v_tgt * 1e3 * steps / (t_enc + t_ras), 2), "gaussians": int(gs.means.shape[1])}
+        rec = {"encoder_ms": round(t_enc / steps, 3), "rasterizer_ms": round(t_ras / steps, 3), "eager_total_ms": round((t_enc + t_ras) / steps, 3),
+               "gaussians": int(gs.means.shape[1])}
         # the same forward as one hipGraph per stream segment (styl3r_amd.graphs.StreamGraphedEncoder): no host launch cost, the GPU-side limit
         try:
             keep = vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH
@@ -769,13 +769,34 @@ def infer_leg(args, dev):
         finally:
             vit_ops.LINEAR_MODE, vit_ops.ATTENTION_ARITH = keep
             vit_ops._x6()
+        # total_ms: the serving form (stream graphs) when it captured, else the eager launch path
+        sg = rec["stream_graphs_total_ms"]
+        rec["total_ms"] = sg if isinstance(sg, float) else rec["eager_total_ms"]
+        rec["serving_form"] = "stream graphs" if isinstance(sg, float) else "eager"
+        rec["views_per_s"] = round(v_tgt * 1e3 / rec["total_ms"], 2)
         return rec
+
+    def ab_round5_launch_forms(mode):
+        """same box, same process: the stream-graph forward with the round-6 serving kernels switched off (the small-M Linear kernel and the
+        two-problem launches of the dual decoders) -- the 128-row split-contraction kernels and one stream per decoder, as in round 5"""
+        keep = vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches
+        vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches = 0, False
+        try:
+            return timed(mode)["stream_graphs_total_ms"]
+        finally:
+            vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches = keep
+            vit_ops._x6()
 
     # bf16x6 = the arithmetic of the 1e-4 RGB statement against fp32; bf16x3 = the TF32-class mode the train leg's headline uses (tests/test_e2e_parity.py bounds both)
     out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("bf16x6"), "steps": steps,
            "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "f16x3": timed("f16x3"),
-           "encoder_launch": "eager, style branch + decoder 2 + heads on side streams (total_ms); stream_graphs_total_ms: one hipGraph per stream segment",
+           "encoder_launch": "total_ms / stream_graphs_total_ms: one hipGraph per stream segment (style branch and the five heads on side streams, the dual decoders "
+                             "as two-problem launches on the main stream); eager_total_ms: the same forward launched kernel by kernel (host-bound: ~1 400 launches)",
            "dtype": "f32", "data": "synthetic, random-init weights"}
+    try:
+        out["stream_graphs_ms_with_the_round5_launch_forms"] = {m: ab_round5_launch_forms(m) for m in ("f16x3", "bf16x6")}
+    except Exception as e:
+        out["stream_graphs_ms_with_the_round5_launch_forms"] = f"{type(e).__name__}: {e}"[:200]
     # `test.align_pose` (config/main.yaml:57-60, model_wrapper_style.py:391-447): before the evaluation render the reference optimises the 3 target
     # poses for pose_align_steps = 100 Adam steps, each one a rasterizer forward + backward with pose gradients (theta / rho) on the 3 views.
     # Timed on a scene the heads were re-centred for (a random-init encoder renders nothing), from poses perturbed by ~1 degree / 1 % of the baseline.

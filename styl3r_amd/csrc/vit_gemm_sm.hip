@@ -325,7 +325,7 @@ int linear_sm_set(int max_rows, int tm, int nw)
 // 1 when (M, N, K) runs on the small-M kernel under the current vit_linear_sm_set state
 int linear_sm_ok(int M, int N, int K)
 {
-    if (M < 1 || M > sm::g_max_rows || (N % 64) != 0 || K < 128) return 0;
+    if (M < 1 || M > sm::g_max_rows || (N % 64) != 0 || K < 128 || (int64_t)M * K >= (1ll << 31) || (int64_t)N * K >= (1ll << 31)) return 0;   // (32-bit element offsets)
     const sm::Cfg c = sm::choose(M, N, K);
     const int nw = sm::g_force_nw ? sm::g_force_nw : c.nw, tm = sm::g_force_tm ? sm::g_force_tm : c.tm;
     return nw != 0 && sm::fits(K, nw) && sm::built(tm, nw, x6_products());

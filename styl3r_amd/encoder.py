@@ -33,7 +33,7 @@ from torch import Tensor, nn
 from .decoder import Gaussians
 from .vit import Block, DecoderBlock, LayerNorm6, RopeCfg, _linear
 from . import vit_ops
-from .vit_ops import Conv2dX6, fused_linear, head_tail, input_merger_upsample_add, relu_dropout, upsample2x
+from .vit_ops import Conv2dX6, derived_weight as _derived, fused_linear, head_tail, input_merger_upsample_add, relu_dropout, upsample2x
 
 inf = float("inf")
 
@@ -131,7 +131,7 @@ class PatchEmbedDust3R(nn.Module):
             # kernel == stride: the convolution is a Linear over the (B h w, C ph pw) patch rows (row order = the weight's (c, i, j)
             # order), on the bf16x6 kernels forward and backward; no library convolution, no NCHW -> token transpose behind it
             rows = x.reshape(B, C, h, ph, w, pw).permute(0, 2, 4, 1, 3, 5).reshape(B * h * w, C * ph * pw)
-            tok = _tok_linear(rows, self.proj.weight.reshape(self.proj.out_channels, C * ph * pw), self.proj.bias)
+            tok = _tok_linear(rows, _derived(self.proj.weight, "patch", lambda w_: w_.reshape(self.proj.out_channels, C * ph * pw)), self.proj.bias)
             return tok.reshape(B, h * w, self.proj.out_channels), pos
         x = _PackGrad.apply(self.proj(x))
         return x.flatten(2).transpose(1, 2), pos
@@ -514,7 +514,7 @@ def _intrinsics_token(layer: nn.Linear, K: Tensor) -> Tensor:
     x = K.flatten(2)
     if x.is_cuda and x.dtype == torch.float32:
         pad = (0, 16 - x.shape[-1])
-        return fused_linear(torch.nn.functional.pad(x, pad).reshape(-1, 16), torch.nn.functional.pad(layer.weight, pad), layer.bias).reshape(*x.shape[:-1], -1)
+        return fused_linear(torch.nn.functional.pad(x, pad).reshape(-1, 16), _derived(layer.weight, "pad16", lambda w_: torch.nn.functional.pad(w_, pad)), layer.bias).reshape(*x.shape[:-1], -1)
     return layer(x)
 
 
@@ -583,14 +583,14 @@ class DPTAdapter(nn.Module):
         seq = self.act_postprocess[i]
         B, N, C = tok.shape
         c1 = seq[0]
-        y = _tok_linear(tok.reshape(B * N, C), c1.weight.reshape(c1.out_channels, C), c1.bias)                    # (B N, C1)
+        y = _tok_linear(tok.reshape(B * N, C), _derived(c1.weight, "1x1", lambda w_: w_.reshape(c1.out_channels, C)), c1.bias)                    # (B N, C1)
         C1 = c1.out_channels
         if i in (0, 1):
             ct = seq[1]
             s_ = ct.kernel_size[0]
             Co = ct.out_channels
-            w = ct.weight.permute(1, 2, 3, 0).reshape(Co * s_ * s_, C1)                  # [(co, di, dj), ci] = W[ci, co, di, dj]
-            bias = ct.bias.repeat_interleave(s_ * s_) if ct.bias is not None else None
+            w = _derived(ct.weight, "ct", lambda w_: w_.permute(1, 2, 3, 0).reshape(Co * s_ * s_, C1))       # [(co, di, dj), ci] = W[ci, co, di, dj]
+            bias = _derived(ct.bias, "ct_bias", lambda b_: b_.repeat_interleave(s_ * s_))
             z = _tok_linear(y, w, bias)                                                   # (B N, Co s s)
             return z.reshape(B, nh, nw, Co, s_, s_).permute(0, 3, 1, 4, 2, 5).reshape(B, Co, nh * s_, nw * s_)
         if i == 2:
@@ -602,7 +602,7 @@ class DPTAdapter(nn.Module):
         idx = _stride2_tap_index(nh, nw, y.device)                                        # (oh * ow * 9,)
         grid = torch.cat([y.reshape(B, nh * nw, C1), y.new_zeros(B, 1, C1)], dim=1)
         cols = grid[:, idx].reshape(B * oh * ow, 9 * C1)
-        w = cv.weight.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * C1)               # [co, (tap, ci)]
+        w = _derived(cv.weight, "s2", lambda w_: w_.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * C1))               # [co, (tap, ci)]
         z = _tok_linear(cols, w, cv.bias)
         return z.reshape(B, oh, ow, cv.out_channels).permute(0, 3, 1, 2).contiguous()
 

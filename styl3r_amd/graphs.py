@@ -142,7 +142,11 @@ class StreamGraphedEncoder:
             main.wait_stream(self.s_dec2)                     # decoder 1, layer i+1 reads decoder 2's layer i
         self.g_dpost.replay()
         main.wait_stream(self.s_style)
-        for s, g in zip(self.s_heads, self.g_heads):
+        # (the five heads share the chip: the heavy ones -- the Gaussian-parameter heads with their input merger, jobs 1 and 4 -- go first, so the
+        #  last stream to finish is not the one that started last with the most work)
+        order = [i for i in (1, 4, 2, 0, 3) if i < len(self.g_heads)] + [i for i in range(len(self.g_heads)) if i not in (1, 4, 2, 0, 3)]
+        for i in order:
+            s, g = self.s_heads[i], self.g_heads[i]
             s.wait_stream(main)
             with torch.cuda.stream(s):
                 g.replay()

@@ -1288,6 +1288,33 @@ class _UpsampleAddRelu(torch.autograd.Function):
         return dx, dc
 
 
+_DERIVED: dict = {}      # (id(parameter), tag) -> (weakref(parameter), version, data_ptr, derived tensor)
+
+
+def derived_weight(param: Optional[Tensor], tag: str, fn):
+    """Serving path: a tensor derived from a parameter (a reshaped / permuted convolution weight, a repeated bias) is built ONCE per parameter
+    version and keeps its identity, so the split images vit_ops caches per weight tensor stay valid -- without this every forward re-made the
+    tensor and with it its copies, its |max| pass and its split launch (5 launches per reassemble layer and head, ~150 per C2 forward).
+    With autograd on, the derivation must stay in the graph: computed in place."""
+    if param is None:
+        return None
+    if torch.is_grad_enabled() and param.requires_grad:
+        return fn(param)
+    key = (id(param), tag)
+    hit = _DERIVED.get(key)
+    if hit is not None and hit[0]() is param and hit[1] == param._version and hit[2] == param.data_ptr():
+        return hit[3]
+
+    def drop(ref, key=key):
+        h = _DERIVED.get(key)
+        if h is not None and h[0] is ref:
+            del _DERIVED[key]
+    with torch.no_grad():
+        d = fn(param.detach())
+    _DERIVED[key] = (weakref.ref(param, drop), param._version, param.data_ptr(), d)
+    return d
+
+
 def input_merger_upsample_add(p1: Tensor, imgs: Tensor, conv7: nn.Conv2d) -> Optional[Tensor]:
     """`feat_up(path_1) + ReLU(Conv2d(3, 256, 7, 1, 3)(imgs))` of the 'gs' head (dpt_gs_head.py:113-118,146-148) without the library:
     the 7x7 patches as 160 planes (vit_im2col7), the convolution as a 1x1 convolution over them on the bf16x6 kernels (forward and
@@ -1303,7 +1330,7 @@ def input_merger_upsample_add(p1: Tensor, imgs: Tensor, conv7: nn.Conv2d) -> Opt
     cols = torch.empty((B, 160, H, W), dtype=torch.float32, device=imgs.device)
     _check(load().vit_im2col7(imgs.data_ptr(), cols.data_ptr(), B, H, W, _stream(imgs.device)), "vit_im2col7")
     Co = conv7.out_channels
-    w160 = torch.nn.functional.pad(conv7.weight.reshape(Co, 147), (0, 13)).reshape(Co, 160, 1, 1)
+    w160 = derived_weight(conv7.weight, "w160", lambda w_: torch.nn.functional.pad(w_.reshape(Co, 147), (0, 13)).reshape(Co, 160, 1, 1))
     CALLS["input_merger_x6"] += 1
     c = _ConvX6.apply(cols, w160, conv7.bias)
     return _UpsampleAddRelu.apply(p1, c)
@@ -1398,8 +1425,8 @@ RING_DISPATCH = os.environ.get("VIT_RING_DISPATCH", "1") == "1"
 
 
 def _ring_cfg(M: int, N: int, K: int) -> int:
-    if M <= SMALL_M_ROWS and small_m_kernel(M, N, K):
-        return 5                    # csrc/vit_gemm_sm.hip (batch-1 serving row counts; the tiny trunks of the tests)
+    if (M <= SMALL_M_ROWS and small_m_kernel(M, N, K)) or (M > SMALL_M_ROWS and narrow_n_kernel(M, N, K)):
+        return 5                    # csrc/vit_gemm_sm.hip (batch-1 serving row counts, the tiny trunks of the tests; narrow outputs at any row count)
     if not RING_DISPATCH or M < 2048:
         return 0
     return (_RING_SHAPES if M >= 4096 else _RING_SHAPES_MID).get(LINEAR_MODE, {}).get((N, K), 0)
@@ -1599,21 +1626,30 @@ class _FusedLinear(torch.autograd.Function):
         return dx, dw, db, g_res, None, None, None, None, None
 
 
-SMALL_M_ROWS = int(os.environ.get("VIT_SMALL_M_ROWS", "1024"))      # vit_linear_sm_set(max_rows): 0 = the 128-row-tile kernel at every M (A/B switch)
+SMALL_M_ROWS = int(os.environ.get("VIT_SMALL_M_ROWS", "1024"))      # launches of up to this many rows take csrc/vit_gemm_sm.hip; 0 = the kernel is off at every M (A/B switch)
+NARROW_N = int(os.environ.get("VIT_NARROW_N", "768"))               # ... and launches of ANY row count whose output is at most this wide (0 = off): see _ring_cfg
 _SMALL_M_SET: dict = {}                                              # host thread -> the max_rows this thread last told the library
 
 
 def small_m_kernel(M: int, N: int, K: int) -> bool:
-    """does vit_linear_x6_fwd take the small-M kernel for this shape?  (the rule of csrc/vit_gemm_sm.hip linear_sm_ok; also keeps the library's
-    per-thread max_rows in step with SMALL_M_ROWS, which tests and benchmarks flip at run time)"""
+    """does this shape run on the small-M kernel (vit_linear_x6r_fwd cfg 5) at batch-1 row counts?  (also keeps the library's per-thread switch in
+    step with SMALL_M_ROWS, which tests and benchmarks flip at run time)"""
     _sync_small_m()
     return SMALL_M_ROWS > 0 and M <= SMALL_M_ROWS and bool(load().vit_linear_sm_ok(M, N, K))
+
+
+def narrow_n_kernel(M: int, N: int, K: int) -> bool:
+    """the same kernel at the train step's row counts, for NARROW outputs (the decoders' 768-wide proj / projq / projk / projv / fc2 and the
+    input-gradient GEMMs of their qkv / fc1): 128-wide tiles leave the chip under-filled there and the barrier-free kernel is 30 % faster
+    (M = 2 570, f16x3: 768 x 768 37 -> 25 us, 768 x 3072 95 -> 67 us; profiles/r06_small_linear_lab_big.jsonl); wider layers stay on the ring kernels"""
+    _sync_small_m()
+    return SMALL_M_ROWS > 0 and 0 < N <= NARROW_N and M > SMALL_M_ROWS and bool(load().vit_linear_sm_ok(M, N, K))
 
 
 def _sync_small_m() -> None:
     tid = threading.get_ident()
     if _SMALL_M_SET.get(tid) != SMALL_M_ROWS:
-        _check(load().vit_linear_sm_set(SMALL_M_ROWS, 0, 0), "vit_linear_sm_set")
+        _check(load().vit_linear_sm_set((1 << 24) if SMALL_M_ROWS > 0 else 0, 0, 0), "vit_linear_sm_set")       # (the row-count policy lives here)
         _SMALL_M_SET[tid] = SMALL_M_ROWS
 
 

@@ -215,3 +215,32 @@ def test_paired_decoder_layers_equal_the_two_decoder_path(mode, vo, monkeypatch)
     for gi, r in enumerate((r0, r1)):
         e = _rel(got[gi], r.double())
         assert e <= (1e-6 if mode == "bf16x6" else 3e-6), (gi, e)         # (bf16x6: the 1-ulp LayerNorm difference carried through the block)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("M,N,K,gelu_behind", [(2570, 768, 768, False), (2570, 768, 3072, True), (5140, 768, 1024, False), (2570, 3072, 768, False)])
+def test_narrow_outputs_take_the_barrier_free_kernel_at_train_step_row_counts(M, N, K, gelu_behind, mode, vo, monkeypatch):
+    """vit_ops.narrow_n_kernel: forward (N <= 768) and input-gradient (its N is the layer's K) launches of the decoders' 768-wide layers at
+    M = 2 570 / 5 140 run csrc/vit_gemm_sm.hip; forward, dX (incl. the GELU' epilogue of an fc2 behind a GELU), dW, db against float64"""
+    monkeypatch.setattr(vo, "LINEAR_MODE", mode)
+    g = torch.Generator(DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV, generator=g, requires_grad=True)
+    gy = torch.randn(M, N, device=DEV, generator=g)
+    pre = torch.randn(M, K, device=DEV, generator=g)
+    link_in = None
+    if gelu_behind:
+        link_in = vo.GeluLink(); link_in.pre = pre
+    before = vo.CALLS["linear_x6r"]
+    y = vo.fused_linear(x, w, b, link_in=link_in)
+    (y * gy).sum().backward()
+    took = vo.CALLS["linear_x6r"] - before
+    assert took >= (1 if N <= 768 else 0) + (1 if K <= 768 else 0), took        # (forward: N narrow; dX: its output width is K; the count includes the ring kernels of the wide layers)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = torch.nn.functional.linear(xd, wd, bd)
+    (ref * gy.double()).sum().backward()
+    dx_ref = xd.grad * _gelu_grad64(pre.double()) if gelu_behind else xd.grad
+    bar = BAR[mode]
+    assert _rel(y.detach(), ref.detach()) <= bar
+    assert _rel(x.grad, dx_ref) <= 3 * bar and _rel(w.grad, wd.grad) <= 3 * bar and _rel(b.grad, bd.grad) <= 3 * bar

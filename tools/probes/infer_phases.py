@@ -49,7 +49,9 @@ def run(self, marks):
         main.wait_stream(self.s_dec2)
     self.g_dpost.replay(); mark("decoders_end")
     main.wait_stream(self.s_style); mark("join_style")
-    for i, (s, gg) in enumerate(zip(self.s_heads, self.g_heads)):
+    order = [i for i in (1, 4, 2, 0, 3) if i < len(self.g_heads)]
+    for i in order:
+        s, gg = self.s_heads[i], self.g_heads[i]
         s.wait_stream(main)
         with torch.cuda.stream(s):
             gg.replay(); mark(f"head{i}_end", s)

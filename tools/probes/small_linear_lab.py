@@ -17,6 +17,12 @@ shapes = dict(enc_qkv=(514, 3072, 1024), enc_proj=(514, 1024, 1024), enc_fc1=(51
               sty_qkv=(257, 3072, 1024), sty_fc1=(257, 4096, 1024), sty_fc2=(257, 1024, 4096), sty_proj=(257, 1024, 1024),
               dec_qkv=(257, 2304, 768), dec_proj=(257, 768, 768), dec_fc1=(257, 3072, 768), dec_fc2=(257, 768, 3072), dec_kv514=(514, 768, 768),
               enc2dec=(514, 768, 1024))
+import os
+if os.environ.get("BIG"):      # the train-step row counts: is the barrier-free kernel worth taking above 1 024 rows?  (ring kernels cfg 1 / 3 timed beside it)
+    Mb = int(os.environ["BIG"])
+    shapes = dict(enc_qkv=(Mb, 3072, 1024), enc_proj=(Mb, 1024, 1024), enc_fc1=(Mb, 4096, 1024), enc_fc2=(Mb, 1024, 4096),
+                  dec_qkv=(Mb // 2, 2304, 768), dec_proj=(Mb // 2, 768, 768), dec_fc1=(Mb // 2, 3072, 768), dec_fc2=(Mb // 2, 768, 3072))
+MAXR = 1 << 20 if os.environ.get("BIG") else 1024
 _w = torch.randn(4096, 4096, device=dev)
 for _ in range(200): _w @ _w
 torch.cuda.synchronize()
@@ -65,11 +71,20 @@ for mode in modes:
         fns[0](); row["err_old"] = float((out.double() - ref).abs().max() / ref.abs().max())
         row["old_us"] = round(timeit(fns), 2)
         for tm, nw in ((1, 4), (1, 8), (2, 4), (2, 8), (0, 0)):
-            assert lib.vit_linear_sm_set(1024, tm, nw) == 0
+            assert lib.vit_linear_sm_set(MAXR, tm, nw) == 0
             if not lib.vit_linear_sm_ok(M, N, K): continue
             fsm[0](); e = float((out.double() - ref).abs().max() / ref.abs().max())
             row[f"sm_{tm}x{nw}_us" if tm else "sm_rule_us"] = round(timeit(fsm), 2)
             row[f"err_{tm}x{nw}"] = e
+        if os.environ.get("BIG"):
+            for cfg in (1, 3):
+                def mkr(wp, cfg=cfg):
+                    def f():
+                        if ax is not None: vo._announce(ax)
+                        rc = lib.vit_linear_x6r_fwd(x.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), out.data_ptr(), None, M, N, K, ACT, cfg, vo._stream(dev))
+                        assert rc == 0, rc
+                    return f
+                row[f"ring{cfg}_us"] = round(timeit([mkr(wp) for wp in wbs], iters=60, warm=6), 2)
         prod = {"bf16x6": 6, "bf16x3": 3, "f16x3": 3}[mode]
         best = min(v for k, v in row.items() if k.startswith("sm_") and k.endswith("_us"))
         row["best_TF_mfma"] = round(2 * M * N * K * prod / best / 1e6, 1)
