@@ -787,9 +787,10 @@ def infer_leg(args, dev):
             vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches = keep
             vit_ops._x6()
 
-    # bf16x6 = the arithmetic of the 1e-4 RGB statement against fp32; bf16x3 = the TF32-class mode the train leg's headline uses (tests/test_e2e_parity.py bounds both)
-    out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("bf16x6"), "steps": steps,
-           "linear_arithmetic": "bf16x6", "bf16x3": timed("bf16x3"), "f16x3": timed("f16x3"),
+    # top level: f16x3, the arithmetic of the train leg's headline (fp32-class accuracy: tests/test_gpu_vit.py measures it at or below bf16x6's error
+    # against float64) ; bf16x6 = six products, the mode rounds 1 - 5 quoted here; bf16x3 = the TF32-class mode (tests/test_e2e_parity.py bounds all three)
+    out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("f16x3"), "steps": steps,
+           "linear_arithmetic": "f16x3", "bf16x6": timed("bf16x6"), "bf16x3": timed("bf16x3"),
            "encoder_launch": "total_ms / stream_graphs_total_ms: one hipGraph per stream segment (style branch and the five heads on side streams, the dual decoders "
                              "as two-problem launches on the main stream); eager_total_ms: the same forward launched kernel by kernel (host-bound: ~1 400 launches)",
            "dtype": "f32", "data": "synthetic, random-init weights"}

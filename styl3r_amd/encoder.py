@@ -425,17 +425,27 @@ class TokenStylizer(CrocoTrunk):
         return _linear(self.decoder_embed, self.enc_norm(x)), spos
 
     def forward(self, style: dict, content_feat: Tensor, content_pos: Tensor, encoded=None):
+        st = self.decode_begin(style, content_feat, content_pos, encoded)
+        self.decode_layers(st, 0, len(self.dec_blocks))
+        return self.decode_end(st)
+
+    # the pieces of `forward`, also driven one by one by graphs.StreamGraphedEncoder (the appearance head hooks into layers 0, L/2, 3L/4, L)
+    def decode_begin(self, style: dict, content_feat: Tensor, content_pos: Tensor, encoded=None):
+        from types import SimpleNamespace
         style_feat, spos = encoded if encoded is not None else self.encode_style(style)
         b, v, l, c = content_feat.shape
-        outs = [content_feat]
         cf = _linear(self.decoder_embed, content_feat.reshape(b, v * l, c))
-        cpos = content_pos.reshape(b, v * l, 2).contiguous()
-        spos = spos.contiguous()
-        for blk in self.dec_blocks:
-            cf, _ = blk(cf, style_feat, cpos, spos)
-            outs.append(cf.view(b, v, l, -1))
-        outs[-1] = self.dec_norm(cf).view(b, v, l, -1)
-        return [t[:, :, :-1] for t in outs]                            # drop the last (intrinsics) token per view (:151-152)
+        return SimpleNamespace(b=b, v=v, l=l, style_feat=style_feat, spos=spos.contiguous(), cf=cf,
+                               cpos=content_pos.reshape(b, v * l, 2).contiguous(), outs=[content_feat])
+
+    def decode_layers(self, st, lo: int, hi: int):
+        for blk in self.dec_blocks[lo:hi]:
+            st.cf, _ = blk(st.cf, st.style_feat, st.cpos, st.spos)
+            st.outs.append(st.cf.view(st.b, st.v, st.l, -1))
+
+    def decode_end(self, st):
+        st.outs[-1] = self.dec_norm(st.cf).view(st.b, st.v, st.l, -1)
+        return [t[:, :, :-1] for t in st.outs]                         # drop the last (intrinsics) token per view (:151-152)
 
 
 class StructureBuilder(nn.Module):
@@ -606,11 +616,17 @@ class DPTAdapter(nn.Module):
         z = _tok_linear(cols, w, cv.bias)
         return z.reshape(B, oh, ow, cv.out_channels).permute(0, 3, 1, 2).contiguous()
 
-    def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None) -> Tensor:
+    def early(self, i: int, tok: Tensor, image_size) -> Tensor:
+        """branch i of the head's front end -- reassemble + layer_rn[i] -- needs only the tokens of hook i: a serving loop can run it as
+        soon as that trunk layer is done (graphs.StreamGraphedEncoder), long before the last decoder layer the rest of the head waits for"""
         H, W = image_size
-        nh, nw = H // 16, W // 16
-        layers = [self._reassemble(i, tokens[h], nh, nw) for i, h in enumerate(self.hooks)]
-        layers = [self.scratch.layer_rn[i](t) for i, t in enumerate(layers)]
+        return self.scratch.layer_rn[i](self._reassemble(i, tok, H // 16, W // 16))
+
+    def forward(self, tokens: list, image_size, imgs: Optional[Tensor] = None, layers: Optional[list] = None) -> Tensor:
+        """layers: per hook, the result of `early(i, ...)` computed ahead (None entries are computed here)"""
+        H, W = image_size
+        layers = [layers[i] if (layers is not None and layers[i] is not None) else self.early(i, tokens[h], image_size)
+                  for i, h in enumerate(self.hooks)]
         # (.contiguous(): MIOpen sends non-packed views -- this crop, the per-view image slice -- to naive_conv_* kernels)
         p4 = self.scratch.refinenet4(layers[3])[:, :, :layers[2].shape[2], :layers[2].shape[3]].contiguous()
         p3 = self.scratch.refinenet3(p4, layers[2])
@@ -652,10 +668,10 @@ class PixelwiseTaskWithDPT(nn.Module):
         self.kind = kind
         self.dpt = DPTAdapter(num_channels, [ed, dd, dd, dd], [0, l2 * 2 // 4, l2 * 3 // 4, l2], "pts3d" if kind == "pts3d_raw" else kind)
 
-    def forward(self, tokens, image_size, imgs=None, raw: bool = False):
+    def forward(self, tokens, image_size, imgs=None, raw: bool = False, layers=None):
         """raw=True: the DPT output (B, C, H, W) as it leaves the last convolution -- the fused adapter kernel
-        (vit_adapter_fwd) applies reg_dense_depth itself"""
-        out = self.dpt(tokens, image_size, imgs)
+        (vit_adapter_fwd) applies reg_dense_depth itself.  layers: DPTAdapter.forward"""
+        out = self.dpt(tokens, image_size, imgs, layers=layers)
         if self.kind == "pts3d" and not raw:
             return {"pts3d": reg_dense_depth_exp(out.permute(0, 2, 3, 1))}
         return out
@@ -882,25 +898,46 @@ class EncoderNoPoSplatMultiTokenStyle(nn.Module):
         x_op = self.cfg.opacity_mapping
         return 2 ** (x_op.initial + min(global_step / x_op.warm_up, 1) * (x_op.final - x_op.initial))
 
-    def _head_jobs(self, images: Tensor, dec_feat, sty_feat):
+    def _head_early_jobs(self, images: Tensor, hook_index: int, first: Tensor, rest: Optional[Tensor]):
+        """Serving: branch `hook_index` (0 .. 2) of the front end of the four heads that read the decoders' hooked features, as closures in the
+        order of `_head_jobs` (entries 0, 1, 3, 4; None where a head is not a DPT head).  first / rest: the hooked features of view 0 / views 1..
+        WITHOUT the trailing intrinsics token, as `_head_jobs` gets them."""
+        b, v, _, h, w = images.shape
+        def job(head, tok):
+            dpt = getattr(head, "dpt", None)
+            return (lambda: dpt.early(hook_index, tok.float(), (h, w))) if dpt is not None else None
+        jobs = [job(self.downstream_head1, first), job(self.gaussian_param_head, first), None]
+        if v > 1:
+            jobs += [job(self.downstream_head2, rest), job(self.gaussian_param_head2, rest)]
+        return jobs
+
+    def _head_early_job_appearance(self, images: Tensor, hook_index: int, tok: Tensor):
+        """the same for the appearance head (job 2 of `_head_jobs`): tok = the stylizer's hooked features (b, v, l, c) WITH the intrinsics token"""
+        b, v, _, h, w = images.shape
+        dpt = getattr(self.gaussian_appearance_head, "dpt", None)
+        return (lambda: dpt.early(hook_index, tok[:, :, :-1].flatten(0, 1).float(), (h, w))) if dpt is not None else None
+
+    def _head_jobs(self, images: Tensor, dec_feat, sty_feat, pre=None):
         """The head calls as a list of closures (they only depend on the trunk outputs).  The reference calls a head once per view
         (encoder_noposplat_multi_token_style.py:152-177: head1 for view 0, head2 for every other view, the appearance head for each view).
         The heads act on every sample independently, so the views that share a head go through it as ONE batch of b * (#views) samples:
         same results, a third of the launches at v = 4, and small-resolution layers that fill more of the chip."""
         b, v, _, h, w = images.shape
         fused = self.fused_adapter and images.is_cuda and w >= h
+        # pre[j]: per head j, the front-end branches a serving loop computed ahead (`_head_early_jobs`), or None
+        lay = lambda j: ({"layers": pre[j]} if (pre is not None and pre[j] is not None) else {})
         if fused:
-            mean_head = lambda head, toks: head(toks, (h, w), raw=True)       # (B, 3, h, w), reg_dense_depth in the kernel
+            mean_head = lambda head, toks, j=None: head(toks, (h, w), raw=True, **(lay(j) if j is not None else {}))       # (B, 3, h, w), reg_dense_depth in the kernel
         else:
-            mean_head = lambda head, toks: landscape_mean_head(head, toks, h, w)
+            mean_head = lambda head, toks, j=None: landscape_mean_head(head, toks, h, w)
         # (evaluated inside the job: at b > 1 this slice is a copy, and a job may be captured once and replayed on new images)
         rest_images = lambda: images[:, 1:].reshape(b * (v - 1), *images.shape[2:])
-        jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat]),
-                lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3]),
+        jobs = [lambda: mean_head(self.downstream_head1, [a.float() for a, _ in dec_feat], 0),
+                lambda: self.gaussian_param_head([a.float() for a, _ in dec_feat], (h, w), images[:, 0, :3], **lay(1)),
                 lambda: self.gaussian_appearance_head([t.flatten(0, 1).float() for t in sty_feat], (h, w))]
         if v > 1:
-            jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat]),
-                     lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest_images()[:, :3])]
+            jobs += [lambda: mean_head(self.downstream_head2, [r.float() for _, r in dec_feat], 3),
+                     lambda: self.gaussian_param_head2([r.float() for _, r in dec_feat], (h, w), rest_images()[:, :3], **lay(4))]
         return jobs
 
     def _heads_and_adapter(self, images: Tensor, dec_feat, sty_feat, global_step: int, visualization_dump, run_heads) -> Gaussians:

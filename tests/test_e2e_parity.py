@@ -116,6 +116,29 @@ def _rel(a, e, mask=None):
     return float(d.max() / max(np.abs(e).max(), 1e-30))
 
 
+def _edge_pixels(got, ref, ok, bar, limit=4):
+    """Pixels of an image comparison (b, v, c, H, W; ok: the generator's non-fragile mask, (b, v, 1, H, W)) that exceed `bar` although the
+    generator did not mask them, IDENTIFIED: every one of them must touch (8-neighbourhood) a pixel the float64 generator found within its
+    epsilon of a rasterizer decision (alpha >= 1/255, T > 1e-4, the 0.99 clamp) -- it lies on the same footprint edge, one pixel further out than
+    the generator's epsilon reached -- there may be at most `limit` of them per case (0.003 % of the image pair) and none may be off by more
+    than 10 % of the image scale.  Returns (the distance over all OTHER pixels, the list of pixels set aside).  Round 6: pixel (34, 37) of view 0
+    of the `full` fixture flips in 3 runs of 8 in bf16x6 since the batch-1 Linear layers run on csrc/vit_gemm_sm.hip (another summation order:
+    a different pixel sits on the threshold); its neighbours (35, 35) and (35, 36) are in the generator's mask."""
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    e = np.abs(got - ref) / scale * ok
+    over = np.argwhere(e.max(axis=2, keepdims=True) > bar)                  # (b, v, 0, y, x)
+    frag = ~np.broadcast_to(ok, e.shape[:2] + (1,) + e.shape[3:])
+    aside, keep = [], np.ones(e.shape[:2] + (1,) + e.shape[3:], bool)
+    for b_, v_, _, y, x in over:
+        near = frag[b_, v_, 0, max(0, y - 1):y + 2, max(0, x - 1):x + 2].any()
+        aside.append((int(v_), int(y), int(x), float(e[b_, v_, :, y, x].max()), bool(near)))
+        keep[b_, v_, 0, y, x] = False
+    assert len(aside) <= limit, ("too many pixels above the bar outside the generator's mask", aside[:12])
+    assert all(n and val <= 0.1 for *_, val, n in aside), ("a pixel above the bar touches no discontinuity the generator found", aside)
+    return float((e * keep).max()), aside
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3", "f16x3"])      # f16x3: the fp16 two-piece split -- the bars of bf16x6 at the MFMA count of bf16x3
 @pytest.mark.parametrize("tag", TAGS)
@@ -168,9 +191,13 @@ def test_e2e_render_and_gradients_match_the_float64_reference_chain(tag, mode, m
         np.savez_compressed(f"{os.environ['E2E_DUMP']}_{tag}_{mode}.npz", color=color, depth=out.depth.detach().cpu().numpy(),
                             means=gs.means.detach().cpu().numpy(), opac=gs.opacities.detach().cpu().numpy(),
                             cov=gs.covariances.detach().cpu().numpy(), sh=gs.harmonics.detach().cpu().numpy())
-    rep["color"] = _rel(color, G["color"], ok)
+    n32_ = lambda k: float(G["fp32noise:" + k]) if "fp32noise:" + k in G.files else float("nan")
+    img_bar = lambda k: (max(1e-4, float(G["tf32noise:" + k])) if mode == "bf16x3" else max(1e-4, 2.0 * n32_(k)))       # (= bar(k) below, for the two images)
+    rep["color"], edge_c = _edge_pixels(color, G["color"], ok, img_bar("color"))
     rep["color_all"] = _rel(color, G["color"])
-    rep["depth"] = _rel(out.depth.detach().cpu().numpy(), G["depth"], ok[:, :, 0])
+    rep["depth"], edge_d = _edge_pixels(out.depth.detach().cpu().numpy()[:, :, None], G["depth"][:, :, None], ok, img_bar("depth"))
+    if edge_c or edge_d:
+        print(f"  [{tag} {mode}] pixels set aside (view, y, x, distance, touches the generator's mask): colour {edge_c} depth {edge_d}")
     rep["loss"] = abs(float(loss.detach()) - float(G["loss"])) / abs(float(G["loss"]))
     # Per-Gaussian gradients at the 4 096 sampled Gaussians.  Like pixels, single Gaussians sit on discontinuities of the rasterizer -- the integer
     # radius ceil(3 sqrt(lambda)) and with it the tile rectangle, and the clamp-at-zero of an SH colour channel (its gradient is off while clamped) --

@@ -21,6 +21,11 @@ ctx = dict(image=torch.rand(1, 2, 3, H, H, device=dev, generator=g) * 2 - 1, int
 style = dict(image=ctx["image"][:, 0])
 with torch.no_grad():
     enc(ctx, style, 0)
+import os
+StreamGraphedEncoder.early_heads = os.environ.get("EARLY_HEADS", "1") == "1"
+StreamGraphedEncoder.early_appearance = os.environ.get("EARLY_APP", "1") == "1"
+if os.environ.get("HEAD_ORDER"):
+    StreamGraphedEncoder.HEAD_ORDER = tuple(int(c) for c in os.environ["HEAD_ORDER"])
 ge = StreamGraphedEncoder(enc, ctx, style)
 E = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -35,12 +40,37 @@ def run(self, marks):
     with torch.cuda.stream(self.s_style):
         self.g_se.replay(); mark("style_encode_end", self.s_style)
     self.g_be.replay(); mark("backbone_encode_end")
+
+    def app_early(i, after):
+        if i < len(self.g_app_early) and self.g_app_early[i] is not None:
+            self.s_heads[2].wait_stream(after)
+            with torch.cuda.stream(self.s_heads[2]):
+                self.g_app_early[i].replay()
+    app_early(0, main)
     self.s_style.wait_stream(main)
     with torch.cuda.stream(self.s_style):
-        self.g_sd.replay(); mark("stylizer_end", self.s_style)
+        self.g_sd_begin.replay()
+    for k, g in enumerate(self.g_sd):
+        with torch.cuda.stream(self.s_style):
+            g.replay()
+        if k + 1 < len(self.g_sd):
+            app_early(k + 1, self.s_style)
+    with torch.cuda.stream(self.s_style):
+        self.g_sd_end.replay(); mark("stylizer_end", self.s_style)
     self.g_dpre.replay()
     if getattr(self, "g_dpair", None) is not None:
-        self.g_dpair.replay()
+        def early(i):
+            if i < len(self.g_early):
+                for j in self.HEAD_ORDER:
+                    if j < len(self.g_early[i]) and self.g_early[i][j] is not None:
+                        self.s_heads[j].wait_stream(main)
+                        with torch.cuda.stream(self.s_heads[j]):
+                            self.g_early[i][j].replay()
+        early(0)
+        for k, g in enumerate(self.g_dpair):
+            g.replay()
+            if k + 1 < len(self.g_dpair):
+                early(k + 1)
     for g1, g2 in zip(self.g_d1, self.g_d2):
         self.s_dec2.wait_stream(main)
         with torch.cuda.stream(self.s_dec2):
@@ -49,7 +79,7 @@ def run(self, marks):
         main.wait_stream(self.s_dec2)
     self.g_dpost.replay(); mark("decoders_end")
     main.wait_stream(self.s_style); mark("join_style")
-    order = [i for i in (1, 4, 2, 0, 3) if i < len(self.g_heads)]
+    order = [i for i in self.HEAD_ORDER if i < len(self.g_heads)]
     for i in order:
         s, gg = self.s_heads[i], self.g_heads[i]
         s.wait_stream(main)
@@ -71,4 +101,4 @@ with torch.no_grad():
             ev = m[0]
             for k, e in ev.items():
                 acc[k] = acc.get(k, 0.0) + ev["t0"].elapsed_time(e)
-print(json.dumps({"mode": vit_ops.LINEAR_MODE, "small_m_rows": vit_ops.SMALL_M_ROWS, "ms_since_start": {k: round(v / steps, 3) for k, v in acc.items()}}))
+print(json.dumps({"mode": vit_ops.LINEAR_MODE, "small_m_rows": vit_ops.SMALL_M_ROWS, "early_heads": StreamGraphedEncoder.early_heads, "early_app": StreamGraphedEncoder.early_appearance, "order": StreamGraphedEncoder.HEAD_ORDER, "ms_since_start": {k: round(v / steps, 3) for k, v in acc.items()}}))
