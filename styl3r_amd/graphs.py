@@ -57,7 +57,8 @@ class StreamGraphedEncoder:
 
     HEAD_ORDER = (2, 1, 4, 0, 3)      # launch order of the head jobs: the appearance head (two views per call) and the Gaussian-parameter heads first
     early_heads = True                # the heads' front-end branches start as soon as their decoder layer is done (A/B switch)
-XX
+    early_appearance = False          # ... the appearance head's too (it hooks into the stylizer's decoder): built, measured, off -- same box, f16x3:
+    #                                   none 13.32 / 13.32 ms, decoder-fed heads only 12.97 / 13.09, all five 13.32 / 13.53 (tools/probes/infer_phases.py)
 
     def __init__(self, encoder: nn.Module, context: dict, style: dict, global_step: int = 0, warmup: int = 2):
         enc = self.encoder = encoder.eval()

@@ -622,9 +622,11 @@ def test_layernorm_kernels_match_fp64_with_and_without_skip(shape, bias):
     assert torch.equal(grads(), grads())
 
 
-def test_no_grad_fast_paths_equal_the_autograd_paths():
-    """serving: under no_grad fused_linear and LayerNorm skip the autograd node and go straight to the kernels; the
-    results are the same bits as the autograd path's forward (same kernels, same arguments)"""
+def test_no_grad_fast_paths_equal_the_autograd_paths(monkeypatch):
+    """serving: under no_grad fused_linear and LayerNorm skip the autograd node and go straight to the kernels; with the same kernel behind
+    both paths (round 6: at up to 1 024 rows the no-grad Linear takes csrc/vit_gemm_sm.hip, the autograd path keeps the 128-row kernel --
+    vit_ops._ring_cfg) the results are the same bits as the autograd path's forward; with the small-M kernel they agree to fp32 round-off"""
+    from styl3r_amd import vit_ops
     from styl3r_amd.vit_ops import LayerNorm, fused_linear
     torch.manual_seed(11)
     x = torch.randn(3, 257, 1024, device=DEV)
@@ -635,7 +637,12 @@ def test_no_grad_fast_paths_equal_the_autograd_paths():
     with torch.no_grad():
         got_lin, got_ln = fused_linear(x, w, b, r, gelu=True), ln(x)
         got_t = fused_linear(x.transpose(0, 1), w, b)              # non-contiguous input
-    assert torch.equal(got_lin, want_lin.detach()) and torch.equal(got_ln, want_ln.detach())
+    assert torch.equal(got_ln, want_ln.detach())
+    assert float((got_lin - want_lin.detach()).abs().max()) <= 2e-6 * float(want_lin.abs().max())         # (two kernels: another summation order)
+    monkeypatch.setattr(vit_ops, "SMALL_M_ROWS", 0)
+    with torch.no_grad():
+        assert torch.equal(fused_linear(x, w, b, r, gelu=True), want_lin.detach())                          # the same kernel behind both paths: the same bits
+    monkeypatch.setattr(vit_ops, "SMALL_M_ROWS", 1024)
     # (this small GEMM splits K across workgroups with fp32 atomics: equal up to the summation order)
     assert torch.allclose(got_t, fused_linear(xg.transpose(0, 1), w, b).detach(), rtol=1e-5, atol=1e-5)
 
