@@ -776,17 +776,6 @@ def infer_leg(args, dev):
         rec["views_per_s"] = round(v_tgt * 1e3 / rec["total_ms"], 2)
         return rec
 
-    def ab_round5_launch_forms(mode):
-        """same box, same process: the stream-graph forward with the round-6 serving kernels switched off (the small-M Linear kernel and the
-        two-problem launches of the dual decoders) -- the 128-row split-contraction kernels and one stream per decoder, as in round 5"""
-        keep = vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches
-        vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches = 0, False
-        try:
-            return timed(mode)["stream_graphs_total_ms"]
-        finally:
-            vit_ops.SMALL_M_ROWS, type(enc.backbone).pair_launches = keep
-            vit_ops._x6()
-
     # top level: f16x3, the arithmetic of the train leg's headline (fp32-class accuracy: tests/test_gpu_vit.py measures it at or below bf16x6's error
     # against float64) ; bf16x6 = six products, the mode rounds 1 - 5 quoted here; bf16x3 = the TF32-class mode (tests/test_e2e_parity.py bounds all three)
     out = {"metric": "C2 inference latency, 2 ctx + 3 tgt views 256x256, forward only, batch 1", **timed("f16x3"), "steps": steps,
@@ -794,10 +783,6 @@ def infer_leg(args, dev):
            "encoder_launch": "total_ms / stream_graphs_total_ms: one hipGraph per stream segment (style branch and the five heads on side streams, the dual decoders "
                              "as two-problem launches on the main stream); eager_total_ms: the same forward launched kernel by kernel (host-bound: ~1 400 launches)",
            "dtype": "f32", "data": "synthetic, random-init weights"}
-    try:
-        out["stream_graphs_ms_with_the_round5_launch_forms"] = {m: ab_round5_launch_forms(m) for m in ("f16x3", "bf16x6")}
-    except Exception as e:
-        out["stream_graphs_ms_with_the_round5_launch_forms"] = f"{type(e).__name__}: {e}"[:200]
     # `test.align_pose` (config/main.yaml:57-60, model_wrapper_style.py:391-447): before the evaluation render the reference optimises the 3 target
     # poses for pose_align_steps = 100 Adam steps, each one a rasterizer forward + backward with pose gradients (theta / rho) on the 3 views.
     # Timed on a scene the heads were re-centred for (a random-init encoder renders nothing), from poses perturbed by ~1 degree / 1 % of the baseline.

@@ -24,6 +24,8 @@ with torch.no_grad():
 import os
 StreamGraphedEncoder.early_heads = os.environ.get("EARLY_HEADS", "1") == "1"
 StreamGraphedEncoder.early_appearance = os.environ.get("EARLY_APP", "1") == "1"
+if os.environ.get("PAIR") == "0":
+    type(enc.backbone).pair_launches = False
 if os.environ.get("HEAD_ORDER"):
     StreamGraphedEncoder.HEAD_ORDER = tuple(int(c) for c in os.environ["HEAD_ORDER"])
 ge = StreamGraphedEncoder(enc, ctx, style)
@@ -101,4 +103,4 @@ with torch.no_grad():
             ev = m[0]
             for k, e in ev.items():
                 acc[k] = acc.get(k, 0.0) + ev["t0"].elapsed_time(e)
-print(json.dumps({"mode": vit_ops.LINEAR_MODE, "small_m_rows": vit_ops.SMALL_M_ROWS, "early_heads": StreamGraphedEncoder.early_heads, "early_app": StreamGraphedEncoder.early_appearance, "order": StreamGraphedEncoder.HEAD_ORDER, "ms_since_start": {k: round(v / steps, 3) for k, v in acc.items()}}))
+print(json.dumps({"mode": vit_ops.LINEAR_MODE, "small_m_rows": vit_ops.SMALL_M_ROWS, "pair_path": ge.g_dpair is not None, "early_heads": StreamGraphedEncoder.early_heads, "early_app": StreamGraphedEncoder.early_appearance, "order": StreamGraphedEncoder.HEAD_ORDER, "ms_since_start": {k: round(v / steps, 3) for k, v in acc.items()}}))
