@@ -23,6 +23,9 @@ if os.environ.get("BIG"):      # the train-step row counts: is the barrier-free 
     shapes = dict(enc_qkv=(Mb, 3072, 1024), enc_proj=(Mb, 1024, 1024), enc_fc1=(Mb, 4096, 1024), enc_fc2=(Mb, 1024, 4096),
                   dec_qkv=(Mb // 2, 2304, 768), dec_proj=(Mb // 2, 768, 768), dec_fc1=(Mb // 2, 3072, 768), dec_fc2=(Mb // 2, 768, 3072))
 MAXR = 1 << 20 if os.environ.get("BIG") else 1024
+if os.environ.get("SHAPES"):
+    shapes = {k: v for k, v in shapes.items() if k in os.environ["SHAPES"].split(",")}
+CONFIGS = ((0, 0),) if os.environ.get("RULE_ONLY") else ((1, 4), (1, 8), (2, 4), (2, 8), (0, 0))
 _w = torch.randn(4096, 4096, device=dev)
 for _ in range(200): _w @ _w
 torch.cuda.synchronize()
@@ -33,6 +36,12 @@ def timeit(fns, iters=240, warm=24):
     n = len(fns)
     for i in range(warm): fns[i % n]()
     torch.cuda.synchronize()
+    if os.environ.get("LAB_EAGER"):                      # (counter collection: plain launches, few of them)
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for i in range(24): fns[i % n]()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 24 * 1e3
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for i in range(iters): fns[i % n]()
@@ -70,7 +79,7 @@ for mode in modes:
         row = dict(mode=mode, shape=name, M=M, N=N, K=K, act=ACT, weight_copies=copies)
         fns[0](); row["err_old"] = float((out.double() - ref).abs().max() / ref.abs().max())
         row["old_us"] = round(timeit(fns), 2)
-        for tm, nw in ((1, 4), (1, 8), (2, 4), (2, 8), (0, 0)):
+        for tm, nw in CONFIGS:
             assert lib.vit_linear_sm_set(MAXR, tm, nw) == 0
             if not lib.vit_linear_sm_ok(M, N, K): continue
             fsm[0](); e = float((out.double() - ref).abs().max() / ref.abs().max())
