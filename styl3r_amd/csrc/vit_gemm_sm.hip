@@ -1,6 +1,8 @@
-// vit_gemm_sm.hip -- the split-arithmetic Linear for SMALL row counts (M <= ~1 000: batch-1 serving, C2: 257 / 514 token rows).
+// vit_gemm_sm.hip -- the split-arithmetic Linear for SMALL row counts (M <= ~1 000: batch-1 serving, C2: 257 / 514 token rows) and, at any row count,
+// for NARROW outputs (N <= 768: the decoders' proj / projq / projk / projv / fc2 and the input-gradient GEMMs of their qkv / fc1 in the train step).
+// Reached through vit_linear_x6r_fwd with cfg = 5 (one problem) and vit_linear_sm_grouped (two problems of one shape: the dual decoders).
 //
-//     out (M,N) = [residual +] act( x (M,K) . w^T (N,K) + bias )            same operands, weight image and epilogue as vit_gemm_x6.hip
+//     out (M,N) = [residual +] act( x (M,K) . w^T (N,K) + bias )            same operands, split functions and epilogue as vit_gemm_x6.hip; BLOCK weight image
 //
 // What is different from k_linear_x6 (128-row tiles, LDS-staged operands, a barrier pair per 16-deep slab, split-K through fp32 atomics into a
 // zero-filled output when the tiles cannot fill the chip -- at M = 257 / 514 that is a zero-fill launch, 640 workgroups of 8 slabs each, 128-row

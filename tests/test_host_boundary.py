@@ -214,3 +214,31 @@ def test_swap_reductions_add_both_results(tmp_path):
         assert any((mm := re.search(r"v_add_f32\S* v\d+, (v\d+), (v\d+)", lines[k])) and {mm.group(1), mm.group(2)} == regs
                    for k in range(i + 1, min(i + 20, len(lines)))), f"swap at line {i}: no v_add_f32 of both results: {line.strip()}"
     assert swaps == 14, swaps
+
+
+def test_small_m_linear_main_loop_keeps_its_loads_in_flight(tmp_path):
+    """csrc/vit_gemm_sm.hip lives on its software pipeline: the first version was correct and 2 x slower than the kernel it replaced because hipcc
+    hoisted the (pure) MFMAs over the scheduling barriers and sank every global load to its first use (DESIGN R6.7).  This compiles the file to
+    gfx950 assembly with the product's flags (no GPU needed) and checks, in the main loop of the encoder-shape instantiation (64-row tiles,
+    4 waves, f16x3): no workgroup barrier, no scratch, 48 MFMAs and 32 global loads per two-stage body, and a counted `s_waitcnt vmcnt(N)` with
+    N >= 16 in front of the first MFMA -- at least two of the three load groups behind it are still in flight."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if Path("/opt/rocm/bin/hipcc").exists() else None)
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    src = Path(_lib.__file__).resolve().parent / "csrc" / "vit_gemm_sm.hip"
+    out = tmp_path / "vit_gemm_sm.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fvisibility=hidden", "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                   check=True, capture_output=True)
+    text = out.read_text()
+    start = text.index("_ZN3vit2sm11k_linear_smILi2ELi4ELi2EEEvNS0_6SmArgsE:")
+    body = text[start:text.index("s_endpgm", start)]
+    assert "scratch_" not in body
+    loop = body[body.index("Inner Loop Header"):]
+    loop = loop[:re.search(r"s_cbranch_\w+ \.LBB\d+_\d+", loop).end()]
+    assert "s_barrier" not in loop
+    assert len(re.findall(r"v_mfma_f32_32x32x16_f16", loop)) == 48
+    assert len(re.findall(r"global_load_dwordx4", loop)) == 32
+    first_mfma = loop.index("v_mfma_f32_32x32x16_f16")
+    waits = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop[:first_mfma])]
+    assert waits and min(waits) >= 16, waits
