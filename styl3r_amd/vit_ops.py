@@ -1429,6 +1429,9 @@ def _ring_cfg(M: int, N: int, K: int) -> int:
     # `fused_linear` asks `small_m_kernel` itself: nothing trains at 257 / 514 rows except the parity fixtures, and those were recorded against the
     # summation order of the 128-row kernels: with the small-M kernel in their forward the c3 fixture's style-encoder gradients sit in the
     # flip-prone state of DESIGN 9 (3) in EVERY run instead of two runs in five -- profiles/r06_c3_stylizer_rows_ab.txt)
+    # (tried and dropped: every served shape at 1 024 < M < 2 048 -- the C4 style stage's 1 536-row style encoder, whose 1024-wide layers are
+    #  split-contraction launches of the 128-row kernel.  The kernel lab says -9 .. -40 % per launch there, the C4 step says 374.6 -> 378.8 / 384.5 ms:
+    #  profiles/r06_mid_rows_ab.jsonl, profiles/r06_small_linear_lab_m1536.txt)
     if M > SMALL_M_ROWS and narrow_n_kernel(M, N, K):
         return 5
     if not RING_DISPATCH or M < 2048:
