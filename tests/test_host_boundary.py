@@ -242,3 +242,52 @@ def test_small_m_linear_main_loop_keeps_its_loads_in_flight(tmp_path):
     first_mfma = loop.index("v_mfma_f32_32x32x16_f16")
     waits = [int(n) for n in re.findall(r"s_waitcnt vmcnt\((\d+)\)", loop[:first_mfma])]
     assert waits and min(waits) >= 16, waits
+
+
+def test_derived_weight_cache_follows_the_parameter_version_and_stays_in_the_graph_when_training():
+    """vit_ops.derived_weight (serving: reshaped / permuted / padded weights are built once per parameter version so that their split images stay
+    cached; training: the derivation is part of the autograd graph)"""
+    import torch
+    from styl3r_amd.vit_ops import derived_weight
+    w = torch.nn.Parameter(torch.arange(12.0).reshape(3, 4))
+    fn = lambda t: t.t().contiguous()
+    with torch.no_grad():
+        a = derived_weight(w, "t", fn)
+        assert derived_weight(w, "t", fn) is a and torch.equal(a, w.detach().t())
+        assert derived_weight(w, "other", lambda t: t.reshape(4, 3)) is not a                      # another tag, another tensor
+        w.add_(1.0)                                                                                 # an optimizer step: the version moves
+        b = derived_weight(w, "t", fn)
+        assert b is not a and torch.equal(b, w.detach().t())
+    c = derived_weight(w, "t", fn)                                                                  # grad mode, trainable: recomputed, differentiable
+    assert c.requires_grad and c is not b
+    c.sum().backward()
+    assert torch.equal(w.grad, torch.ones_like(w))
+    w.requires_grad_(False)                                                                         # frozen (C4 style stage): the cache serves grad mode too
+    assert derived_weight(w, "t", fn) is b
+    assert derived_weight(None, "t", fn) is None
+
+
+def test_edge_pixel_rule_of_the_e2e_image_comparison():
+    """tests/test_e2e_parity.py::_edge_pixels: a pixel above the bar is set aside only if it touches the generator's fragile mask; more than four,
+    or one that touches nothing, or one off by more than 10 % of the image scale is an error"""
+    import numpy as np
+    from tests.test_e2e_parity import _edge_pixels
+    H = W = 16
+    ref = np.ones((1, 2, 3, H, W)); ref[0, 0, 0, 0, 0] = 2.0
+    ok = np.ones((1, 2, 1, H, W), bool); ok[0, 0, 0, 5, 5] = False                                  # one fragile pixel
+    got = ref.copy(); got[0, 0, 1, 4, 6] += 0.01                                                    # its diagonal neighbour is off by 5e-3 of the scale
+    rest, aside = _edge_pixels(got, ref, ok, bar=1e-3)
+    assert rest == 0.0 and len(aside) == 1 and aside[0][:3] == (0, 4, 6) and abs(aside[0][3] - 0.005) < 1e-12 and aside[0][4] is True
+    got[0, 0, 0, 5, 5] += 1.0                                                                        # the masked pixel itself never counts
+    assert _edge_pixels(got, ref, ok, bar=1e-3)[0] == 0.0
+    far = ref.copy(); far[0, 1, 0, 10, 10] += 0.01                                                   # touches no fragile pixel
+    with pytest.raises(AssertionError):
+        _edge_pixels(far, ref, ok, bar=1e-3)
+    big = ref.copy(); big[0, 0, 1, 4, 6] += 0.5                                                      # 25 % of the scale
+    with pytest.raises(AssertionError):
+        _edge_pixels(big, ref, ok, bar=1e-3)
+    many = ref.copy()
+    for dy, dx in ((-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1)):
+        many[0, 0, 2, 5 + dy, 5 + dx] += 0.01
+    with pytest.raises(AssertionError):
+        _edge_pixels(many, ref, ok, bar=1e-3)
